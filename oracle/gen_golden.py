@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""ORACLE / TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz (build container only).
+
+Runs the REFERENCE'S OWN source (``/root/reference/seqikpy``: ``LegInvKinSeq``,
+``LegInvKinGeneric``, ``KinematicChainSeq``, ``KinematicChainGeneric``,
+``AlignPose``) unmodified, over the build-owned ``ikpy`` shim + the container's real
+scipy (``oracle/ref_import.py``), and cuts the reference's shipped data files
+(inputs and shipped pipeline outputs) into small fixtures.  A fixture is data only:
+inputs, expected outputs, and the per-leg parameter arrays (segment lengths, bounds,
+seeds) that the run used.  Nothing here travels to the GPU box except the .npz files.
+
+    python oracle/gen_golden.py [--only NAME ...]
+
+Fixtures (all float64 unless noted; DOF order = c_oracle.DOFS):
+  anipose_shipped.npz   pose RF/LF (6000,5,3) from pose3d_aligned.pkl; shipped
+                        leg_joint_angles.pkl as (6000,7) per leg; shipped
+                        forward_kinematics.pkl cut to frames 0:100 and 250:330
+  anipose_scipy_cut.npz reference source run here on frames 0:330 (RF, LF):
+                        angles, fk, scipy status / nfev per (frame, stage)
+  df3d_100.npz          shipped df3d pose3d_aligned.pkl (6 legs x 100) + reference run here
+  df3d_1000.npz         full 1000-frame df3d recording aligned here with the
+                        reference's AlignPose + reference run here
+  generic_rf_100.npz    LegInvKinGeneric on anipose RF frames 0:100, run here
+"""
+import argparse
+import importlib.util
+import multiprocessing as mp
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_import import REFERENCE_ROOT, import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+DOFS = ["ThC_yaw", "ThC_pitch", "ThC_roll", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
+SEGMENTS = ["Coxa", "Femur", "Tibia", "Tarsus"]
+ANIPOSE = os.path.join(REFERENCE_ROOT, "data", "anipose_220525_aJO_Fly001_001", "pose-3d")
+DF3D = os.path.join(REFERENCE_ROOT, "data", "df3d_pose_result__210902_PR_Fly1")
+CUT = np.r_[0:100, 250:330]
+
+
+def load_pickle(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def locomotion_constants():
+    """BOUNDS/INITIAL_ANGLES/TEMPLATE of the locomotion example (data only; the module's
+    work is under ``if __name__ == '__main__'``: examples/example_leg_inv_kinematics_parallel.py:21-140)."""
+    import_reference()
+    path = os.path.join(REFERENCE_ROOT, "examples", "example_leg_inv_kinematics_parallel.py")
+    spec = importlib.util.spec_from_file_location("_ref_example_parallel", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.TEMPLATE_NMF_LOCOMOTION, mod.INITIAL_ANGLES_LOCOMOTION, mod.BOUNDS_LOCOMOTION
+
+
+def leg_param_arrays(leg, bounds_dof, body_size, initial_angles):
+    seg = np.array([body_size[f"{leg}_{s}"] for s in SEGMENTS], dtype=np.float64)
+    bounds = np.array([bounds_dof[f"{leg}_{d}"] for d in DOFS], dtype=np.float64)
+    seeds = np.concatenate([np.asarray(initial_angles[leg][f"stage_{k}"], dtype=np.float64) for k in (1, 2, 3, 4)])
+    return seg, bounds, seeds
+
+
+def _run_one_leg(args):
+    """Worker: the reference's LegInvKinSeq / LegInvKinGeneric on one leg (cf. worker_wrapper,
+    examples/example_leg_inv_kinematics_parallel.py:143-160)."""
+    kind, leg, pose, bounds_dof, body_size, initial_angles = args
+    import_reference()
+    from ikpy.chain import Chain
+    from seqikpy.kinematic_chain import KinematicChainGeneric, KinematicChainSeq
+    from seqikpy.leg_inverse_kinematics import LegInvKinGeneric, LegInvKinSeq
+    Chain.solve_log = []
+    aligned = {f"{leg}_leg": pose}
+    if kind == "seq":
+        ik = LegInvKinSeq(aligned, KinematicChainSeq(bounds_dof, [leg], body_size), initial_angles, log_level="ERROR")
+    else:
+        ik = LegInvKinGeneric(aligned, KinematicChainGeneric(bounds_dof, [leg], body_size), initial_angles,
+                              log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk(hide_progress_bar=True)
+    n = pose.shape[0]
+    angles = np.stack([ang[f"Angle_{leg}_{d}"] for d in DOFS], axis=1)
+    log = np.asarray(Chain.solve_log, dtype=np.int32)
+    if kind == "seq":
+        log = log.reshape(4, n, 2).transpose(1, 0, 2)  # reference loop order is stage-major
+    else:
+        log = log.reshape(n, 1, 2)
+    return leg, angles, fk[f"{leg}_leg"], log[..., 0].copy(), log[..., 1].copy()
+
+
+def run_reference(kind, poses, bounds_dof, body_size, initial_angles, procs=6):
+    jobs = [(kind, leg, pose, bounds_dof, body_size, initial_angles) for leg, pose in poses.items()]
+    t0 = time.time()
+    with mp.Pool(min(procs, len(jobs))) as pool:
+        res = pool.map(_run_one_leg, jobs)
+    dt = time.time() - t0
+    out = {}
+    for leg, angles, fk, status, nfev in res:
+        seg, bounds, seeds = leg_param_arrays(leg, bounds_dof, body_size, initial_angles)
+        out.update({f"{leg}_pose": poses[leg], f"{leg}_angles": angles, f"{leg}_fk": fk,
+                    f"{leg}_status": status, f"{leg}_nfev": nfev,
+                    f"{leg}_seg": seg, f"{leg}_bounds": bounds, f"{leg}_seeds": seeds})
+    out["legs"] = np.array(list(poses.keys()))
+    out["ref_seconds"] = np.float64(dt)
+    return out
+
+
+def gen_anipose_shipped():
+    import_reference()
+    from seqikpy.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
+    from seqikpy.utils import calculate_body_size
+    pose = load_pickle(os.path.join(ANIPOSE, "pose3d_aligned.pkl"))
+    gold = load_pickle(os.path.join(ANIPOSE, "leg_joint_angles.pkl"))
+    gfk = load_pickle(os.path.join(ANIPOSE, "forward_kinematics.pkl"))
+    body = calculate_body_size(NMF_TEMPLATE, ["RF", "LF"])
+    out = {"legs": np.array(["RF", "LF"]), "fk_frames": CUT}
+    for leg in ("RF", "LF"):
+        seg, bounds, seeds = leg_param_arrays(leg, BOUNDS, body, INITIAL_ANGLES)
+        out.update({f"{leg}_pose": pose[f"{leg}_leg"],
+                    f"{leg}_angles": np.stack([gold[f"Angle_{leg}_{d}"] for d in DOFS], axis=1),
+                    f"{leg}_fk_cut": gfk[f"{leg}_leg"][CUT],
+                    f"{leg}_seg": seg, f"{leg}_bounds": bounds, f"{leg}_seeds": seeds})
+    return out
+
+
+def gen_anipose_scipy_cut():
+    import_reference()
+    from seqikpy.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
+    from seqikpy.utils import calculate_body_size
+    pose = load_pickle(os.path.join(ANIPOSE, "pose3d_aligned.pkl"))
+    body = calculate_body_size(NMF_TEMPLATE, ["RF", "LF"])
+    poses = {leg: pose[f"{leg}_leg"][:330].copy() for leg in ("RF", "LF")}
+    return run_reference("seq", poses, BOUNDS, body, INITIAL_ANGLES)
+
+
+def gen_df3d_100():
+    import_reference()
+    from seqikpy.utils import calculate_body_size
+    template, init, bounds = locomotion_constants()
+    legs = ["RF", "RM", "RH", "LF", "LM", "LH"]
+    pose = load_pickle(os.path.join(DF3D, "pose3d_aligned.pkl"))
+    poses = {leg: pose[f"{leg}_leg"] for leg in legs}
+    return run_reference("seq", poses, bounds, calculate_body_size(template, legs), init)
+
+
+def gen_df3d_1000():
+    """Config 2: the full locomotion recording, aligned as in seqikpy_locomotion.ipynb cells 2-6
+    but without the 300:400 cut."""
+    import_reference()
+    from seqikpy.alignment import AlignPose, convert_from_df3dpp_to_dict
+    from seqikpy.utils import calculate_body_size
+    template, init, bounds = locomotion_constants()
+    legs = ["RF", "RM", "RH", "LF", "LM", "LH"]
+    raw = load_pickle(os.path.join(DF3D, "pose_result__210902_PR_Fly1_aligned.pkl"))
+    converted = convert_from_df3dpp_to_dict(raw)
+    align = AlignPose(pose_data_dict=converted, legs_list=legs, include_claw=False,
+                      body_template=template, body_size=None, log_level="ERROR")
+    aligned = align.align_pose(export_path=None)
+    poses = {leg: np.ascontiguousarray(aligned[f"{leg}_leg"], dtype=np.float64) for leg in legs}
+    out = run_reference("seq", poses, bounds, calculate_body_size(template, legs), init)
+    for leg in legs:  # also keep the un-aligned key points: input of the alignment row
+        out[f"{leg}_raw"] = np.ascontiguousarray(converted[f"{leg}_leg"], dtype=np.float64)
+    return out
+
+
+def gen_generic_rf_100():
+    import_reference()
+    from seqikpy.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
+    from seqikpy.utils import calculate_body_size
+    pose = load_pickle(os.path.join(ANIPOSE, "pose3d_aligned.pkl"))
+    body = calculate_body_size(NMF_TEMPLATE, ["RF", "LF"])
+    poses = {leg: pose[f"{leg}_leg"][:100].copy() for leg in ("RF", "LF")}
+    return run_reference("generic", poses, BOUNDS, body, INITIAL_ANGLES)
+
+
+GENERATORS = {
+    "anipose_shipped": gen_anipose_shipped,
+    "anipose_scipy_cut": gen_anipose_scipy_cut,
+    "df3d_100": gen_df3d_100,
+    "df3d_1000": gen_df3d_1000,
+    "generic_rf_100": gen_generic_rf_100,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in GENERATORS.items():
+        if args.only and name not in args.only:
+            continue
+        t0 = time.time()
+        data = fn()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **data)
+        print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB in {time.time() - t0:.1f} s")
+
+
+if __name__ == "__main__":
+    main()
