@@ -1,0 +1,122 @@
+/*
+ * seqik.h -- C ABI of libseqik_hip.so: batched sequential leg inverse kinematics on
+ * AMD Instinct MI355X (gfx950).
+ *
+ * The reference (NeLy-EPFL/sequential-inverse-kinematics, `seqikpy` 1.0.2) is pure
+ * Python and has no FFI; its narrowest seam for this path is the per-frame pair
+ *     LegInvKinBase.calculate_ik(chain, target_pos, initial_angles)
+ *     LegInvKinBase.calculate_fk(chain, joint_angles)
+ *         seqikpy/leg_inverse_kinematics.py:62-77
+ * called from the serial frame loop of
+ *     LegInvKinSeq.calculate_ik_stage         seqikpy/leg_inverse_kinematics.py:200-322
+ * under
+ *     LegInvKinSeq.run_ik_and_fk              seqikpy/leg_inverse_kinematics.py:324-403
+ * with chains built by
+ *     KinematicChainSeq.create_leg_chain_stage_1..4   seqikpy/kinematic_chain.py:152-421.
+ * A batched replacement has to sit at the run_ik_and_fk level: the entry points
+ * below take whole recordings (sequences x legs x frames) and return what
+ * run_ik_and_fk returns.  INTEGRATION.md shows the ctypes binding a seqikpy
+ * maintainer would add.
+ *
+ * Conventions: plain pointers and sizes, all arrays dense C order, float64 unless
+ * noted; the caller owns every buffer; nothing is retained after return.  Functions
+ * return 0 on success or a negative SEQIK_ERR_* code; seqik_last_error() gives a
+ * thread-local message.  The host wrapper maps SEQIK_ERR_X0_OUT_OF_BOUNDS /
+ * SEQIK_ERR_BAD_BOUNDS / SEQIK_ERR_BAD_STAGE to ValueError, the exception type the
+ * reference raises in those cases (scipy least_squares: "Initial guess is outside of
+ * provided bounds"; seqikpy/leg_inverse_kinematics.py:232-236, 350-353).
+ */
+#ifndef SEQIK_H
+#define SEQIK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEQIK_ABI_VERSION 1
+
+#define SEQIK_OK 0
+#define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
+#define SEQIK_ERR_X0_OUT_OF_BOUNDS (-2)  /* a stage seed lies outside its [lb, ub] */
+#define SEQIK_ERR_BAD_BOUNDS (-3)        /* lb >= ub for some joint */
+#define SEQIK_ERR_BAD_ARG (-4)           /* null pointer, negative size, ... */
+#define SEQIK_ERR_BAD_STAGE (-5)         /* stages not within 1..4 / not consecutive */
+
+/* Joint (DOF) order used by every angle array of this ABI.  Axis naming follows the
+ * reference: "yaw" = rotation about X, "pitch" about Y, "roll" about Z
+ * (seqikpy/kinematic_chain.py:176,184,237). */
+enum {
+    SEQIK_DOF_THC_YAW = 0,
+    SEQIK_DOF_THC_PITCH = 1,
+    SEQIK_DOF_THC_ROLL = 2,
+    SEQIK_DOF_CTR_PITCH = 3,
+    SEQIK_DOF_CTR_ROLL = 4,
+    SEQIK_DOF_FTI_PITCH = 5,
+    SEQIK_DOF_TITA_PITCH = 6,
+    SEQIK_NDOF = 7
+};
+
+/* Everything KinematicChainSeq + INITIAL_ANGLES hold for one leg:
+ *   seg     body_size["<leg>_Coxa|Femur|Tibia|Tarsus"]   (seqikpy/utils.py:89-123)
+ *   bounds  bounds_dof["<leg>_<dof>"] = (lb, ub), DOF order above (seqikpy/data.py:24-41)
+ *   seeds   initial_angles[leg]["stage_1".."stage_4"] concatenated: 4 + 6 + 8 + 9 values,
+ *           one per link of the stage chain (seqikpy/data.py:4-22)                        */
+typedef struct SeqikLegParams {
+    double seg[4];
+    double bounds[7][2];
+    double seeds[27];
+} SeqikLegParams;
+
+typedef struct SeqikOptions {
+    int32_t device;      /* HIP device ordinal (host-buffer entry point only) */
+    int32_t block_size;  /* threads per workgroup, multiple of 64; 0 = default (64) */
+    int32_t reserved[6];
+} SeqikOptions;
+
+int seqik_abi_version(void);
+int seqik_device_count(void);
+const char *seqik_last_error(void);
+
+/* Validates `legs` exactly as the reference would fail at frame 0 (bounds order,
+ * seeds inside bounds).  Returns SEQIK_OK or the error code; no GPU needed. */
+int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage);
+
+/*
+ * LegInvKinSeq.run_ik_and_fk for n_seq independent recordings ("sequences") of
+ * n_frames frames and n_legs legs each; HOST buffers, blocking.
+ *
+ *   pose    [n_seq][n_legs][n_frames][5][3]  aligned key points; row 0 = Thorax-Coxa origin,
+ *           row k = end effector of stage k  (aligned_pos["<leg>_leg"], leg_inverse_kinematics.py:371-375)
+ *   legs    [n_legs]
+ *   first_stage..last_stage  consecutive stages to run, 1 <= first <= last <= 4
+ *   angles  [n_seq][n_legs][n_frames][7]  in/out: columns of stages < first_stage are READ
+ *           (earlier results, as joint_angles_dict in the reference), columns of the stages run
+ *           are written, others untouched
+ *   fk      nullable [n_seq][n_legs][n_frames][9][3]; written only when last_stage == 4
+ *           (stage-4 forward kinematics + origin, leg_inverse_kinematics.py:279-282)
+ *   status, nfev  nullable int32 [n_seq][n_legs][n_frames][4]: scipy termination status /
+ *           trial-evaluation count per (frame, stage); requesting either costs one extra
+ *           Jacobian per solve
+ * Frame t of a chain is warm-started from frame t-1 of the same chain; frame 0 from the seeds.
+ */
+int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                    const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
+                    double *angles, double *fk, int32_t *status, int32_t *nfev,
+                    const SeqikOptions *opt);
+
+/*
+ * Same computation on DEVICE buffers of the current HIP device, enqueued on `hip_stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and NOT synchronised; `legs` is a
+ * host pointer (copied before return).  This is the entry point the benchmark times.
+ */
+int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                           const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
+                           double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
+                           const SeqikOptions *opt, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQIK_H */

@@ -1,0 +1,102 @@
+// seqik_consts.hpp -- host side: validation of SeqikLegParams and construction of the
+// per-(leg, stage) device constants.  Mirrors what the reference derives per stage in
+// KinematicChainSeq.create_leg_chain_stage_1..4 (seqikpy/kinematic_chain.py:152-421):
+// which links are revolute, their axes, translations and bounds.
+#pragma once
+#include "seqik_core.hpp"
+#include "../../include/seqik.h"
+
+namespace seqik {
+
+// links per stage chain and, per stage, the link index of the first active link
+static const int kStageLinks[4] = {4, 6, 8, 9};
+static const int kFirstActive[4] = {1, 3, 5, 7};
+static const int kNumActive[4] = {2, 2, 2, 1};
+static const int kSeedOffset[4] = {0, 4, 10, 18};
+
+// DOF whose bounds apply to link i of the stage-k chain (0 = base: unbounded; 8 = claw: +-pi)
+// stage chains list the DOFs in order yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa, except that
+// stage 1 ends with CTr_pitch and stage 2 ends with FTi_pitch (kinematic_chain.py:188-196, 250-257).
+inline int link_dof(int stage, int link)
+{
+    if (link == 0) return -1;
+    if (stage == 1) { static const int m[4] = {-1, 0, 1, 3}; return m[link]; }
+    if (stage == 2) { static const int m[6] = {-1, 0, 1, 2, 3, 5}; return m[link]; }
+    if (link == 8) return -2;  // claw
+    return link - 1;
+}
+
+inline void link_bounds(const SeqikLegParams &lp, int stage, int link, double &lb, double &ub)
+{
+    const double PI = 3.141592653589793;
+    int dof = link_dof(stage, link);
+    if (dof == -1) { lb = -__builtin_huge_val(); ub = __builtin_huge_val(); }
+    else if (dof == -2) { lb = -PI; ub = PI; }
+    else { lb = lp.bounds[dof][0]; ub = lp.bounds[dof][1]; }
+}
+
+// scipy least_squares argument checks, in scipy's order, for the stages that will run.
+inline int validate_leg(const SeqikLegParams &lp, int first_stage, int last_stage)
+{
+    for (int stage = first_stage; stage <= last_stage; ++stage) {
+        int n = kStageLinks[stage - 1];
+        for (int i = 0; i < n; ++i) {
+            double lb, ub;
+            link_bounds(lp, stage, i, lb, ub);
+            if (!(lb < ub)) return SEQIK_ERR_BAD_BOUNDS;
+        }
+        for (int i = 0; i < n; ++i) {
+            double lb, ub;
+            link_bounds(lp, stage, i, lb, ub);
+            double x = lp.seeds[kSeedOffset[stage - 1] + i];
+            if (!(x >= lb && x <= ub)) return SEQIK_ERR_X0_OUT_OF_BOUNDS;
+        }
+    }
+    return SEQIK_OK;
+}
+
+inline void make_leg_consts(const SeqikLegParams &lp, LegConst &lc)
+{
+    for (int stage = 1; stage <= 4; ++stage) {
+        StageConst &sc = lc.st[stage - 1];
+        const int n = kStageLinks[stage - 1];
+        const int a0 = kFirstActive[stage - 1];
+        const int na = kNumActive[stage - 1];
+        const double *seed = lp.seeds + kSeedOffset[stage - 1];
+        sc.max_nfev = 100 * n;
+        sc.pad_ = 0;
+        // translations: CTr_pitch carries -coxa, FTi -femur, TiTa -tibia, claw -tarsus
+        switch (stage) {
+        case 1: sc.tz_a = 0.0; sc.tz_b = 0.0; sc.tz_last = -lp.seg[0]; break;
+        case 2: sc.tz_a = 0.0; sc.tz_b = -lp.seg[0]; sc.tz_last = -lp.seg[1]; break;
+        case 3: sc.tz_a = 0.0; sc.tz_b = -lp.seg[1]; sc.tz_last = -lp.seg[2]; break;
+        default: sc.tz_a = -lp.seg[2]; sc.tz_b = 0.0; sc.tz_last = -lp.seg[3]; break;
+        }
+        for (int j = 0; j < 2; ++j) {
+            if (j < na) {
+                link_bounds(lp, stage, a0 + j, sc.lb[j], sc.ub[j]);
+                sc.seed[j] = seed[a0 + j];
+            } else {
+                sc.lb[j] = -1.0; sc.ub[j] = 1.0; sc.seed[j] = 0.0;
+            }
+        }
+        // inert entries of the start vector, made strictly feasible as scipy does, then the
+        // partial sums of squares that ||x0 / sqrt(v)|| and ||x|| need (link order, from 0.0)
+        double acc = 0.0;
+        for (int i = 0; i < a0; ++i) {
+            double lb, ub;
+            link_bounds(lp, stage, i, lb, ub);
+            double xi = strictly_feasible(seed[i], lb, ub, 1e-10);
+            acc = acc + xi * xi;
+        }
+        sc.x_pre_sq = acc;
+        {
+            double lb, ub;
+            link_bounds(lp, stage, n - 1, lb, ub);
+            double xi = strictly_feasible(seed[n - 1], lb, ub, 1e-10);
+            sc.x_suf_sq = xi * xi;
+        }
+    }
+}
+
+}  // namespace seqik

@@ -1,0 +1,944 @@
+// seqik_core.hpp -- per-chain sequential leg-IK solver, CDNA4 (gfx950) device code.
+//
+// One *chain* = one (sequence, leg).  The path replaced is
+//   LegInvKinSeq.calculate_ik_stage         seqikpy/leg_inverse_kinematics.py:200-322
+//   KinematicChainSeq.create_leg_chain_*    seqikpy/kinematic_chain.py:152-421
+//   LegInvKinBase.calculate_ik/calculate_fk seqikpy/leg_inverse_kinematics.py:62-77
+//   ikpy Chain.inverse_kinematics -> scipy.optimize.least_squares(method="trf")
+// i.e. for every frame four bounded trust-region-reflective least-squares problems with
+// 2 (stages 1-3) or 1 (stage 4) effective unknowns, frame t warm-started from frame t-1.
+//
+// Decomposition (same loop order as the reference, :373-385): ONE KERNEL PER STAGE, and
+// inside a stage kernel ONE LANE PER CHAIN walking its frames serially.  A lane runs a flat
+// state machine whose step ("pass") is one outer TRF iteration, so the 64 lanes of a
+// wavefront never wait for each other at frame boundaries -- only the total work per chain
+// has to balance -- and because all lanes of a launch are in the same stage, the stage
+// properties (number of unknowns, rotation axes, rank handling) are compile-time constants.
+// No MFMA: the sub-problems are 5x2 / 4x1.
+//
+// Structure that is exploited (none of it changes the arithmetic, see below):
+//   * links that cannot move the end effector (base, "fixed" links, last link) have
+//     exactly-zero Jacobian columns: they are never evaluated;
+//   * the product of the fixed links in front of the active ones is a per-frame constant,
+//     rebuilt from the stored angles of the earlier stages (2-6 sin/cos pairs) -- what the
+//     reference does by re-building the whole ikpy chain per frame, kinematic_chain.py:200+;
+//   * every link matrix is [axis rotation | (0,0,-length)]: products are written out per axis.
+//
+// Floating-point contract: every operation below is one IEEE binary64 op, sums run in the
+// same index order as the generic restatement in oracle/seqik_oracle.c (multiplications by
+// exact 0/1 and additions of exact 0 dropped), sin/cos is the same Cody-Waite +
+// fdlibm-polynomial routine.  Built with -ffp-contract=off the kernels therefore reproduce
+// the oracle bit for bit; tests/ check exactly that.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define SEQIK_HD __host__ __device__ __forceinline__
+
+namespace seqik {
+
+enum : int { AXIS_X = 0, AXIS_Y = 1, AXIS_Z = 2 };
+enum : int { STATUS_NONE = -99 };
+
+// ---------------------------------------------------------------------------
+// Per-(leg, stage) constants, built on the host by make_leg_consts().
+// ---------------------------------------------------------------------------
+struct StageConst {
+    double lb[2], ub[2];   // bounds of the active link(s), link order
+    double seed[2];        // initial_angles["stage_k"] entries of the active link(s)
+    double tz_a, tz_b;     // origin_translation z of active link a / b (0 or -segment length)
+    double tz_last;        // origin_translation z of the last (inert) link
+    double x_pre_sq;       // sum of squares of the (strictly feasible) seed entries in FRONT of the
+                           // active links, accumulated in link order from 0.0
+    double x_suf_sq;       // square of the seed entry of the last link
+    int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
+    int32_t pad_;
+};
+
+struct LegConst {
+    StageConst st[4];
+};
+
+// Compile-time description of a stage chain (kinematic_chain.py:152-421):
+//   stage 1: Base | yaw(X) pitch(Y)            | CTr_pitch(-coxa)
+//   stage 2: Base yaw pitch | roll(Z) CTr_pitch(Y,-coxa) | FTi(-femur)
+//   stage 3: Base .. CTr_pitch | CTr_roll(Z) FTi(Y,-femur) | TiTa(-tibia)
+//   stage 4: Base .. FTi | TiTa(Y,-tibia)      | Claw(-tarsus)
+template <int STAGE>
+struct StageTraits {
+    static constexpr int NA = (STAGE == 4) ? 1 : 2;
+    static constexpr int AXIS_A = (STAGE == 1) ? AXIS_X : (STAGE == 4 ? AXIS_Y : AXIS_Z);
+    // Stage 1 has no inert link between the base and the active links; LAPACK then returns
+    // exactly-zero singular values for the zero columns and scipy's m < n logic ("never full
+    // rank") applies verbatim.  See the ACTIVE SET note in oracle/seqik_oracle.c.
+    static constexpr bool DEFICIENT = (STAGE == 1);
+};
+
+// cumulative frame: rotation (row major) + translation
+struct Frame {
+    double r[9];
+    double t[3];
+};
+
+// ---------------------------------------------------------------------------
+// sin / cos -- same algorithm and constants as oracle_sincos()
+// ---------------------------------------------------------------------------
+SEQIK_HD void sincos_cw(double x, double &sn, double &cs)
+{
+    const double INVPIO2 = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00;
+    const double PIO2_2 = 6.07710050630396597660e-11;
+    const double PIO2_2T = 2.02226624879595063154e-21;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double fn = rint(x * INVPIO2);
+    double t = x - fn * PIO2_1;
+    double w = fn * PIO2_2;
+    double r = t - w;
+    w = fn * PIO2_2T - ((t - r) - w);
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+
+    double z = y0 * y0;
+    double v = z * y0;
+    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double zz = z * z;
+    double rc = z * (C1 + z * (C2 + z * C3)) + (zz * zz) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    double wc = 1.0 - hz;
+    double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+
+    int q = ((int)fn) & 3;
+    double s_sel = (q & 1) ? kc : ks;
+    double c_sel = (q & 1) ? ks : kc;
+    sn = (q & 2) ? -s_sel : s_sel;
+    cs = ((q == 1) || (q == 2)) ? -c_sel : c_sel;
+}
+
+// next representable double after b in the direction of `toward` (b != toward)
+SEQIK_HD double next_toward(double b, double toward)
+{
+    union { double d; uint64_t u; } v;
+    v.d = b;
+    if (b == 0.0) {
+        v.u = 1ull;  // smallest subnormal
+        return (toward > 0.0) ? v.d : -v.d;
+    }
+    bool up = toward > b;
+    bool positive = b > 0.0;
+    if (up == positive) v.u += 1; else v.u -= 1;
+    return v.d;
+}
+
+SEQIK_HD bool is_finite(double x) { return (x - x) == 0.0; }
+
+// out = in @ [R_axis(s, c) | (0, 0, tz)]   (one ikpy link frame appended on the right)
+template <int AXIS>
+SEQIK_HD void frame_mul_link(Frame &out, const Frame &in, double s, double c, double tz)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.t[i] = in.r[3 * i + 2] * tz + in.t[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double a0 = in.r[3 * i], a1 = in.r[3 * i + 1], a2 = in.r[3 * i + 2];
+        if constexpr (AXIS == AXIS_X) {
+            out.r[3 * i] = a0;
+            out.r[3 * i + 1] = a1 * c + a2 * s;
+            out.r[3 * i + 2] = a1 * (-s) + a2 * c;
+        } else if constexpr (AXIS == AXIS_Y) {
+            out.r[3 * i] = a0 * c + a2 * (-s);
+            out.r[3 * i + 1] = a1;
+            out.r[3 * i + 2] = a0 * s + a2 * c;
+        } else {
+            out.r[3 * i] = a0 * c + a1 * s;
+            out.r[3 * i + 1] = a0 * (-s) + a1 * c;
+            out.r[3 * i + 2] = a2;
+        }
+    }
+}
+
+SEQIK_HD void frame_identity(Frame &f)
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) f.r[i] = 0.0;
+    f.r[0] = f.r[4] = f.r[8] = 1.0;
+    f.t[0] = f.t[1] = f.t[2] = 0.0;
+}
+
+// _lsq/common.py:make_strictly_feasible on one entry
+SEQIK_HD double strictly_feasible(double x, double lb, double ub, double rstep)
+{
+    int active = 0;
+    if (rstep == 0.0) {
+        if (x <= lb) active = -1;
+        if (x >= ub) active = 1;
+    } else {
+        double lower_dist = x - lb;
+        double upper_dist = ub - x;
+        double lower_threshold = rstep * fmax(1.0, fabs(lb));
+        double upper_threshold = rstep * fmax(1.0, fabs(ub));
+        if (is_finite(lb) && lower_dist <= fmin(upper_dist, lower_threshold)) active = -1;
+        if (is_finite(ub) && upper_dist <= fmin(lower_dist, upper_threshold)) active = 1;
+    }
+    double xn = x;
+    if (active == -1)
+        xn = (rstep == 0.0) ? next_toward(lb, ub) : lb + rstep * fmax(1.0, fabs(lb));
+    else if (active == 1)
+        xn = (rstep == 0.0) ? next_toward(ub, lb) : ub - rstep * fmax(1.0, fabs(ub));
+    if (xn < lb || xn > ub) xn = 0.5 * (lb + ub);
+    return xn;
+}
+
+// ---------------------------------------------------------------------------
+// Small fixed-size linear algebra.  Vectors have 2 slots; slot 1 is unused when NA == 1.
+// ---------------------------------------------------------------------------
+template <int NA>
+SEQIK_HD double norm2v(const double *a)
+{
+    double acc = 0.0;
+    acc = acc + a[0] * a[0];
+    if constexpr (NA == 2) acc = acc + a[1] * a[1];
+    return sqrt(acc);
+}
+
+template <int NA>
+SEQIK_HD double dot2v(const double *a, const double *b)
+{
+    double acc = 0.0;
+    acc = acc + a[0] * b[0];
+    if constexpr (NA == 2) acc = acc + a[1] * b[1];
+    return acc;
+}
+
+SEQIK_HD double dot3(const double *a, const double *b)
+{
+    double acc = 0.0;
+    acc = acc + a[0] * b[0];
+    acc = acc + a[1] * b[1];
+    acc = acc + a[2] * b[2];
+    return acc;
+}
+
+template <int NA>
+SEQIK_HD void matvec32(const double Jh[3][2], const double *s, double *out)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+        acc = acc + Jh[k][0] * s[0];
+        if constexpr (NA == 2) acc = acc + Jh[k][1] * s[1];
+        out[k] = acc;
+    }
+}
+
+template <int NA>
+SEQIK_HD double diag_form(const double *a, const double *diag, const double *b)
+{
+    double acc = 0.0;
+    acc = acc + (a[0] * diag[0]) * b[0];
+    if constexpr (NA == 2) acc = acc + (a[1] * diag[1]) * b[1];
+    return acc;
+}
+
+// _lsq/common.py:CL_scaling_vector on one entry
+SEQIK_HD void cl_scaling(double x, double g, double lb, double ub, double &v, double &dv)
+{
+    v = 1.0; dv = 0.0;
+    if (g < 0 && is_finite(ub)) { v = ub - x; dv = -1.0; }
+    if (g > 0 && is_finite(lb)) { v = x - lb; dv = 1.0; }
+}
+
+// _numdiff.py: 2-point step with _adjust_scheme_to_bounds('1-sided')
+SEQIK_HD double fd_step(double x, double lb, double ub)
+{
+    const double RSTEP = 1.4901161193847656e-08;
+    double sign = (x >= 0.0) ? 1.0 : -1.0;
+    double h = RSTEP * sign * fmax(1.0, fabs(x));
+    double lower_dist = x - lb;
+    double upper_dist = ub - x;
+    double xh = x + h;
+    bool violated = (xh < lb) || (xh > ub);
+    bool fitting = fabs(h) <= fmax(lower_dist, upper_dist);
+    if (violated && fitting) h = -h;
+    else if (!fitting) h = (upper_dist >= lower_dist) ? upper_dist : -lower_dist;
+    return h;
+}
+
+// SVD of the augmented matrix [[J_h], [diag(q)]] restricted to the active columns, by
+// one-sided Jacobi (same sweep / threshold / ordering rules as oracle jacobi_svd).
+// Out: s (descending), V (2x2), uf = U^T f.
+template <int NA>
+SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f, double *s, double V[2][2],
+                         double *uf)
+{
+    if constexpr (NA == 1) {
+        // 4 x 1: singular value = column norm, V = [1]
+        double acc = 0.0;
+        acc = acc + Jh[0][0] * Jh[0][0];
+        acc = acc + Jh[1][0] * Jh[1][0];
+        acc = acc + Jh[2][0] * Jh[2][0];
+        acc = acc + q[0] * q[0];
+        double sv0 = sqrt(acc);
+        double u0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double e0 = (sv0 > 0.0) ? Jh[k][0] / sv0 : 0.0;
+            u0 = u0 + e0 * f[k];
+        }
+        s[0] = sv0; s[1] = 0.0; uf[0] = u0; uf[1] = 0.0;
+        V[0][0] = 1.0; V[0][1] = 0.0; V[1][0] = 0.0; V[1][1] = 1.0;
+    } else {
+        const double TOL = 8.881784197001252e-16;
+        double A[5][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { A[k][0] = Jh[k][0]; A[k][1] = Jh[k][1]; }
+        A[3][0] = q[0]; A[3][1] = 0.0;
+        A[4][0] = 0.0;  A[4][1] = q[1];
+        V[0][0] = 1.0; V[0][1] = 0.0; V[1][0] = 0.0; V[1][1] = 1.0;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                alpha = alpha + A[i][0] * A[i][0];
+                beta = beta + A[i][1] * A[i][1];
+                gamma = gamma + A[i][0] * A[i][1];
+            }
+            if (gamma == 0.0) break;
+            if (fabs(gamma) <= TOL * sqrt(alpha * beta)) break;
+            double zeta = (beta - alpha) / (2.0 * gamma);
+            double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            if (zeta < 0.0) t = -t;
+            double c = 1.0 / sqrt(1.0 + t * t);
+            double sn = c * t;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                double ap = A[i][0], aq = A[i][1];
+                A[i][0] = c * ap - sn * aq;
+                A[i][1] = sn * ap + c * aq;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                double vp = V[i][0], vq = V[i][1];
+                V[i][0] = c * vp - sn * vq;
+                V[i][1] = sn * vp + c * vq;
+            }
+        }
+        double sv0 = 0.0, sv1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { sv0 = sv0 + A[i][0] * A[i][0]; sv1 = sv1 + A[i][1] * A[i][1]; }
+        sv0 = sqrt(sv0);
+        sv1 = sqrt(sv1);
+        double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double e0 = (sv0 > 0.0) ? A[k][0] / sv0 : 0.0;
+            u0 = u0 + e0 * f[k];
+            double e1 = (sv1 > 0.0) ? A[k][1] / sv1 : 0.0;
+            u1 = u1 + e1 * f[k];
+        }
+        // descending order (stable): swap only if the second is strictly larger
+        if (sv0 < sv1) {
+            s[0] = sv1; s[1] = sv0; uf[0] = u1; uf[1] = u0;
+            double t0 = V[0][0], t1 = V[1][0];
+            V[0][0] = V[0][1]; V[1][0] = V[1][1];
+            V[0][1] = t0; V[1][1] = t1;
+        } else {
+            s[0] = sv0; s[1] = sv1; uf[0] = u0; uf[1] = u1;
+        }
+    }
+}
+
+template <int NA>
+SEQIK_HD void phi_and_derivative(double alpha, const double *suf, const double *s, double Delta, double &phi,
+                                 double &phi_prime)
+{
+    double tmp[2] = {0.0, 0.0};
+    tmp[0] = suf[0] / (s[0] * s[0] + alpha);
+    if constexpr (NA == 2) tmp[1] = suf[1] / (s[1] * s[1] + alpha);
+    double p_norm = norm2v<NA>(tmp);
+    double acc = 0.0;
+    {
+        double denom = s[0] * s[0] + alpha;
+        acc = acc + (suf[0] * suf[0]) / (denom * denom * denom);
+    }
+    if constexpr (NA == 2) {
+        double denom = s[1] * s[1] + alpha;
+        acc = acc + (suf[1] * suf[1]) / (denom * denom * denom);
+    }
+    phi = p_norm - Delta;
+    phi_prime = -acc / p_norm;
+}
+
+template <int NA>
+SEQIK_HD void apply_V_neg(const double V[2][2], const double *tmp, double *p)
+{
+    {
+        double acc = 0.0;
+        acc = acc + V[0][0] * tmp[0];
+        if constexpr (NA == 2) acc = acc + V[0][1] * tmp[1];
+        p[0] = -acc;
+    }
+    if constexpr (NA == 2) {
+        double acc = 0.0;
+        acc = acc + V[1][0] * tmp[0];
+        acc = acc + V[1][1] * tmp[1];
+        p[1] = -acc;
+    } else {
+        p[1] = 0.0;
+    }
+}
+
+// _lsq/common.py:solve_lsq_trust_region on the active set (m = 3 residuals >= NA)
+template <int NA, bool DEFICIENT>
+SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const double V[2][2], double Delta,
+                                     double &alpha_io, double *p)
+{
+    const double EPS = 2.220446049250313e-16;
+    double suf[2] = {s[0] * uf[0], 0.0};
+    if constexpr (NA == 2) suf[1] = s[1] * uf[1];
+    double tmp[2] = {0.0, 0.0};
+    bool full_rank = false;
+    if constexpr (!DEFICIENT) {
+        double threshold = EPS * 3 * s[0];
+        full_rank = s[NA - 1] > threshold;
+        if (full_rank) {
+            tmp[0] = uf[0] / s[0];
+            if constexpr (NA == 2) tmp[1] = uf[1] / s[1];
+            apply_V_neg<NA>(V, tmp, p);
+            if (norm2v<NA>(p) <= Delta) { alpha_io = 0.0; return; }
+        }
+    }
+    double alpha_upper = norm2v<NA>(suf) / Delta;
+    double alpha_lower = 0.0;
+    if (full_rank) {
+        double phi, phi_prime;
+        phi_and_derivative<NA>(0.0, suf, s, Delta, phi, phi_prime);
+        alpha_lower = -phi / phi_prime;
+    }
+    double alpha = alpha_io;
+    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double phi, phi_prime;
+        phi_and_derivative<NA>(alpha, suf, s, Delta, phi, phi_prime);
+        if (phi < 0) alpha_upper = alpha;
+        double ratio = phi / phi_prime;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio / Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    tmp[0] = suf[0] / (s[0] * s[0] + alpha);
+    if constexpr (NA == 2) tmp[1] = suf[1] / (s[1] * s[1] + alpha);
+    apply_V_neg<NA>(V, tmp, p);
+    double scale = Delta / norm2v<NA>(p);
+    p[0] = p[0] * scale;
+    if constexpr (NA == 2) p[1] = p[1] * scale;
+    alpha_io = alpha;
+}
+
+template <int NA>
+SEQIK_HD bool in_bounds2(const double *x, const double *lb, const double *ub)
+{
+    bool ok = (x[0] >= lb[0]) && (x[0] <= ub[0]);
+    if constexpr (NA == 2) ok = ok && (x[1] >= lb[1]) && (x[1] <= ub[1]);
+    return ok;
+}
+
+// _lsq/common.py:step_size_to_bound
+template <int NA>
+SEQIK_HD double step_size_to_bound(const double *x, const double *s, const double *lb, const double *ub, int *hits)
+{
+    const double INF = __builtin_huge_val();
+    double steps[2] = {INF, INF};
+    if (s[0] != 0.0) steps[0] = fmax((lb[0] - x[0]) / s[0], (ub[0] - x[0]) / s[0]);
+    if constexpr (NA == 2)
+        if (s[1] != 0.0) steps[1] = fmax((lb[1] - x[1]) / s[1], (ub[1] - x[1]) / s[1]);
+    double min_step = fmin(steps[0], steps[1]);
+    if (hits) {
+        int sg0 = (s[0] > 0) - (s[0] < 0);
+        int sg1 = (s[1] > 0) - (s[1] < 0);
+        hits[0] = (steps[0] == min_step) ? sg0 : 0;
+        hits[1] = (NA == 2 && steps[1] == min_step) ? sg1 : 0;
+    }
+    return min_step;
+}
+
+// _lsq/common.py:evaluate_quadratic
+template <int NA>
+SEQIK_HD double evaluate_quadratic(const double Jh[3][2], const double *g, const double *s, const double *diag)
+{
+    double Js[3];
+    matvec32<NA>(Jh, s, Js);
+    double q = dot3(Js, Js);
+    q = q + diag_form<NA>(s, diag, s);
+    double l = dot2v<NA>(s, g);
+    return 0.5 * q + l;
+}
+
+// _lsq/common.py:minimize_quadratic_1d
+SEQIK_HD double minimize_quadratic_1d(double a, double b, double lb, double ub, double c, double &y_out)
+{
+    double tbest = lb;
+    double ybest = lb * (a * lb + b) + c;
+    {
+        double y = ub * (a * ub + b) + c;
+        if (y < ybest) { ybest = y; tbest = ub; }
+    }
+    if (a != 0) {
+        double extremum = -0.5 * b / a;
+        if (lb < extremum && extremum < ub) {
+            double y = extremum * (a * extremum + b) + c;
+            if (y < ybest) { ybest = y; tbest = extremum; }
+        }
+    }
+    y_out = ybest;
+    return tbest;
+}
+
+// _lsq/trf.py:select_step when x + p leaves the bounds (the in-bounds case is handled by
+// the caller).  p, p_h are clobbered.  Not inlined: it is the cold path of stages 2-4.
+template <int NA>
+SEQIK_HD double select_step_reflective(
+    const double *x, const double Jh[3][2], const double *diag_h, const double *g_h, double *p, double *p_h,
+    const double *d, double Delta, const double *lb, const double *ub, double theta, double *step, double *step_h)
+{
+    const double INF = __builtin_huge_val();
+    int hits[2];
+    double p_stride = step_size_to_bound<NA>(x, p, lb, ub, hits);
+    double r_h[2], r[2], x_on_bound[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        r_h[i] = p_h[i];
+        if (hits[i] != 0) r_h[i] = r_h[i] * -1.0;
+        r[i] = d[i] * r_h[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        p[i] = p[i] * p_stride;
+        p_h[i] = p_h[i] * p_stride;
+        x_on_bound[i] = x[i] + p[i];
+    }
+    // intersect_trust_region(p_h, r_h, Delta) -> positive root
+    double to_tr;
+    {
+        double a = dot2v<NA>(r_h, r_h);
+        double b = dot2v<NA>(p_h, r_h);
+        double c = dot2v<NA>(p_h, p_h) - Delta * Delta;
+        double dd = sqrt(b * b - a * c);
+        double q = -(b + copysign(dd, b));
+        double t1 = q / a;
+        double t2 = c / q;
+        to_tr = (t1 < t2) ? t2 : t1;
+    }
+    double to_bound = step_size_to_bound<NA>(x_on_bound, r, lb, ub, nullptr);
+    double r_stride = fmin(to_bound, to_tr);
+    double r_stride_l, r_stride_u;
+    if (r_stride > 0) {
+        r_stride_l = (1 - theta) * p_stride / r_stride;
+        r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
+    } else {
+        r_stride_l = 0;
+        r_stride_u = -1;
+    }
+    double r_value;
+    if (r_stride_l <= r_stride_u) {
+        // build_quadratic_1d(J_h, g_h, r_h, s0=p_h, diag=diag_h)
+        double v[3], u[3];
+        matvec32<NA>(Jh, r_h, v);
+        double a = dot3(v, v);
+        a = a + diag_form<NA>(r_h, diag_h, r_h);
+        a = a * 0.5;
+        double b = dot2v<NA>(g_h, r_h);
+        matvec32<NA>(Jh, p_h, u);
+        b = b + dot3(u, v);
+        double c = 0.5 * dot3(u, u) + dot2v<NA>(g_h, p_h);
+        b = b + diag_form<NA>(p_h, diag_h, r_h);
+        c = c + 0.5 * diag_form<NA>(p_h, diag_h, p_h);
+        r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, r_value);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r_h[i] = r_h[i] * r_stride;
+            r_h[i] = r_h[i] + p_h[i];
+            r[i] = r_h[i] * d[i];
+        }
+    } else {
+        r_value = INF;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { p[i] = p[i] * theta; p_h[i] = p_h[i] * theta; }
+    double p_value = evaluate_quadratic<NA>(Jh, g_h, p_h, diag_h);
+
+    double ag_h[2], ag[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
+    to_tr = Delta / norm2v<NA>(ag_h);
+    to_bound = step_size_to_bound<NA>(x, ag, lb, ub, nullptr);
+    double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
+    double ag_value;
+    {
+        double v[3];
+        matvec32<NA>(Jh, ag_h, v);
+        double a = dot3(v, v);
+        a = a + diag_form<NA>(ag_h, diag_h, ag_h);
+        a = a * 0.5;
+        double b = dot2v<NA>(g_h, ag_h);
+        ag_stride = minimize_quadratic_1d(a, b, 0.0, ag_stride, 0.0, ag_value);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ag_h[i] = ag_h[i] * ag_stride; ag[i] = ag[i] * ag_stride; }
+
+    if (p_value < r_value && p_value < ag_value) {
+        step[0] = p[0]; step[1] = p[1]; step_h[0] = p_h[0]; step_h[1] = p_h[1];
+        return -p_value;
+    } else if (r_value < p_value && r_value < ag_value) {
+        step[0] = r[0]; step[1] = r[1]; step_h[0] = r_h[0]; step_h[1] = r_h[1];
+        return -r_value;
+    }
+    step[0] = ag[0]; step[1] = ag[1]; step_h[0] = ag_h[0]; step_h[1] = ag_h[1];
+    return -ag_value;
+}
+
+// ---------------------------------------------------------------------------
+// Forward kinematics of the active part of a stage chain
+// ---------------------------------------------------------------------------
+template <int STAGE>
+struct StageProblem {
+    Frame pre;          // product of the links in front of the active ones
+    double target[3];
+    double tz_a, tz_b, tz_last;
+};
+
+// Frame after the active links for given sin/cos pairs.
+template <int STAGE>
+SEQIK_HD void frame_after_active(const StageProblem<STAGE> &P, double sa, double ca, double sb, double cb,
+                                 Frame &after)
+{
+    using T = StageTraits<STAGE>;
+    if constexpr (T::NA == 2) {
+        Frame f1;
+        frame_mul_link<T::AXIS_A>(f1, P.pre, sa, ca, P.tz_a);
+        frame_mul_link<AXIS_Y>(after, f1, sb, cb, P.tz_b);
+    } else {
+        frame_mul_link<T::AXIS_A>(after, P.pre, sa, ca, P.tz_a);
+    }
+}
+
+// End-effector residual for given sin/cos pairs of the active joints.
+template <int STAGE>
+SEQIK_HD void residual_sc(const StageProblem<STAGE> &P, double sa, double ca, double sb, double cb, double *f)
+{
+    Frame after;
+    frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f[i] = (after.r[3 * i + 2] * P.tz_last + after.t[i]) - P.target[i];
+}
+
+// End-effector residual at (xa, xb); also returns the sin/cos pairs.
+template <int STAGE>
+SEQIK_HD void eval_residual(const StageProblem<STAGE> &P, double xa, double xb, double *f,
+                            double &sa, double &ca, double &sb, double &cb)
+{
+    sincos_cw(xa, sa, ca);
+    if constexpr (StageTraits<STAGE>::NA == 2) sincos_cw(xb, sb, cb);
+    else { sb = 0.0; cb = 1.0; }
+    residual_sc<STAGE>(P, sa, ca, sb, cb, f);
+}
+
+// 2-point finite-difference Jacobian of the active columns: J[k][j].  Column a perturbs
+// link a and reuses link b's sin/cos, column b the other way round.
+template <int STAGE>
+SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const double *f0, const double *lb,
+                          const double *ub, double sa, double ca, double sb, double cb, double J[3][2])
+{
+    using T = StageTraits<STAGE>;
+    {
+        double h = fd_step(x[0], lb[0], ub[0]);
+        double x1 = x[0] + h;
+        double dx = x1 - x[0];
+        double s1, c1, f1[3];
+        sincos_cw(x1, s1, c1);
+        residual_sc<STAGE>(P, s1, c1, sb, cb, f1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) J[i][0] = (f1[i] - f0[i]) / dx;
+    }
+    if constexpr (T::NA == 2) {
+        double h = fd_step(x[1], lb[1], ub[1]);
+        double x1 = x[1] + h;
+        double dx = x1 - x[1];
+        double s1, c1, f1[3];
+        sincos_cw(x1, s1, c1);
+        residual_sc<STAGE>(P, sa, ca, s1, c1, f1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) J[i][1] = (f1[i] - f0[i]) / dx;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) J[i][1] = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stage driver
+// ---------------------------------------------------------------------------
+struct ChainIO {
+    const double *pose;     // this chain's key points: frame t at pose + t * 15, [5][3] contiguous
+    double *angles;         // [n_frames][7], DOF order yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa
+    double *fk;             // nullable [n_frames][9][3]
+    int32_t *status;        // nullable [n_frames][4]
+    int32_t *nfev;          // nullable [n_frames][4]
+    int64_t n_frames;
+};
+
+// Prefix frame of STAGE from the angles of the earlier stages: the "fixed" links of
+// kinematic_chain.py:215-241, 276-316, 353-401, multiplied in link order.
+template <int STAGE>
+SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang)
+{
+    frame_identity(pre);
+    if constexpr (STAGE >= 2) {
+        double sn, cs;
+        Frame tmp;
+        sincos_cw(ang[0], sn, cs);
+        frame_mul_link<AXIS_X>(tmp, pre, sn, cs, lc.st[0].tz_a);
+        sincos_cw(ang[1], sn, cs);
+        frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[0].tz_b);
+    }
+    if constexpr (STAGE >= 3) {
+        double sn, cs;
+        Frame tmp;
+        sincos_cw(ang[2], sn, cs);
+        frame_mul_link<AXIS_Z>(tmp, pre, sn, cs, lc.st[1].tz_a);
+        sincos_cw(ang[3], sn, cs);
+        frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[1].tz_b);
+    }
+    if constexpr (STAGE >= 4) {
+        double sn, cs;
+        Frame tmp;
+        sincos_cw(ang[4], sn, cs);
+        frame_mul_link<AXIS_Z>(tmp, pre, sn, cs, lc.st[2].tz_a);
+        sincos_cw(ang[5], sn, cs);
+        frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[2].tz_b);
+    }
+}
+
+// Runs stage STAGE over all frames of one chain.
+//   WANT_FK   : also write this stage's rows of the stage-4 forward kinematics
+//               (leg_inverse_kinematics.py:279-282): stage 2 -> rows 4, 5 (coxa end),
+//               stage 3 -> row 6 (femur end), stage 4 -> rows 0-3 (origin), 7, 8.
+//   WANT_DIAG : also produce scipy's status / nfev (one extra Jacobian per solve: scipy
+//               re-evaluates it after the last accepted step and may overwrite the status
+//               with 1 = gtol).
+template <int STAGE, bool WANT_FK, bool WANT_DIAG>
+SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
+{
+    using T = StageTraits<STAGE>;
+    constexpr int NA = T::NA;
+    constexpr int DOF0 = 2 * (STAGE - 1);  // angle columns written: DOF0 (and DOF0 + 1)
+    const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    const StageConst &sc = lc.st[STAGE - 1];
+    const double *lb = sc.lb;
+    const double *ub = sc.ub;
+    const int max_nfev = sc.max_nfev;
+
+    StageProblem<STAGE> P;
+    P.tz_a = sc.tz_a; P.tz_b = sc.tz_b; P.tz_last = sc.tz_last;
+    frame_identity(P.pre);
+    P.target[0] = P.target[1] = P.target[2] = 0.0;
+
+    // x carries the solution from frame to frame: it is the warm start of the next solve
+    double x[2] = {sc.seed[0], (NA == 2) ? sc.seed[1] : 0.0}, f[3] = {0.0, 0.0, 0.0};
+    double cost = 0.0, Delta = 0.0, alpha = 0.0;
+    double sa = 0.0, ca = 1.0, sb = 0.0, cb = 1.0;  // sin/cos of the active joints at x
+    int nfev = 0, status = STATUS_NONE;
+    bool first_pass = true, new_solve = true;
+    int64_t t = 0;
+
+    while (t < io.n_frames) {
+        if (new_solve) {
+            const double *kp = io.pose + t * 15;
+            if constexpr (STAGE > 1) build_prefix<STAGE>(P.pre, lc, io.angles + t * 7);
+            P.target[0] = kp[3 * STAGE + 0] - kp[0];
+            P.target[1] = kp[3 * STAGE + 1] - kp[1];
+            P.target[2] = kp[3 * STAGE + 2] - kp[2];
+            x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+            if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+            eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
+            cost = 0.5 * dot3(f, f);
+            nfev = 1;
+            alpha = 0.0;
+            status = STATUS_NONE;
+            first_pass = true;
+            new_solve = false;
+        }
+
+        bool finished = false;
+        if (WANT_DIAG || status == STATUS_NONE) {
+            // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
+            double J[3][2], g[2], v[2], dv[2];
+            fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                double acc = 0.0;
+                acc = acc + J[0][j] * f[0];
+                acc = acc + J[1][j] * f[1];
+                acc = acc + J[2][j] * f[2];
+                g[j] = acc;
+            }
+            cl_scaling(x[0], g[0], lb[0], ub[0], v[0], dv[0]);
+            if constexpr (NA == 2) cl_scaling(x[1], g[1], lb[1], ub[1], v[1], dv[1]);
+            else { v[1] = 1.0; dv[1] = 0.0; }
+            if (first_pass) {
+                // Delta_0 = || x0 / sqrt(v) || over ALL links (inert entries: v = 1)
+                double acc = sc.x_pre_sq;
+                // (x is still the start point x0 here: no step has been taken yet)
+                double t0 = x[0] / sqrt(v[0]);
+                acc = acc + t0 * t0;
+                if constexpr (NA == 2) { double t1 = x[1] / sqrt(v[1]); acc = acc + t1 * t1; }
+                acc = acc + sc.x_suf_sq;
+                Delta = sqrt(acc);
+                if (Delta == 0) Delta = 1.0;
+                first_pass = false;
+            }
+            double g_norm = fabs(g[0] * v[0]);
+            if constexpr (NA == 2) g_norm = fmax(g_norm, fabs(g[1] * v[1]));
+            if (g_norm < gtol) status = 1;
+
+            if (status != STATUS_NONE || nfev == max_nfev) {
+                finished = true;
+            } else {
+                // ---- trust-region sub-problem -------------------------------------------
+                double d[2], diag_h[2], g_h[2], q[2], Jh[3][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    d[j] = sqrt(v[j]) * 1.0;
+                    diag_h[j] = g[j] * dv[j] * 1.0;
+                    g_h[j] = d[j] * g[j];
+                    q[j] = sqrt(diag_h[j]);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { Jh[k][0] = J[k][0] * d[0]; Jh[k][1] = J[k][1] * d[1]; }
+                double s[2], V[2][2], uf[2];
+                svd_active<NA>(Jh, q, f, s, V, uf);
+                double theta = fmax(0.995, 1 - g_norm);
+
+                // ---- ONE trial step per pass.  scipy's inner `while actual_reduction <= 0` loop is
+                // unrolled over passes: after a rejected trial x, f and therefore J, g, the scaling
+                // and the SVD are unchanged, so re-deriving them at the top of the next pass gives
+                // bit-identical values, and no lane ever makes the other 63 wait in an inner loop.
+                double p_h[2], p[2], step[2], step_h[2];
+                solve_lsq_trust_region<NA, T::DEFICIENT>(uf, s, V, Delta, alpha, p_h);
+                p[0] = d[0] * p_h[0]; p[1] = d[1] * p_h[1];
+                double predicted_reduction;
+                double xp[2] = {x[0] + p[0], x[1] + p[1]};
+                if (in_bounds2<NA>(xp, lb, ub)) {
+                    predicted_reduction = -evaluate_quadratic<NA>(Jh, g_h, p_h, diag_h);
+                    step[0] = p[0]; step[1] = p[1]; step_h[0] = p_h[0]; step_h[1] = p_h[1];
+                } else {
+                    predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
+                                                                     theta, step, step_h);
+                }
+                double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n;
+                x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
+                if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);
+                eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n);
+                nfev += 1;
+                double step_h_norm = norm2v<NA>(step_h);
+                double cost_new = 0.5 * dot3(f_new, f_new);
+                double actual_reduction = cost - cost_new;
+                double ratio;
+                if (predicted_reduction > 0) ratio = actual_reduction / predicted_reduction;
+                else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
+                else ratio = 0;
+                double Delta_new = Delta;
+                if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
+                else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
+                double step_norm = norm2v<NA>(step);
+                // ||x|| over all links: inert prefix, active, inert last link
+                double xn = sc.x_pre_sq;
+                xn = xn + x[0] * x[0];
+                if constexpr (NA == 2) xn = xn + x[1] * x[1];
+                xn = xn + sc.x_suf_sq;
+                xn = sqrt(xn);
+                bool ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
+                bool xtol_ok = step_norm < xtol * (xtol + xn);
+                if (ftol_ok && xtol_ok) status = 4;
+                else if (ftol_ok) status = 2;
+                else if (xtol_ok) status = 3;
+                if (status == STATUS_NONE) {
+                    alpha = alpha * (Delta / Delta_new);
+                    Delta = Delta_new;
+                }
+                if (actual_reduction > 0) {
+                    x[0] = x_new[0]; x[1] = x_new[1];
+                    f[0] = f_new[0]; f[1] = f_new[1]; f[2] = f_new[2];
+                    cost = cost_new;
+                    sa = sa_n; ca = ca_n; sb = sb_n; cb = cb_n;
+                }
+                if (!WANT_DIAG && (status != STATUS_NONE || nfev == max_nfev)) finished = true;
+            }
+        } else {
+            finished = true;
+        }
+
+        if (finished) {
+            // ---- solve done: store, advance to the next frame -------------------------------
+            double *ang = io.angles + t * 7;
+            ang[DOF0] = x[0];
+            if constexpr (NA == 2) ang[DOF0 + 1] = x[1];
+            if constexpr (WANT_DIAG) {
+                if (io.status) io.status[t * 4 + STAGE - 1] = (status == STATUS_NONE) ? 0 : status;
+                if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
+            }
+            if constexpr (WANT_FK && STAGE >= 2) {
+                const double *origin = io.pose + t * 15;
+                double *fk = io.fk + t * 27;
+                Frame after;  // frame after the active links at the solution
+                frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
+                if constexpr (STAGE == 2) {
+                    for (int a = 0; a < 3; ++a) { fk[12 + a] = after.t[a] + origin[a]; fk[15 + a] = after.t[a] + origin[a]; }
+                } else if constexpr (STAGE == 3) {
+                    for (int a = 0; a < 3; ++a) fk[18 + a] = after.t[a] + origin[a];
+                } else {
+                    for (int i = 0; i < 4; ++i)
+                        for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
+                    for (int a = 0; a < 3; ++a) {
+                        fk[21 + a] = after.t[a] + origin[a];
+                        fk[24 + a] = (after.r[3 * a + 2] * P.tz_last + after.t[a]) + origin[a];
+                    }
+                }
+            }
+            t += 1;
+            new_solve = true;
+        }
+    }
+}
+
+// Stage-4 FK rows that earlier stages would have written, for runs that start at a later
+// stage (first_stage > 2): rows 4, 5 from the stage-3 prefix, row 6 from the stage-4 prefix.
+template <int FIRST_STAGE>
+SEQIK_HD void fill_fk_prefix_rows(const LegConst &lc, const ChainIO &io)
+{
+    for (int64_t t = 0; t < io.n_frames; ++t) {
+        const double *kp = io.pose + t * 15;
+        const double *ang = io.angles + t * 7;
+        double *fk = io.fk + t * 27;
+        if constexpr (FIRST_STAGE >= 3) {
+            Frame pre;
+            build_prefix<3>(pre, lc, ang);
+            for (int a = 0; a < 3; ++a) { fk[12 + a] = pre.t[a] + kp[a]; fk[15 + a] = pre.t[a] + kp[a]; }
+        }
+        if constexpr (FIRST_STAGE >= 4) {
+            Frame pre;
+            build_prefix<4>(pre, lc, ang);
+            for (int a = 0; a < 3; ++a) fk[18 + a] = pre.t[a] + kp[a];
+        }
+    }
+}
+
+}  // namespace seqik

@@ -1,0 +1,262 @@
+// seqik_hip.hip -- HIP kernel launchers and the C ABI of libseqik_hip.so (include/seqik.h).
+// gfx950 only.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+
+#include "seqik_core.hpp"
+#include "seqik_consts.hpp"
+
+namespace {
+
+constexpr int kMaxLegs = 8;   // LegConst table staged in LDS (a fly has 6 legs)
+constexpr int kMaxBlock = 256;
+
+// Register budget: waves per SIMD the stage kernels are compiled for (512 / N VGPRs per lane).
+#ifndef SEQIK_WAVES_PER_EU
+#define SEQIK_WAVES_PER_EU 2
+#endif
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, const char *detail = "")
+{
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) return fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+struct KernelArgs {
+    const double *pose;
+    double *angles;
+    double *fk;
+    int32_t *status;
+    int32_t *nfev;
+    const seqik::LegConst *legs;  // device, [n_legs]
+    int64_t n_chains;             // n_seq * n_legs
+    int64_t n_frames;
+    int32_t n_legs;
+    int32_t fill_fk_from;  // > 0: this launch first writes the FK rows owed by stages that are not run
+};
+
+// One lane per chain, one launch per stage (the reference's own loop order,
+// leg_inverse_kinematics.py:373-385).  A workgroup is one or more independent wavefronts;
+// the only shared data is the read-only per-leg constant table, staged once into LDS.
+// Chains of a wave are consecutive (sequence, leg) pairs, so a 64-lane wave owns
+// 64 * n_frames * 120 B of contiguous key points.
+template <int STAGE, bool WANT_FK, bool WANT_DIAG>
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_stage_kernel(KernelArgs a)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_chains) return;
+    const int leg = (int)(c % a.n_legs);
+
+    seqik::ChainIO io;
+    io.pose = a.pose + c * a.n_frames * 15;
+    io.angles = a.angles + c * a.n_frames * 7;
+    io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
+    io.status = a.status ? a.status + c * a.n_frames * 4 : nullptr;
+    io.nfev = a.nfev ? a.nfev + c * a.n_frames * 4 : nullptr;
+    io.n_frames = a.n_frames;
+    if (a.fill_fk_from > 0) {
+        if (a.fill_fk_from == 3) seqik::fill_fk_prefix_rows<3>(s_legs[leg], io);
+        else seqik::fill_fk_prefix_rows<4>(s_legs[leg], io);
+    }
+    seqik::run_stage<STAGE, WANT_FK, WANT_DIAG>(s_legs[leg], io);
+}
+
+template <int STAGE>
+void launch_stage(const KernelArgs &a, bool fk, bool diag, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (fk && diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, true>), grid, block, 0, stream, a);
+    else if (fk) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, false>), grid, block, 0, stream, a);
+    else if (diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, false>), grid, block, 0, stream, a);
+}
+
+// Device copy of the per-leg constant table.  Callers almost always pass the same legs on
+// every call, so the table is cached per host thread and device: a repeat call is a pure
+// kernel launch (no allocation, no copy).  When the contents change, the device is drained
+// first because kernels still in flight read the old table in their prologue.
+struct LegTableCache {
+    seqik::LegConst *d = nullptr;
+    int device = -1;
+    std::vector<seqik::LegConst> h;
+};
+thread_local LegTableCache g_cache;
+
+int device_leg_table(const SeqikLegParams *legs, int32_t n_legs, const seqik::LegConst **out)
+{
+    std::vector<seqik::LegConst> h(n_legs);
+    memset(h.data(), 0, sizeof(seqik::LegConst) * n_legs);
+    for (int l = 0; l < n_legs; ++l) seqik::make_leg_consts(legs[l], h[l]);
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    LegTableCache &c = g_cache;
+    const bool same = c.d && c.device == dev && c.h.size() == h.size() &&
+                      memcmp(c.h.data(), h.data(), sizeof(seqik::LegConst) * n_legs) == 0;
+    if (!same) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c.d && c.device != dev) c.d = nullptr;  // belongs to another device: leave it (tiny)
+        if (!c.d) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d), sizeof(seqik::LegConst) * kMaxLegs));
+        HIP_TRY(hipMemcpy(c.d, h.data(), sizeof(seqik::LegConst) * n_legs, hipMemcpyHostToDevice));
+        c.device = dev;
+        c.h = h;
+    }
+    *out = c.d;
+    return SEQIK_OK;
+}
+
+int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegParams *legs,
+               int32_t first_stage, int32_t last_stage, const void *pose, const void *angles)
+{
+    if (!legs || !pose || !angles) return fail(SEQIK_ERR_BAD_ARG, "null pointer argument%s");
+    if (n_seq < 0 || n_frames < 0 || n_legs <= 0 || n_legs > kMaxLegs)
+        return fail(SEQIK_ERR_BAD_ARG, "bad sizes (n_legs must be 1..8)%s");
+    if (first_stage < 1 || last_stage > 4 || first_stage > last_stage)
+        return fail(SEQIK_ERR_BAD_STAGE, "Maximum stage number is 4 and the list should be strictly incremental.%s");
+    return seqik_validate_legs(legs, n_legs, first_stage, last_stage);
+}
+
+int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+           const seqik::LegConst *d_legs, int32_t first_stage, int32_t last_stage, double *d_angles,
+           double *d_fk, int32_t *d_status, int32_t *d_nfev, const SeqikOptions *opt, hipStream_t stream)
+{
+    KernelArgs a;
+    a.pose = d_pose; a.angles = d_angles; a.fk = d_fk; a.status = d_status; a.nfev = d_nfev;
+    a.legs = d_legs;
+    a.n_chains = n_seq * (int64_t)n_legs;
+    a.n_frames = n_frames;
+    a.n_legs = n_legs;
+    a.fill_fk_from = 0;
+    if (a.n_chains == 0 || n_frames == 0) return SEQIK_OK;
+    int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
+    if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
+    int64_t grid64 = (a.n_chains + block - 1) / block;
+    if (grid64 > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
+    const dim3 grid((unsigned)grid64), blk(block);
+    const bool diag = d_status || d_nfev;
+    const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
+    if (!fk) a.fk = nullptr;
+    for (int stage = first_stage; stage <= last_stage; ++stage) {
+        // a run that starts after stage 2 still owes the FK rows of the links solved earlier
+        a.fill_fk_from = (fk && stage == first_stage && first_stage >= 3) ? first_stage : 0;
+        switch (stage) {
+        case 1: launch_stage<1>(a, false, diag, grid, blk, stream); break;
+        case 2: launch_stage<2>(a, fk, diag, grid, blk, stream); break;
+        case 3: launch_stage<3>(a, fk, diag, grid, blk, stream); break;
+        default: launch_stage<4>(a, fk, diag, grid, blk, stream); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipGetLastError());
+    return SEQIK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int seqik_abi_version(void) { return SEQIK_ABI_VERSION; }
+
+int seqik_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *seqik_last_error(void) { return g_err; }
+
+int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage)
+{
+    if (!legs || n_legs <= 0) return fail(SEQIK_ERR_BAD_ARG, "null legs%s");
+    if (first_stage < 1 || last_stage > 4 || first_stage > last_stage)
+        return fail(SEQIK_ERR_BAD_STAGE, "Maximum stage number is 4 and the list should be strictly incremental.%s");
+    for (int l = 0; l < n_legs; ++l) {
+        int rc = seqik::validate_leg(legs[l], first_stage, last_stage);
+        if (rc == SEQIK_ERR_BAD_BOUNDS)
+            return fail(rc, "Each lower bound must be strictly less than each upper bound.%s");
+        if (rc == SEQIK_ERR_X0_OUT_OF_BOUNDS)
+            return fail(rc, "Initial guess is outside of provided bounds%s");
+    }
+    return SEQIK_OK;
+}
+
+int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                           const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
+                           double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
+                           const SeqikOptions *opt, void *hip_stream)
+{
+    int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
+    if (rc != SEQIK_OK) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const seqik::LegConst *d_legs = nullptr;
+    rc = device_leg_table(legs, n_legs, &d_legs);
+    if (rc != SEQIK_OK) return rc;
+    return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
+                  d_status, d_nfev, opt, stream);
+}
+
+int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                    const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
+                    double *angles, double *fk, int32_t *status, int32_t *nfev, const SeqikOptions *opt)
+{
+    int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, pose, angles);
+    if (rc != SEQIK_OK) return rc;
+    const int64_t n_lf = n_seq * (int64_t)n_legs * n_frames;  // leg-frames
+    if (n_lf == 0) return SEQIK_OK;
+    if (opt) HIP_TRY(hipSetDevice(opt->device));
+    hipStream_t stream;
+    HIP_TRY(hipStreamCreate(&stream));
+    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr;
+    int32_t *d_status = nullptr, *d_nfev = nullptr;
+    const bool want_fk = fk && last_stage == 4;
+    int out = SEQIK_OK;
+    do {
+#define TRY_BREAK(expr)                                                                          \
+    {                                                                                            \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) { out = fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); break; } \
+    }
+        TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_pose), sizeof(double) * 15 * n_lf));
+        TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_angles), sizeof(double) * 7 * n_lf));
+        if (want_fk) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_fk), sizeof(double) * 27 * n_lf));
+        if (status) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_status), sizeof(int32_t) * 4 * n_lf));
+        if (nfev) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_nfev), sizeof(int32_t) * 4 * n_lf));
+        TRY_BREAK(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
+        // angles is in/out: earlier-stage columns are inputs when first_stage > 1
+        TRY_BREAK(hipMemcpyAsync(d_angles, angles, sizeof(double) * 7 * n_lf, hipMemcpyHostToDevice, stream));
+        if (d_status) TRY_BREAK(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
+        if (d_nfev) TRY_BREAK(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
+        out = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
+                                     d_fk, d_status, d_nfev, opt, stream);
+        if (out != SEQIK_OK) break;
+        TRY_BREAK(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
+        if (want_fk) TRY_BREAK(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
+        if (status) TRY_BREAK(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
+        if (nfev) TRY_BREAK(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
+        TRY_BREAK(hipStreamSynchronize(stream));
+#undef TRY_BREAK
+    } while (0);
+    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev);
+    (void)hipStreamDestroy(stream);
+    return out;
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+"""seqikpy_amd -- MI355X-native drop-in for the leg-IK path of ``seqikpy``.
+
+Same module / class names as the reference for this path:
+
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+
+All arithmetic runs in ``csrc/libseqik_hip.so`` (hand-written HIP for gfx950) behind the C ABI
+of ``include/seqik.h``; there is no CPU fallback.
+"""
+__version__ = "0.1.0"
+
+from . import data, utils  # noqa: F401
+from .kinematic_chain import KinematicChainGeneric, KinematicChainSeq  # noqa: F401
+from .leg_inverse_kinematics import LegInvKinGeneric, LegInvKinSeq  # noqa: F401

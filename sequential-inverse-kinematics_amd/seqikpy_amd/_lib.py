@@ -1,0 +1,209 @@
+"""ctypes binding of ``libseqik_hip.so`` (C ABI: ``include/seqik.h``).
+
+There is no CPU implementation behind this module: if the HIP library is missing, or no
+GPU is visible when a solve is requested, the call raises.  ``build()`` compiles the
+library in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+
+from .data import DOFS, SEGMENTS
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
+LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
+SOURCES = ["seqik_hip.hip", "seqik_core.hpp", "seqik_consts.hpp"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+
+SEQIK_OK = 0
+ERR_HIP, ERR_X0, ERR_BOUNDS, ERR_ARG, ERR_STAGE = -1, -2, -3, -4, -5
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+
+
+class SeqikLegParams(ctypes.Structure):
+    """Mirror of ``struct SeqikLegParams`` (include/seqik.h)."""
+    _fields_ = [("seg", ctypes.c_double * 4),
+                ("bounds", (ctypes.c_double * 2) * 7),
+                ("seeds", ctypes.c_double * 27)]
+
+
+class SeqikOptions(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+
+
+class SeqikLibraryError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def build(force: bool = False) -> str:
+    """Compiles ``csrc/seqik_hip.hip`` -> ``csrc/libseqik_hip.so`` (gfx950)."""
+    if force or is_stale():
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "seqik_hip.hip")]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+def load():
+    """Loads the HIP library; raises ``SeqikLibraryError`` if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SeqikLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "seqikpy_amd has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one
+        # process cannot both own the GPU, so when torch is installed let it load first: the
+        # dynamic linker then binds this library to the already-loaded runtime (same SONAME)
+        # and torch tensors / streams / RCCL can be shared with it.
+        if os.environ.get("SEQIK_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        L = ctypes.CDLL(LIB_PATH)
+        L.seqik_abi_version.restype = ctypes.c_int
+        L.seqik_device_count.restype = ctypes.c_int
+        L.seqik_last_error.restype = ctypes.c_char_p
+        L.seqik_validate_legs.restype = ctypes.c_int
+        L.seqik_validate_legs.argtypes = [ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+        L.seqik_solve_seq.restype = ctypes.c_int
+        L.seqik_solve_seq.argtypes = [_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                      ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
+                                      _dp, _dp, _ip, _ip, ctypes.POINTER(SeqikOptions)]
+        L.seqik_solve_seq_device.restype = ctypes.c_int
+        L.seqik_solve_seq_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+        _lib = L
+        return _lib
+
+
+EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_validate_legs",
+                    "seqik_solve_seq", "seqik_solve_seq_device"]
+
+
+def make_leg_params(leg, bounds_dof, body_size, initial_angles) -> SeqikLegParams:
+    """Packs the reference's dict-shaped chain description of one leg into the ABI struct."""
+    lp = SeqikLegParams()
+    for i, seg in enumerate(SEGMENTS):
+        lp.seg[i] = float(body_size[f"{leg}_{seg}"])
+    for i, dof in enumerate(DOFS):
+        lb, ub = bounds_dof[f"{leg}_{dof}"]
+        lp.bounds[i][0] = float(lb)
+        lp.bounds[i][1] = float(ub)
+    seeds = np.concatenate([np.asarray(initial_angles[leg][f"stage_{k}"], dtype=np.float64).ravel()
+                            for k in (1, 2, 3, 4)])
+    if seeds.shape != (27,):
+        raise ValueError(f"initial_angles[{leg!r}] must hold 4, 6, 8 and 9 values for stage_1..stage_4")
+    for i in range(27):
+        lp.seeds[i] = float(seeds[i])
+    return lp
+
+
+def leg_params_from_arrays(seg, bounds, seeds) -> SeqikLegParams:
+    lp = SeqikLegParams()
+    for i in range(4):
+        lp.seg[i] = float(seg[i])
+    for i in range(7):
+        lp.bounds[i][0] = float(bounds[i][0])
+        lp.bounds[i][1] = float(bounds[i][1])
+    for i in range(27):
+        lp.seeds[i] = float(seeds[i])
+    return lp
+
+
+def _raise(rc: int):
+    msg = load().seqik_last_error().decode("utf-8", "replace")
+    if rc in (ERR_X0, ERR_BOUNDS, ERR_STAGE):
+        raise ValueError(msg)
+    if rc == ERR_ARG:
+        raise ValueError(f"seqik: bad argument: {msg}")
+    raise SeqikLibraryError(f"seqik: HIP error: {msg}")
+
+
+def validate_legs(legs, first_stage=1, last_stage=4):
+    arr = (SeqikLegParams * len(legs))(*legs)
+    rc = load().seqik_validate_legs(arr, len(legs), first_stage, last_stage)
+    if rc != SEQIK_OK:
+        _raise(rc)
+
+
+def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
+              device=0, block_size=0):
+    """``seqik_solve_seq`` on host arrays.
+
+    pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
+    (S, L, N, 7) with earlier-stage columns filled when ``first_stage > 1``.
+    Returns dict(angles, fk or None, status or None, nfev or None).
+    """
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    if pose.ndim != 5 or pose.shape[3:] != (5, 3):
+        raise ValueError(f"pose must have shape (S, L, N, 5, 3), got {pose.shape}")
+    S, L, N = pose.shape[:3]
+    if len(legs) != L:
+        raise ValueError("one SeqikLegParams per leg expected")
+    if angles is None:
+        angles = np.zeros((S, L, N, 7), dtype=np.float64)
+    else:
+        angles = np.array(angles, dtype=np.float64, order="C", copy=True)
+        if angles.shape != (S, L, N, 7):
+            raise ValueError(f"angles must have shape {(S, L, N, 7)}")
+    fk = np.full((S, L, N, 9, 3), np.nan) if (want_fk and last_stage == 4) else None
+    status = np.full((S, L, N, 4), -1, dtype=np.int32) if want_diag else None
+    nfev = np.zeros((S, L, N, 4), dtype=np.int32) if want_diag else None
+    arr = (SeqikLegParams * L)(*legs)
+    opt = SeqikOptions()
+    opt.device = device
+    opt.block_size = block_size
+    lib = load()
+    rc = lib.seqik_solve_seq(pose.ctypes.data_as(_dp), S, L, N, arr, first_stage, last_stage,
+                             angles.ctypes.data_as(_dp),
+                             fk.ctypes.data_as(_dp) if fk is not None else None,
+                             status.ctypes.data_as(_ip) if status is not None else None,
+                             nfev.ctypes.data_as(_ip) if nfev is not None else None,
+                             ctypes.byref(opt))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return dict(angles=angles, fk=fk, status=status, nfev=nfev)
+
+
+def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
+                     first_stage=1, last_stage=4, stream=0, block_size=0):
+    """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``."""
+    arr = (SeqikLegParams * n_legs)(*legs)
+    opt = SeqikOptions()
+    opt.block_size = block_size
+    rc = load().seqik_solve_seq_device(ctypes.c_void_p(d_pose), n_seq, n_legs, n_frames, arr, first_stage,
+                                       last_stage, ctypes.c_void_p(d_angles), ctypes.c_void_p(d_fk or None),
+                                       ctypes.c_void_p(d_status or None), ctypes.c_void_p(d_nfev or None),
+                                       ctypes.byref(opt), ctypes.c_void_p(stream or None))
+    if rc != SEQIK_OK:
+        _raise(rc)

@@ -1,0 +1,283 @@
+"""Leg inverse kinematics -- host-side mirror of the reference's
+``seqikpy/leg_inverse_kinematics.py`` (``LegInvKinBase`` :25-133, ``LegInvKinSeq`` :136-403).
+
+Same classes, constructor arguments, method names, dictionary outputs and exceptions; the
+per-(frame, stage) ``ikpy``/``scipy`` solve loop (:259-282) is replaced by one call into the
+HIP library (``include/seqik.h``) for all legs, stages and frames.  There is no CPU path: a
+missing library or GPU raises.
+"""
+from abc import ABC, abstractmethod
+from pathlib import Path
+from typing import Dict, Literal, Optional, Tuple, Union
+import logging
+
+import numpy as np
+
+from . import _lib
+from .data import DOFS, INITIAL_ANGLES
+from .kinematic_chain import Chain, KinematicChainBase, KinematicChainGeneric, KinematicChainSeq, LEG_NAMES
+from .utils import save_file
+
+logging.basicConfig(format=" %(asctime)s - %(levelname)s- %(message)s", handlers=[logging.StreamHandler()])
+
+#: joints stored by each stage (leg_inverse_kinematics.py:285-320)
+STAGE_DOFS = {1: ["ThC_yaw", "ThC_pitch"], 2: ["ThC_roll", "CTr_pitch"], 3: ["CTr_roll", "FTi_pitch"],
+              4: ["TiTa_pitch"]}
+STAGE_LINKS = {1: 4, 2: 6, 3: 8, 4: 9}
+
+
+def _rot(axis, a):
+    c, s = np.cos(a), np.sin(a)
+    x, y, z = axis
+    return np.array([[x * x + (1 - x * x) * c, x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                     [x * y * (1 - c) + z * s, y * y + (1 - y * y) * c, y * z * (1 - c) - x * s],
+                     [x * z * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z + (1 - z * z) * c]])
+
+
+def _link_matrix(link, theta):
+    m = np.eye(4)
+    m[:3, 3] = link.origin_translation
+    r, p, y = link.origin_orientation
+    m[:3, :3] = _rot((0, 0, 1), y) @ _rot((0, 1, 0), p) @ _rot((1, 0, 0), r)
+    if link.has_rotation:
+        h = np.eye(4)
+        h[:3, :3] = _rot(tuple(link.rotation), theta)
+        m = m @ h
+    return m
+
+
+class LegInvKinBase(ABC):
+    """Abstract class to calculate inverse kinematics for leg joints.
+
+    Parameters
+    ----------
+    aligned_pos : Dict[str, np.ndarray]
+        Aligned pose, ``"<side><segment>_leg" -> (N_frames, N_key_points, 3)``.
+    kinematic_chain_class : KinematicChainBase
+        Kinematic chain description of the legs.
+    initial_angles : Dict[str, Dict[str, np.ndarray]], optional
+        Seeds per leg and stage; defaults to ``data.INITIAL_ANGLES``.
+    log_level : {"DEBUG", "INFO", "WARNING", "ERROR"}
+    """
+
+    def __init__(self, aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainBase,
+                 initial_angles: Optional[Dict[str, np.ndarray]] = None,
+                 log_level: Literal["DEBUG", "INFO", "WARNING", "ERROR"] = "INFO") -> None:
+        self.aligned_pos = aligned_pos
+        self.kinematic_chain_class = kinematic_chain_class
+        self.initial_angles = INITIAL_ANGLES if initial_angles is None else initial_angles
+        self.logger = logging.getLogger(self.__class__.__name__)
+        self.logger.setLevel(getattr(logging, log_level.upper(), None))
+        #: HIP device ordinal used by this object
+        self.device = 0
+
+    # -- per-frame seam (reference :62-77) ---------------------------------------------
+    def calculate_ik(self, kinematic_chain: Chain, target_pos: np.ndarray,
+                     initial_angles: np.ndarray = None) -> np.ndarray:
+        """Joint angles of ``kinematic_chain`` that bring its end effector closest to ``target_pos``.
+
+        One single-frame, single-stage launch of the HIP solver (the batched entry points are
+        the fast path; this seam exists for API compatibility)."""
+        spec = kinematic_chain.spec
+        if spec.get("kind") != "seq":
+            raise NotImplementedError("calculate_ik is implemented for KinematicChainSeq chains")
+        stage, leg, factory = spec["stage"], spec["leg"], spec["factory"]
+        n = STAGE_LINKS[stage]
+        x0 = np.zeros(n) if initial_angles is None else np.asarray(initial_angles, dtype=np.float64)
+        if x0.shape != (n,):
+            raise ValueError(f"Your joints vector length is {x0.size} but you have {n} links")
+        seeds = {leg: {f"stage_{k}": np.zeros(STAGE_LINKS[k]) for k in (1, 2, 3, 4)}}
+        seeds[leg][f"stage_{stage}"] = x0
+        lp = _lib.make_leg_params(leg, factory.bounds_dof, factory.body_size, seeds)
+        pose = np.zeros((1, 1, 1, 5, 3))
+        pose[0, 0, 0, stage] = np.asarray(target_pos, dtype=np.float64)
+        angles = np.zeros((1, 1, 1, 7))
+        if spec["prior_angles"] is not None:
+            angles[0, 0, 0] = spec["prior_angles"]
+        out = _lib.solve_seq(pose, [lp], stage, stage, angles=angles, want_fk=False, device=self.device)
+        res = x0.copy()
+        lo = np.array([l.bounds[0] for l in kinematic_chain.links])
+        hi = np.array([l.bounds[1] for l in kinematic_chain.links])
+        # scipy shifts start entries that sit on a bound inwards by 1e-10 * max(1, |bound|)
+        near_lo = np.isfinite(lo) & (res - lo <= np.minimum(hi - res, 1e-10 * np.maximum(1, np.abs(lo))))
+        near_hi = np.isfinite(hi) & (hi - res <= np.minimum(res - lo, 1e-10 * np.maximum(1, np.abs(hi))))
+        res[near_lo] = (lo + 1e-10 * np.maximum(1, np.abs(lo)))[near_lo]
+        res[near_hi] = (hi - 1e-10 * np.maximum(1, np.abs(hi)))[near_hi]
+        names = [l.name for l in kinematic_chain.links]
+        for dof in STAGE_DOFS[stage]:
+            res[names.index(f"{leg}_{dof}")] = out["angles"][0, 0, 0, DOFS.index(dof)]
+        return res
+
+    def calculate_fk(self, kinematic_chain: Chain, joint_angles: np.ndarray) -> np.ndarray:
+        """Positions of every link frame of ``kinematic_chain`` at ``joint_angles`` (n_links, 3)."""
+        if len(joint_angles) != len(kinematic_chain.links):
+            raise ValueError(f"Your joints vector length is {len(joint_angles)} but you have "
+                             f"{len(kinematic_chain.links)} links")
+        frame = np.eye(4)
+        out = np.zeros((len(kinematic_chain.links), 3))
+        for i, (link, theta) in enumerate(zip(kinematic_chain.links, joint_angles)):
+            frame = frame @ _link_matrix(link, theta)
+            out[i] = frame[:3, 3]
+        return out
+
+    def get_scale_factor(self, vector: np.ndarray, length: float) -> float:
+        """Ratio between ``length`` and the summed segment lengths of ``vector``."""
+        return length / np.sum(np.linalg.norm(np.diff(vector, axis=0), axis=1))
+
+    @abstractmethod
+    def calculate_ik_stage(self, end_effector_pos, origin, initial_angles, segment_name, **kwargs) -> np.ndarray:
+        ...
+
+    @abstractmethod
+    def run_ik_and_fk(self, export_path: Union[Path, str] = None, **kwargs
+                      ) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+        ...
+
+    # -- shared helpers ----------------------------------------------------------------
+    def _leg_segments(self):
+        """(segment_name, leg_name, array) of the legs this object will process, in dict order."""
+        out = []
+        for segment_name, segment_array in self.aligned_pos.items():
+            if "leg" not in segment_name.lower():
+                self.logger.debug("Segment %s is not a leg, continuing...", segment_name)
+                continue
+            leg_name = segment_name.split("_")[0]
+            if leg_name not in self.kinematic_chain_class.body_size:
+                self.logger.warning("Leg %s is not in the kinematic chain, continuing...", leg_name)
+                continue
+            out.append((segment_name, leg_name, segment_array))
+        return out
+
+    def _export(self, export_path, forward_kinematics_dict):
+        if export_path is not None:
+            save_file(Path(export_path) / "forward_kinematics.pkl", forward_kinematics_dict)
+            save_file(Path(export_path) / "leg_joint_angles.pkl", self.joint_angles_dict)
+            self.logger.info("Joint angles and forward kinematics are saved at %s", export_path)
+
+
+class LegInvKinSeq(LegInvKinBase):
+    """Sequential inverse kinematics: four stages per frame, each matching one more joint.
+
+    >>> seq_ik = LegInvKinSeq(aligned_pos, KinematicChainSeq(BOUNDS, ["RF", "LF"]), INITIAL_ANGLES)
+    >>> leg_joint_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=DATA_PATH)
+    """
+
+    def __init__(self, aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainSeq,
+                 initial_angles: Optional[Dict[str, np.ndarray]] = None,
+                 log_level: Literal["DEBUG", "INFO", "WARNING", "ERROR"] = "INFO") -> None:
+        super().__init__(aligned_pos, kinematic_chain_class, initial_angles, log_level)
+        self.joint_angles_dict = {}
+        #: scipy termination status / nfev of the last run when ``diagnostics=True`` was passed
+        self.solver_status = {}
+        self.solver_nfev = {}
+
+    def _leg_params(self, leg_name, initial_angles=None):
+        kc = self.kinematic_chain_class
+        return _lib.make_leg_params(leg_name, kc.bounds_dof, kc.body_size,
+                                    self.initial_angles if initial_angles is None else initial_angles)
+
+    def _prior_angles(self, leg_name, n_frames, first_stage):
+        """(N, 7) array with the columns of stages < first_stage taken from ``joint_angles_dict``
+        (raises KeyError like the reference's chain factory when they are missing)."""
+        angles = np.zeros((n_frames, 7))
+        for stage in range(1, first_stage):
+            for dof in STAGE_DOFS[stage]:
+                col = np.asarray(self.joint_angles_dict[f"Angle_{leg_name}_{dof}"], dtype=np.float64)
+                angles[:, DOFS.index(dof)] = col[:n_frames]
+        return angles
+
+    def calculate_ik_stage(self, end_effector_pos: np.ndarray, origin: np.ndarray, initial_angles: np.ndarray,
+                           segment_name: str, **kwargs) -> np.ndarray:
+        """Inverse kinematics of one stage over all frames of one leg.
+
+        ``segment_name`` is the leg (RF, LF, ...), ``stage`` (kwarg) in 1..4.  Joint angles are
+        stored in ``self.joint_angles_dict``; returns the joint positions ``(N, n_links, 3)``,
+        meaningful for stage 4 only (as in the reference, :279-282)."""
+        stage = kwargs.get("stage", 1)
+        if segment_name not in LEG_NAMES:
+            raise ValueError(f"Segment name ({segment_name}) is not valid.")
+        if not 1 <= stage <= 4:
+            raise ValueError(f"Stage ({stage}) should be between 1 and 4.")
+        end_effector_pos = np.asarray(end_effector_pos, dtype=np.float64)
+        frames_no = end_effector_pos.shape[0]
+        origin = np.asarray(origin, dtype=np.float64)
+        if origin.size == 3:
+            origin = np.tile(origin.reshape(3), (frames_no, 1))
+        n_links = len(initial_angles)
+        if n_links != STAGE_LINKS[stage]:
+            raise ValueError(f"Your joints vector length is {n_links} but you have {STAGE_LINKS[stage]} links")
+        seeds = {segment_name: {f"stage_{k}": np.zeros(STAGE_LINKS[k]) for k in (1, 2, 3, 4)}}
+        seeds[segment_name][f"stage_{stage}"] = np.asarray(initial_angles, dtype=np.float64)
+        lp = self._leg_params(segment_name, seeds)
+        pose = np.zeros((1, 1, frames_no, 5, 3))
+        pose[0, 0, :, 0] = origin
+        pose[0, 0, :, stage] = end_effector_pos
+        prior = self._prior_angles(segment_name, frames_no, stage)
+        out = _lib.solve_seq(pose, [lp], stage, stage, angles=prior[None, None], want_fk=(stage == 4),
+                             device=self.device)
+        for dof in STAGE_DOFS[stage]:
+            self.joint_angles_dict[f"Angle_{segment_name}_{dof}"] = out["angles"][0, 0, :, DOFS.index(dof)].copy()
+        self.logger.debug("Stage %d is completed!", stage)
+        if stage == 4:
+            return out["fk"][0, 0]
+        return np.full((frames_no, n_links, 3), np.nan)
+
+    def run_ik_and_fk(self, export_path: Union[Path, str] = None, **kwargs
+                      ) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+        """Inverse and forward kinematics of every leg.
+
+        kwargs: ``stages`` (default [1, 2, 3, 4], consecutive), ``hide_progress_bar`` (accepted,
+        unused: there is no per-frame host loop), ``diagnostics`` (also collect scipy status/nfev).
+        Returns ``(joint_angles_dict, forward_kinematics_dict)``."""
+        stages = list(kwargs.get("stages", [1, 2, 3, 4]))
+        diagnostics = bool(kwargs.get("diagnostics", False))
+        if max(stages) > 4 or not all(np.diff(stages) == 1):
+            raise ValueError("Maximum stage number is 4 and the list should be strictly incremental.")
+        first_stage, last_stage = stages[0], stages[-1]
+        forward_kinematics_dict = {}
+        self.logger.info("Computing joint angles and forward kinematics...")
+
+        segments = self._leg_segments()
+        # one launch per group of legs with the same number of frames (normally a single group)
+        groups = {}
+        for item in segments:
+            groups.setdefault(np.asarray(item[2]).shape[0], []).append(item)
+        for n_frames, items in groups.items():
+            legs = [self._leg_params(leg_name) for _, leg_name, _ in items]
+            pose = np.stack([np.asarray(arr, dtype=np.float64)[:, :5, :] for _, _, arr in items])[None]
+            prior = np.stack([self._prior_angles(leg_name, n_frames, first_stage) for _, leg_name, _ in items])[None]
+            out = _lib.solve_seq(pose, legs, first_stage, last_stage, angles=prior, want_fk=True,
+                                 want_diag=diagnostics, device=self.device)
+            for li, (segment_name, leg_name, _) in enumerate(items):
+                for stage in stages:
+                    for dof in STAGE_DOFS[stage]:
+                        self.joint_angles_dict[f"Angle_{leg_name}_{dof}"] = out["angles"][0, li, :, DOFS.index(dof)].copy()
+                if last_stage == 4:
+                    forward_kinematics_dict[segment_name] = out["fk"][0, li].copy()
+                else:  # the reference returns an uninitialised array here
+                    forward_kinematics_dict[segment_name] = np.full((n_frames, STAGE_LINKS[last_stage], 3), np.nan)
+                if diagnostics:
+                    self.solver_status[leg_name] = out["status"][0, li].copy()
+                    self.solver_nfev[leg_name] = out["nfev"][0, li].copy()
+        # keep the reference's insertion order of the FK dict (dict order of aligned_pos)
+        forward_kinematics_dict = {name: forward_kinematics_dict[name] for name, _, _ in segments}
+        self.logger.debug("Joint angles and forward kinematics are computed.")
+        self._export(export_path, forward_kinematics_dict)
+        return self.joint_angles_dict, forward_kinematics_dict
+
+
+class LegInvKinGeneric(LegInvKinBase):
+    """Generic (single 9-link chain, claw only) inverse kinematics -- reference :406-613.
+
+    Listed as a follow-up row in SURVEY.md 8(f)-3; not implemented in this round."""
+
+    def __init__(self, aligned_pos, kinematic_chain_class: KinematicChainGeneric, initial_angles=None,
+                 log_level="INFO") -> None:
+        super().__init__(aligned_pos, kinematic_chain_class, initial_angles, log_level)
+        self.joint_angles_dict = {}
+
+    def calculate_ik_stage(self, end_effector_pos, origin, initial_angles, segment_name, **kwargs):
+        raise NotImplementedError("LegInvKinGeneric is not implemented yet (SURVEY.md 8f-3)")
+
+    def run_ik_and_fk(self, export_path=None, **kwargs):
+        raise NotImplementedError("LegInvKinGeneric is not implemented yet (SURVEY.md 8f-3)")

@@ -1,0 +1,42 @@
+// TEST INFRASTRUCTURE ONLY -- not part of the product, never loaded by seqikpy_amd.
+//
+// Runs the kernel's per-chain device function (csrc/seqik_core.hpp, `__host__ __device__`)
+// on the HOST, one chain at a time, so that the CPU-only test tier can compare the
+// kernel's arithmetic bit for bit with the generic restatement in oracle/seqik_oracle.c
+// without a GPU.  Built by tests/conftest.py with `hipcc --offload-host-only`.
+#include "../../sequential-inverse-kinematics_amd/csrc/seqik_core.hpp"
+#include "../../sequential-inverse-kinematics_amd/csrc/seqik_consts.hpp"
+
+extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const SeqikLegParams *leg,
+                                 int32_t first_stage, int32_t last_stage, double *angles, double *fk,
+                                 int32_t *status, int32_t *nfev)
+{
+    int rc = seqik::validate_leg(*leg, first_stage, last_stage);
+    if (rc != SEQIK_OK) return rc;
+    seqik::LegConst lc;
+    seqik::make_leg_consts(*leg, lc);
+    seqik::ChainIO io;
+    io.pose = pose;
+    io.angles = angles;
+    io.fk = (fk && last_stage == 4) ? fk : nullptr;
+    io.status = status; io.nfev = nfev;
+    io.n_frames = n_frames;
+    const bool want_fk = io.fk != nullptr;
+    const bool diag = status || nfev;
+    if (want_fk && first_stage == 3) seqik::fill_fk_prefix_rows<3>(lc, io);
+    if (want_fk && first_stage == 4) seqik::fill_fk_prefix_rows<4>(lc, io);
+    // same launch sequence as seqik_hip.hip::launch(): one pass over all frames per stage
+    for (int stage = first_stage; stage <= last_stage; ++stage) {
+#define RUN(S, FK)                                                        \
+    if (diag) seqik::run_stage<S, FK, true>(lc, io);                      \
+    else seqik::run_stage<S, FK, false>(lc, io);
+        if (stage == 1) { RUN(1, false) }
+        else if (stage == 2) { if (want_fk) { RUN(2, true) } else { RUN(2, false) } }
+        else if (stage == 3) { if (want_fk) { RUN(3, true) } else { RUN(3, false) } }
+        else { if (want_fk) { RUN(4, true) } else { RUN(4, false) } }
+#undef RUN
+    }
+    return SEQIK_OK;
+}
+
+extern "C" void harness_sincos(double x, double *s, double *c) { seqik::sincos_cw(x, *s, *c); }
