@@ -49,6 +49,8 @@ def lib():
         L.oracle_stage_solve.argtypes = [ctypes.c_int, dp, dp, dp, dp, dp, dp, ip, ip]
         L.oracle_stage_fk.restype = ctypes.c_int
         L.oracle_stage_fk.argtypes = [ctypes.c_int, dp, dp, dp, dp, dp]
+        L.oracle_seq_batch.restype = ctypes.c_int
+        L.oracle_seq_batch.argtypes = [dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, dp, dp, dp, dp, dp]
         L.oracle_sincos.restype = None
         L.oracle_sincos.argtypes = [ctypes.c_double, dp, dp]
         _lib = L
@@ -92,6 +94,22 @@ def seq_leg(pose, seg, bounds, seeds, first_stage=1, last_stage=4, prior_angles=
     if rc != 0:
         raise ValueError(f"{ERRORS.get(rc, rc)} (frame {ef.value}, stage {es.value})")
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)
+
+
+def seq_batch(pose, segs, bounds, seeds, want_fk=True):
+    """[S, L, N, 5, 3] key points -> dict(angles [S, L, N, 7], fk [S, L, N, 9, 3]); one C call (the GIL
+    is released for its whole duration, so callers can run one batch per thread)."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    S, L, N = pose.shape[:3]
+    segs = np.ascontiguousarray(segs, dtype=np.float64).reshape(L, 4)
+    bounds = np.ascontiguousarray(bounds, dtype=np.float64).reshape(L, 7, 2)
+    seeds = np.ascontiguousarray(seeds, dtype=np.float64).reshape(L, 27)
+    angles = np.zeros((S, L, N, 7))
+    fk = np.zeros((S, L, N, 9, 3)) if want_fk else None
+    rc = lib().oracle_seq_batch(_dp(pose), S, L, N, _dp(segs), _dp(bounds), _dp(seeds), _dp(angles), _dp(fk))
+    if rc != 0:
+        raise ValueError(ERRORS.get(rc, str(rc)))
+    return dict(angles=angles, fk=fk)
 
 
 def generic_leg(pose, seg, bounds, seed9, want_fk=True):

@@ -1042,4 +1042,24 @@ int oracle_stage_fk(int stage, const double *seg, const double *bounds, const do
     return SEQIK_OK;
 }
 
+/*
+ * Batch driver for the CPU baseline: [n_seq][n_legs] independent chains, each run exactly as
+ * oracle_seq_leg does (one call per (sequence, leg), the task shape of the reference's
+ * examples/example_leg_inv_kinematics_parallel.py:186-187).  Layouts as in include/seqik.h:
+ * pose [n_seq][n_legs][N][5][3], angles [..][N][7], fk nullable [..][N][9][3];
+ * seg [n_legs][4], bounds [n_legs][7][2], seeds [n_legs][27].
+ */
+int oracle_seq_batch(const double *pose, int64_t n_seq, int32_t n_legs, int64_t N, const double *seg,
+                     const double *bounds, const double *seeds, double *angles, double *fk)
+{
+    for (int64_t s = 0; s < n_seq; ++s)
+        for (int32_t l = 0; l < n_legs; ++l) {
+            int64_t c = s * n_legs + l;
+            int rc = oracle_seq_leg(pose + c * N * 15, N, seg + 4 * l, bounds + 14 * l, seeds + 27 * l, 1, 4,
+                                    angles + c * N * 7, fk ? fk + c * N * 27 : NULL, NULL, NULL, NULL, NULL);
+            if (rc != SEQIK_OK) return rc;
+        }
+    return SEQIK_OK;
+}
+
 int oracle_version(void) { return 1; }

@@ -1,0 +1,92 @@
+"""CPU tier: the C-ABI shared library loads and exports every symbol include/seqik.h declares;
+argument validation works without a GPU; a missing library fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG_PARENT, ROOT, leg_arrays, load_golden
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "seqik.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(seqik_[a-z_]+)\s*\(", text)))
+
+
+def test_header_declares_expected_entry_points():
+    assert declared_functions() == sorted(["seqik_abi_version", "seqik_device_count", "seqik_last_error",
+                                           "seqik_validate_legs", "seqik_solve_seq", "seqik_solve_seq_device"])
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    lib = hiplib.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
+    assert lib.seqik_abi_version() == 1
+
+
+def test_struct_layout_matches_header(hiplib):
+    assert ctypes.sizeof(hiplib.SeqikLegParams) == 8 * (4 + 14 + 27)
+    assert ctypes.sizeof(hiplib.SeqikOptions) == 32
+
+
+def test_validate_legs_error_codes(hiplib):
+    z = load_golden("df3d_100")
+    _, seg, b, seeds = leg_arrays(z, "RF")
+    good = hiplib.leg_params_from_arrays(seg, b, seeds)
+    hiplib.validate_legs([good])
+    bad_seed = seeds.copy()
+    bad_seed[1] = 4.0
+    with pytest.raises(ValueError, match="Initial guess is outside of provided bounds"):
+        hiplib.validate_legs([hiplib.leg_params_from_arrays(seg, b, bad_seed)])
+    hiplib.validate_legs([hiplib.leg_params_from_arrays(seg, b, bad_seed)], 2, 4)  # stage 1 not run: not checked
+    bb = b.copy()
+    bb[2] = (1.0, -1.0)
+    with pytest.raises(ValueError, match="strictly less"):
+        hiplib.validate_legs([hiplib.leg_params_from_arrays(seg, bb, seeds)])
+    with pytest.raises(ValueError, match="Maximum stage number is 4"):
+        hiplib.validate_legs([good], 2, 5)
+
+
+def test_solve_rejects_bad_arguments_before_touching_the_gpu(hiplib):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RF")
+    lp = hiplib.leg_params_from_arrays(seg, b, seeds)
+    with pytest.raises(ValueError):
+        hiplib.solve_seq(pose[None, None, :4], [lp], 3, 2)
+    with pytest.raises(ValueError):
+        hiplib.solve_seq(pose[:4], [lp])  # wrong rank
+    bad = seeds.copy()
+    bad[26] = 9.0  # claw seed outside +-pi
+    with pytest.raises(ValueError, match="outside of provided bounds"):
+        hiplib.solve_seq(pose[None, None, :4], [hiplib.leg_params_from_arrays(seg, b, bad)])
+
+
+def test_missing_library_fails_loudly():
+    code = ("import sys; sys.path.insert(0, %r); from seqikpy_amd import _lib\n"
+            "try:\n    _lib.load()\nexcept _lib.SeqikLibraryError as e:\n    print('LOUD', e)\n" % PKG_PARENT)
+    env = dict(os.environ, SEQIK_LIB="/nonexistent/libseqik_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "LOUD" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_does_not_import_the_oracle():
+    """The package must not reach into oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(PKG_PARENT, "seqikpy_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            for needle in ("import oracle", "from oracle", "c_oracle", "ref_import", "libseqik_oracle"):
+                assert needle not in src, (fn, needle)
+    csrc = os.path.join(PKG_PARENT, "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".hpp", ".h", ".cpp")):
+            for line in open(os.path.join(csrc, fn)):
+                if line.lstrip().startswith("#include"):
+                    assert "oracle" not in line, (fn, line)

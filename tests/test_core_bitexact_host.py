@@ -1,0 +1,88 @@
+"""CPU tier: the kernel's device functions (csrc/seqik_core.hpp), compiled for the host by
+tests/harness, must reproduce the generic C oracle BIT FOR BIT -- angles, FK, scipy status and
+nfev.  The same comparison runs on the GPU in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import leg_arrays, load_golden
+
+
+def _cmp(h, o):
+    assert np.array_equal(h["angles"], o["angles"])
+    assert np.array_equal(h["fk"], o["fk"])
+    assert np.array_equal(h["status"], o["status"])
+    assert np.array_equal(h["nfev"], o["nfev"])
+
+
+def test_sincos_identical(oracle, host_harness):
+    rng = np.random.default_rng(1)
+    for x in np.concatenate([rng.uniform(-3.3, 3.3, 5000), [0.0, -0.0, np.pi, -np.pi, 1e-9]]):
+        assert oracle.sincos(x) == host_harness.sincos(x)
+
+
+@pytest.mark.parametrize("name,frames", [("anipose_shipped", 1500), ("df3d_1000", 1000), ("df3d_100", 100)])
+def test_core_equals_oracle_on_recordings(oracle, host_harness, name, frames):
+    z = load_golden(name)
+    for leg in z["legs"]:
+        pose, seg, b, seeds = leg_arrays(z, str(leg))
+        pose = pose[:frames]
+        _cmp(host_harness.run(pose, seg, b, seeds), oracle.seq_leg(pose, seg, b, seeds))
+
+
+def test_core_equals_oracle_through_degenerate_episode(oracle, host_harness):
+    z = load_golden("anipose_shipped")
+    pose, seg, b, seeds = leg_arrays(z, "LF")
+    _cmp(host_harness.run(pose[200:400], seg, b, seeds), oracle.seq_leg(pose[200:400], seg, b, seeds))
+
+
+def test_core_without_diagnostics_gives_same_angles(host_harness):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "LH")
+    a = host_harness.run(pose, seg, b, seeds, diag=True)
+    c = host_harness.run(pose, seg, b, seeds, diag=False)
+    assert np.array_equal(a["angles"], c["angles"]) and np.array_equal(a["fk"], c["fk"])
+
+
+@pytest.mark.parametrize("first,last", [(1, 1), (1, 2), (1, 3), (2, 2), (2, 4), (3, 4), (4, 4)])
+def test_core_stage_subsets(oracle, host_harness, first, last):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RH")
+    full = oracle.seq_leg(pose, seg, b, seeds)
+    prior = np.zeros_like(full["angles"])
+    prior[:, : 2 * (first - 1)] = full["angles"][:, : 2 * (first - 1)]
+    o = oracle.seq_leg(pose, seg, b, seeds, first, last, prior_angles=prior)
+    h = host_harness.run(pose, seg, b, seeds, first, last, prior=prior)
+    ncol = min(2 * last, 7)
+    assert np.array_equal(h["angles"][:, :ncol], o["angles"][:, :ncol])
+    assert np.array_equal(h["angles"][:, :ncol], full["angles"][:, :ncol])
+    assert np.array_equal(h["status"][:, first - 1:last], o["status"][:, first - 1:last])
+    if last == 4:
+        assert np.array_equal(h["fk"], full["fk"])
+
+
+def test_core_equals_oracle_on_synthetic(oracle, host_harness):
+    """i.i.d. and smooth synthetic key points (bench workload), incl. targets
+    that jump across the workspace from frame to frame."""
+    from seqikpy_amd import data, synthetic, utils
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    for variant in ("iid", "smooth"):
+        pose = synthetic.synthetic_pose(2, 40, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                        variant=variant)
+        for li, leg in enumerate(legs):
+            seg, b, seeds = oracle.leg_params(leg, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+            for s in range(2):
+                _cmp(host_harness.run(pose[s, li], seg, b, seeds), oracle.seq_leg(pose[s, li], seg, b, seeds))
+
+
+def test_core_rejects_bad_parameters(host_harness):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RF")
+    bad = seeds.copy()
+    bad[4 + 3] = 10.0  # stage-2 roll seed outside [-pi, pi]
+    with pytest.raises(ValueError):
+        host_harness.run(pose[:2], seg, b, bad)
+    bb = b.copy()
+    bb[6] = (0.0, 0.0)
+    with pytest.raises(ValueError):
+        host_harness.run(pose[:2], seg, bb, seeds)

@@ -1,0 +1,238 @@
+"""GPU tier (`-m gpu`): parity of the HIP path, called through the C ABI, against the oracle
+(bit for bit), the committed golden vectors (1e-4 rad), and size-independent properties at
+BASELINE.json's full sizes."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import DOFS, good_frames, leg_arrays, load_golden
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # rad -- BASELINE.json north star
+
+
+def _params(lib, z, legs):
+    return [lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+
+
+def _stack(z, legs, sl=slice(None)):
+    return np.stack([z[f"{l}_pose"][sl] for l in legs])[None]
+
+
+@pytest.fixture(scope="module")
+def lib(hiplib):
+    if hiplib.load().seqik_device_count() < 1:
+        pytest.fail("GPU tier needs a GPU: the HIP path must not be skipped silently")
+    return hiplib
+
+
+@pytest.mark.parametrize("name", ["anipose_scipy_cut", "df3d_100", "df3d_1000"])
+def test_hip_equals_oracle_bit_for_bit(lib, oracle, name):
+    z = load_golden(name)
+    legs = [str(l) for l in z["legs"]]
+    out = lib.solve_seq(_stack(z, legs), _params(lib, z, legs), want_fk=True, want_diag=True)
+    for i, leg in enumerate(legs):
+        ref = oracle.seq_leg(*leg_arrays(z, leg))
+        assert np.array_equal(out["angles"][0, i], ref["angles"]), leg
+        assert np.array_equal(out["fk"][0, i], ref["fk"]), leg
+        assert np.array_equal(out["status"][0, i], ref["status"]), leg
+        assert np.array_equal(out["nfev"][0, i], ref["nfev"]), leg
+
+
+def test_hip_vs_shipped_golden_full_recording(lib, oracle):
+    """Config 4 stand-in: the shipped 6000-frame anipose recording, RF + LF in one launch."""
+    z = load_golden("anipose_shipped")
+    legs = ["RF", "LF"]
+    out = lib.solve_seq(_stack(z, legs), _params(lib, z, legs), want_fk=True)
+    cut = z["fk_frames"]
+    for i, leg in enumerate(legs):
+        ok = good_frames(leg, 6000)
+        err = np.abs(out["angles"][0, i] - z[f"{leg}_angles"])
+        assert err[ok].max() < TOL, (leg, err[ok].max())
+        assert np.all(~ok[np.where(err.max(1) >= TOL)[0]])
+        assert np.abs(out["fk"][0, i][cut] - z[f"{leg}_fk_cut"])[ok[cut]].max() < TOL
+        ref = oracle.seq_leg(*leg_arrays(z, leg))
+        assert np.array_equal(out["angles"][0, i], ref["angles"])
+
+
+def test_hip_vs_reference_source_run_df3d(lib):
+    """Config 2: all 6 legs of the full locomotion recording vs the reference source run here."""
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    out = lib.solve_seq(_stack(z, legs), _params(lib, z, legs), want_fk=True)
+    for i, leg in enumerate(legs):
+        assert np.abs(out["angles"][0, i] - z[f"{leg}_angles"]).max() < TOL, leg
+        assert np.abs(out["fk"][0, i] - z[f"{leg}_fk"]).max() < TOL, leg
+
+
+def test_config1_single_leg_100_frames(lib):
+    z = load_golden("anipose_shipped")
+    out = lib.solve_seq(_stack(z, ["RF"], slice(0, 100)), _params(lib, z, ["RF"]))
+    assert np.abs(out["angles"][0, 0] - z["RF_angles"][:100]).max() < TOL
+
+
+def test_batched_sequences_equal_individual_runs(lib):
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    offs = [0, 130, 500, 777, 900]
+    pose = np.concatenate([_stack(z, legs, slice(o, o + 50)) for o in offs])
+    for block in (64, 256):
+        batch = lib.solve_seq(pose, params, want_fk=True, block_size=block)
+        for s in range(len(offs)):
+            one = lib.solve_seq(pose[s:s + 1], params, want_fk=True)
+            assert np.array_equal(batch["angles"][s], one["angles"][0])
+            assert np.array_equal(batch["fk"][s], one["fk"][0])
+
+
+@pytest.mark.parametrize("split", [1, 2, 3])
+def test_stage_subsets_compose(lib, split):
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = _stack(z, legs)
+    full = lib.solve_seq(pose, params, want_fk=True)
+    a = lib.solve_seq(pose, params, 1, split, want_fk=True)
+    assert a["fk"] is None
+    b = lib.solve_seq(pose, params, split + 1, 4, angles=a["angles"], want_fk=True)
+    assert np.array_equal(b["angles"], full["angles"])
+    assert np.array_equal(b["fk"], full["fk"])
+
+
+def test_empty_and_tiny_inputs(lib):
+    z = load_golden("df3d_100")
+    params = _params(lib, z, ["RF"])
+    pose = _stack(z, ["RF"])
+    assert lib.solve_seq(pose[:, :, :0], params)["angles"].shape == (1, 1, 0, 7)
+    assert lib.solve_seq(pose[:0], params)["angles"].shape == (0, 1, 100, 7)
+    one = lib.solve_seq(pose[:, :, :1], params)
+    assert np.array_equal(one["angles"][0, 0, 0], lib.solve_seq(pose, params)["angles"][0, 0, 0])
+
+
+def test_bad_seed_raises_value_error(lib):
+    z = load_golden("df3d_100")
+    seeds = z["RF_seeds"].copy()
+    seeds[2] = 3.0  # stage-1 pitch seed outside +-90 deg
+    with pytest.raises(ValueError, match="outside of provided bounds"):
+        lib.solve_seq(_stack(z, ["RF"]), [lib.leg_params_from_arrays(z["RF_seg"], z["RF_bounds"], seeds)])
+
+
+def test_python_api_matches_reference_layout(lib, tmp_path):
+    """LegInvKinSeq.run_ik_and_fk: dict keys, shapes, dtypes, export files, leg filtering."""
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    z = load_golden("anipose_shipped")
+    aligned = {"R_head": np.zeros((200, 2, 3)), "RF_leg": z["RF_pose"][:200], "LF_leg": z["LF_pose"][:200],
+               "RM_leg": z["RF_pose"][:200], "Neck": np.zeros((1, 1, 3))}
+    ik = LegInvKinSeq(aligned, KinematicChainSeq(BOUNDS, ["RF", "LF"]), INITIAL_ANGLES, log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk(export_path=tmp_path, hide_progress_bar=True)
+    assert list(ang.keys()) == [f"Angle_{leg}_{d}" for leg in ("RF", "LF") for d in DOFS]
+    assert list(fk.keys()) == ["RF_leg", "LF_leg"]  # RM is not in the chain's body_size: skipped
+    for leg in ("RF", "LF"):
+        assert fk[f"{leg}_leg"].shape == (200, 9, 3) and fk[f"{leg}_leg"].dtype == np.float64
+        got = np.stack([ang[f"Angle_{leg}_{d}"] for d in DOFS], 1)
+        assert got.shape == (200, 7)
+        assert np.abs(got - z[f"{leg}_angles"][:200]).max() < TOL
+        assert np.array_equal(fk[f"{leg}_leg"][:, 0], aligned[f"{leg}_leg"][:, 0])
+    with open(tmp_path / "leg_joint_angles.pkl", "rb") as f:
+        saved = pickle.load(f)
+    assert np.array_equal(saved["Angle_LF_TiTa_pitch"], ang["Angle_LF_TiTa_pitch"])
+    assert os.path.exists(tmp_path / "forward_kinematics.pkl")
+    assert ang is ik.joint_angles_dict
+
+
+def test_python_stagewise_api_and_per_frame_seam(lib):
+    """calculate_ik_stage stage by stage == run_ik_and_fk; calculate_ik / calculate_fk on one frame."""
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    z = load_golden("anipose_shipped")
+    pose = z["RF_pose"][:60]
+    kc = KinematicChainSeq(BOUNDS, ["RF"])
+    ik = LegInvKinSeq({"RF_leg": pose}, kc, INITIAL_ANGLES, log_level="ERROR")
+    full_ang, full_fk = ik.run_ik_and_fk()
+    full_ang = {k: v.copy() for k, v in full_ang.items()}
+    ik2 = LegInvKinSeq({"RF_leg": pose}, kc, INITIAL_ANGLES, log_level="ERROR")
+    for stage in (1, 2, 3, 4):
+        fk = ik2.calculate_ik_stage(pose[:, stage], pose[:, 0], INITIAL_ANGLES["RF"][f"stage_{stage}"], "RF",
+                                    stage=stage)
+    for k in full_ang:
+        assert np.array_equal(ik2.joint_angles_dict[k], full_ang[k]), k
+    assert np.array_equal(fk, full_fk["RF_leg"])
+    # two-call form with accumulated dict
+    ik3 = LegInvKinSeq({"RF_leg": pose}, kc, INITIAL_ANGLES, log_level="ERROR")
+    ik3.run_ik_and_fk(stages=[1, 2])
+    assert set(ik3.joint_angles_dict) == {f"Angle_RF_{d}" for d in DOFS[:4]}
+    ang3, fk3 = ik3.run_ik_and_fk(stages=[3, 4])
+    assert all(np.array_equal(ang3[k], full_ang[k]) for k in full_ang)
+    assert np.array_equal(fk3["RF_leg"], full_fk["RF_leg"])
+    # per-frame seam: frame 0, stage 3
+    chain = kc.create_leg_chain("RF", stage=3, angles=full_ang, t=0)
+    x = ik.calculate_ik(chain, pose[0, 3] - pose[0, 0], INITIAL_ANGLES["RF"]["stage_3"])
+    assert x.shape == (8,)
+    assert x[5] == full_ang["Angle_RF_CTr_roll"][0] and x[6] == full_ang["Angle_RF_FTi_pitch"][0]
+    q = np.concatenate([[0.0], [full_ang[f"Angle_RF_{d}"][7] for d in DOFS], [0.0]])
+    chain4 = kc.create_leg_chain("RF", stage=4, angles=full_ang, t=7)
+    assert np.abs(ik.calculate_fk(chain4, q) + pose[7, 0] - full_fk["RF_leg"][7]).max() < 1e-12
+
+
+def test_device_pointer_entry_point_with_torch(lib):
+    import torch
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = np.concatenate([_stack(z, legs)] * 3)
+    host = lib.solve_seq(pose, params, want_fk=True, want_diag=True)
+    d_pose = torch.from_numpy(pose).cuda()
+    d_ang = torch.zeros((3, 6, 100, 7), dtype=torch.float64, device="cuda")
+    d_fk = torch.zeros((3, 6, 100, 9, 3), dtype=torch.float64, device="cuda")
+    d_nfev = torch.zeros((3, 6, 100, 4), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        lib.solve_seq_device(d_pose.data_ptr(), 3, 6, 100, params, d_ang.data_ptr(), d_fk.data_ptr(),
+                             d_nfev=d_nfev.data_ptr(), stream=side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(d_ang.cpu().numpy(), host["angles"])
+    assert np.array_equal(d_fk.cpu().numpy(), host["fk"])
+    assert np.array_equal(d_nfev.cpu().numpy(), host["nfev"])
+
+
+@pytest.mark.parametrize("variant", ["iid", "smooth"])
+def test_full_size_synthetic_properties(lib, oracle, variant):
+    """Config 3 at scale (default 131072 sequences x 6 legs x 8 frames = 6.3 M leg-frames would take
+    seconds; use 16384 x 6 x 64 = 6.3 M): size-independent properties instead of an oracle run.
+      * the returned FK is the forward kinematics of the returned angles (independent numpy FK);
+      * every angle lies inside its bounds;
+      * the claw residual is small for these reachable, lightly perturbed targets;
+      * a random sample of chains equals the oracle bit for bit."""
+    from seqikpy_amd import data, synthetic, utils
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    S, N = 16384, 64
+    pose = synthetic.synthetic_pose(S, N, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                    variant=variant)
+    params = [lib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
+    out = lib.solve_seq(pose, params, want_fk=True)
+    ang, fk = out["angles"], out["fk"]
+    assert np.isfinite(ang).all() and np.isfinite(fk).all()
+    for li, leg in enumerate(legs):
+        lb = np.array([data.BOUNDS_LOCOMOTION[f"{leg}_{d}"][0] for d in DOFS])
+        ub = np.array([data.BOUNDS_LOCOMOTION[f"{leg}_{d}"][1] for d in DOFS])
+        assert (ang[:, li] >= lb).all() and (ang[:, li] <= ub).all()
+        seg = [body[f"{leg}_{s}"] for s in data.SEGMENTS]
+        kp = synthetic.leg_forward_kinematics(ang[:, li], seg) + pose[:, li, :, :1]
+        assert np.abs(kp - fk[:, li][:, :, [0, 4, 6, 7, 8]]).max() < 1e-12
+        assert np.array_equal(fk[:, li, :, 0], pose[:, li, :, 0])
+    # sequential fitting of noisy reachable targets: every stage should land near its key point
+    resid = np.linalg.norm(fk[:, :, :, [4, 6, 7, 8]] - pose[:, :, :, 1:], axis=-1)
+    assert np.median(resid) < 0.05
+    rng = np.random.default_rng(7)
+    for s, li in zip(rng.integers(0, S, 24), rng.integers(0, 6, 24)):
+        leg = legs[li]
+        seg, b, seeds = oracle.leg_params(leg, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+        ref = oracle.seq_leg(pose[s, li], seg, b, seeds)
+        assert np.array_equal(ang[s, li], ref["angles"]) and np.array_equal(fk[s, li], ref["fk"])

@@ -1,0 +1,119 @@
+"""CPU tier: host-side mirror of the reference interface -- chain factories, constants,
+argument checks (mirrors the reference's tests/test_kin_chain.py: link names per stage,
+ValueError on bad leg / stage)."""
+import numpy as np
+import pytest
+
+from conftest import DOFS, load_golden
+
+from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
+from seqikpy_amd.kinematic_chain import KinematicChainGeneric, KinematicChainSeq
+from seqikpy_amd.leg_inverse_kinematics import LegInvKinGeneric, LegInvKinSeq
+from seqikpy_amd.utils import calculate_body_size
+
+
+@pytest.fixture()
+def angles():
+    z = load_golden("anipose_shipped")
+    return {f"Angle_{leg}_{d}": z[f"{leg}_angles"][:, i] for leg in ("RF", "LF") for i, d in enumerate(DOFS)}
+
+
+def test_chain_classes_have_attributes():
+    for cls in (KinematicChainSeq, KinematicChainGeneric):
+        kc = cls(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None)
+        assert hasattr(kc, "body_size") and hasattr(kc, "bounds_dof")
+        assert kc.body_size["RF_Coxa"] == pytest.approx(0.40)
+        assert kc.body_size["RF"] == pytest.approx(2.26)
+
+
+def test_seq_chain_link_names_per_stage(angles):
+    kc = KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None)
+    expect = {
+        1: ["Base link", "RF_ThC_yaw", "RF_ThC_pitch", "RF_CTr_pitch"],
+        2: ["Base link", "RF_ThC_yaw", "RF_ThC_pitch", "RF_ThC_roll", "RF_CTr_pitch", "RF_FTi_pitch"],
+        3: ["Base link", "RF_ThC_yaw", "RF_ThC_pitch", "RF_ThC_roll", "RF_CTr_pitch", "RF_CTr_roll",
+            "RF_FTi_pitch", "RF_TiTa_pitch"],
+        4: ["Base link", "RF_ThC_yaw", "RF_ThC_pitch", "RF_ThC_roll", "RF_CTr_pitch", "RF_CTr_roll",
+            "RF_FTi_pitch", "RF_TiTa_pitch", "RF_Claw"],
+    }
+    for stage, names in expect.items():
+        chain = kc.create_leg_chain(leg_name="RF", stage=stage, angles=angles, t=0)
+        assert [l.name for l in chain.links] == names
+        assert chain.name == f"chain_stage_{stage}"
+    # fixed links carry the earlier angles of frame t
+    chain = kc.create_leg_chain(leg_name="RF", stage=3, angles=angles, t=5)
+    assert chain.links[1].joint_type == "fixed"
+    assert chain.links[1].origin_orientation[0] == angles["Angle_RF_ThC_yaw"][5]
+    assert chain.links[4].origin_translation[2] == -kc.body_size["RF_Coxa"]
+    assert chain.links[5].joint_type == "revolute" and tuple(chain.links[5].rotation) == (0, 0, 1)
+
+
+def test_generic_chain_link_names():
+    kc = KinematicChainGeneric(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None)
+    chain = kc.create_leg_chain(leg_name="LF")
+    assert [l.name for l in chain.links] == ["Base link", "LF_ThC_roll", "LF_ThC_yaw", "LF_ThC_pitch",
+                                             "LF_CTr_pitch", "LF_CTr_roll", "LF_FTi_pitch", "LF_TiTa_pitch", "LF_Claw"]
+
+
+def test_chain_factory_errors(angles):
+    kc = KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None)
+    with pytest.raises(ValueError):
+        kc.create_leg_chain(leg_name="XX", stage=1)
+    with pytest.raises(ValueError):
+        kc.create_leg_chain(leg_name="RF", stage=5, angles=angles, t=0)
+    with pytest.raises(ValueError):
+        KinematicChainGeneric(BOUNDS, ["RF"]).create_leg_chain(leg_name="R1")
+    with pytest.raises(NameError):
+        calculate_body_size(NMF_TEMPLATE, ["RF", "ZZ"])
+
+
+def test_run_ik_and_fk_validates_stages_before_any_launch():
+    pose = {"RF_leg": np.zeros((3, 5, 3))}
+    ik = LegInvKinSeq(pose, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES, log_level="ERROR")
+    for stages in ([1, 3], [1, 2, 3, 4, 5], [2, 1]):
+        with pytest.raises(ValueError, match="Maximum stage number is 4"):
+            ik.run_ik_and_fk(stages=stages)
+    with pytest.raises(ValueError, match="not valid"):
+        ik.calculate_ik_stage(np.zeros((3, 3)), np.zeros(3), INITIAL_ANGLES["RF"]["stage_1"], "XX", stage=1)
+    with pytest.raises(ValueError, match="between 1 and 4"):
+        ik.calculate_ik_stage(np.zeros((3, 3)), np.zeros(3), INITIAL_ANGLES["RF"]["stage_1"], "RF", stage=7)
+    assert ik.initial_angles is INITIAL_ANGLES and ik.joint_angles_dict == {}
+
+
+def test_later_stage_without_earlier_angles_raises_keyerror():
+    pose = {"RF_leg": np.zeros((3, 5, 3))}
+    ik = LegInvKinSeq(pose, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES, log_level="ERROR")
+    with pytest.raises(KeyError):
+        ik.run_ik_and_fk(stages=[2, 3])
+
+
+def test_calculate_fk_matches_oracle(oracle, angles):
+    kc = KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None)
+    ik = LegInvKinSeq({}, kc, INITIAL_ANGLES, log_level="ERROR")
+    seg, b, _ = oracle.leg_params("RF", BOUNDS, kc.body_size, INITIAL_ANGLES)
+    z = load_golden("anipose_shipped")
+    t = 17
+    chain = kc.create_leg_chain(leg_name="RF", stage=4, angles=angles, t=t)
+    q = np.concatenate([[0.0], z["RF_angles"][t], [0.0]])
+    got = ik.calculate_fk(chain, q)
+    want = oracle.stage_fk(4, seg, b, z["RF_angles"][t], q)
+    assert np.abs(got - want).max() < 1e-14
+    assert ik.get_scale_factor(np.array([[0, 0, 0], [0, 0, 1.0], [0, 0, 3.0]]), 6.0) == pytest.approx(2.0)
+
+
+def test_generic_ik_is_declared_but_not_implemented():
+    ik = LegInvKinGeneric({}, KinematicChainGeneric(BOUNDS, ["RF"]), INITIAL_ANGLES, log_level="ERROR")
+    with pytest.raises(NotImplementedError):
+        ik.run_ik_and_fk()
+
+
+def test_synthetic_fk_matches_oracle(oracle):
+    from seqikpy_amd import data, synthetic
+    body = calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, data.LEGS)
+    pose, theta = synthetic.synthetic_pose(1, 5, ["RM"], data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                           noise=0.0, return_theta=True)
+    seg, b, _ = oracle.leg_params("RM", data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+    for t in range(5):
+        q = np.concatenate([[0.0], theta[0, 0, t], [0.0]])
+        pos = oracle.stage_fk(4, seg, b, theta[0, 0, t], q) + data.TEMPLATE_NMF_LOCOMOTION["RM_Coxa"]
+        assert np.abs(pos[[0, 4, 6, 7, 8]] - pose[0, 0, t]).max() < 1e-12

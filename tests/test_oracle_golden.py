@@ -1,0 +1,77 @@
+"""CPU tier: the C oracle against (1) the shipped outputs of the reference pipeline and (2) the
+reference's own source re-run in the build container over real scipy (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+
+from conftest import good_frames, leg_arrays, load_golden
+
+TOL = 1e-4  # rad -- BASELINE.json north star
+
+
+def test_sincos_is_accurate(oracle):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-3.3, 3.3, 20000), [0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, 1e-300]])
+    sc = np.array([oracle.sincos(x) for x in xs])
+    assert np.all(np.abs(sc[:, 0] - np.sin(xs)) <= np.spacing(np.abs(np.sin(xs))) + 1e-300)
+    assert np.all(np.abs(sc[:, 1] - np.cos(xs)) <= np.spacing(np.abs(np.cos(xs))) + 1e-300)
+    assert oracle.sincos(0.0) == (0.0, 1.0)
+
+
+@pytest.mark.parametrize("leg", ["RF", "LF"])
+def test_oracle_vs_shipped_anipose_golden(oracle, leg):
+    """leg_joint_angles.pkl / forward_kinematics.pkl shipped with the reference (6000 frames)."""
+    z = load_golden("anipose_shipped")
+    r = oracle.seq_leg(*leg_arrays(z, leg))
+    ok = good_frames(leg, 6000)
+    err = np.abs(r["angles"] - z[f"{leg}_angles"])
+    assert err[ok].max() < TOL
+    # outside the documented degenerate episode nothing may exceed the bar; inside, only there
+    bad = np.where(err.max(1) >= TOL)[0]
+    assert np.all(~ok[bad])
+    cut = z["fk_frames"]
+    fk_err = np.abs(r["fk"][cut] - z[f"{leg}_fk_cut"])
+    assert fk_err[ok[cut]].max() < TOL
+
+
+@pytest.mark.parametrize("name", ["anipose_scipy_cut", "df3d_100", "df3d_1000"])
+def test_oracle_vs_reference_source_run(oracle, name):
+    """Outputs of the reference's LegInvKinSeq/KinematicChainSeq source, run over real scipy."""
+    z = load_golden(name)
+    for leg in z["legs"]:
+        leg = str(leg)
+        r = oracle.seq_leg(*leg_arrays(z, leg))
+        n = r["angles"].shape[0]
+        ok = good_frames(leg, n) if name.startswith("anipose") else np.ones(n, bool)
+        assert np.abs(r["angles"] - z[f"{leg}_angles"])[ok].max() < TOL, leg
+        assert np.abs(r["fk"] - z[f"{leg}_fk"])[ok].max() < TOL, leg
+        # stage 1 (exact-zero singular values) and stage 4 (one unknown) follow scipy's iteration
+        # path itself, not just its answer: same number of function evaluations
+        same = (r["nfev"] == z[f"{leg}_nfev"])[ok].mean(0)
+        assert same[0] > 0.97 and same[3] > 0.97, (leg, same)
+        assert set(np.unique(r["status"])) <= {1, 2, 3, 4}
+
+
+def test_oracle_stage_subsets_compose(oracle):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RM")
+    full = oracle.seq_leg(pose, seg, b, seeds)
+    a = oracle.seq_leg(pose, seg, b, seeds, 1, 2, want_fk=False)
+    c = oracle.seq_leg(pose, seg, b, seeds, 3, 4, prior_angles=a["angles"])
+    assert np.array_equal(c["angles"], full["angles"])
+    assert np.array_equal(c["fk"], full["fk"])
+
+
+def test_oracle_rejects_seed_outside_bounds(oracle):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RF")
+    bad = seeds.copy()
+    bad[1] = b[0, 1] + 0.1  # stage-1 yaw seed above its upper bound
+    with pytest.raises(ValueError, match="outside of provided bounds"):
+        oracle.seq_leg(pose[:2], seg, b, bad)
+
+
+def test_oracle_empty_input(oracle):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RF")
+    r = oracle.seq_leg(pose[:0], seg, b, seeds)
+    assert r["angles"].shape == (0, 7)
