@@ -35,9 +35,9 @@ from seqikpy_amd import _lib, data, sharding, synthetic, utils  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # Algorithmic HBM bytes per leg-frame (DESIGN.md "Kernels"):
 BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
-BYTES_STAGE = {1: 48 + 16, 2: 48 + 16 + 16 + 48, 3: 48 + 32 + 16 + 24, 4: 48 + 48 + 8 + 144}
-# stage k reads the origin + its key point (48 B) and the angles of earlier stages, writes its
-# angles and its FK rows (stage 2: rows 4, 5; stage 3: row 6; stage 4: rows 0-3, 7, 8)
+BYTES_STAGE = {1: 48 + 16, 2: 48 + 16 + 16, 3: 48 + 32 + 16, 4: 48 + 48 + 8 + 216}
+# stage k reads the origin + its key point (48 B) and the angles of the earlier stages, writes its own
+# angles; stage 4 also writes the 9 x 3 FK record (216 B)
 
 
 def parse():
@@ -112,8 +112,10 @@ def main():
     L = len(legs)
     units_per_step = S * L * T  # leg-frames per GPU per step
 
-    d_pose = torch.from_numpy(pose).cuda()
-    d_ang = [torch.zeros((S, L, T, 7), dtype=torch.float64, device="cuda") for _ in range(2)]
+    # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
+    layout = _lib.planar_layout(T)
+    d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+    d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(2)]
     d_fk = torch.zeros((S, L, T, 9, 3), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
     gather = sharding.GatherPipeline(dist, world, rank, d_ang[0]) if world > 1 else None
@@ -129,7 +131,7 @@ def main():
                 events[stage - 1].record(stream)
             _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(), d_fk.data_ptr(),
                                   first_stage=stage, last_stage=stage, stream=stream.cuda_stream,
-                                  block_size=args.block)
+                                  block_size=args.block, layout=layout)
         if events:
             events[4].record(stream)
         if gather:
@@ -190,7 +192,7 @@ def main():
             "config": {"workload": "config 3: synthetic 1M frames x 6 legs per GPU, in-workspace targets",
                        "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
-                       "outputs": "7 angles + 9x3 FK per leg-frame",
+                       "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU"},
             "roofline": roofline,
         }

@@ -75,6 +75,19 @@ typedef struct SeqikOptions {
     int32_t reserved[6];
 } SeqikOptions;
 
+/* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.
+ *   key point (c, row, t):  pose   + c * pose_chain + row * pose_row + t * pose_frame   (x, y, z contiguous)
+ *   angle     (c, dof, t):  angles + c * ang_chain  + dof * ang_dof  + t * ang_frame
+ * NULL layout = the dense arrays of seqik_solve_seq: pose [chain][frame][5][3], angles [chain][frame][7].
+ * The HBM-friendly "planar" layout (what bench.py uses) stores every key-point row and
+ * every joint as its own time series -- pose [chain][5][frame][3], angles [chain][7][frame] -- so each
+ * stage kernel touches exactly the rows it needs; the per-joint series are also the reference's own
+ * output format (joint_angles_dict["Angle_<leg>_<dof>"] is an (N,) array). */
+typedef struct SeqikLayout {
+    int64_t pose_chain, pose_row, pose_frame;
+    int64_t ang_chain, ang_dof, ang_frame;
+} SeqikLayout;
+
 int seqik_abi_version(void);
 int seqik_device_count(void);
 const char *seqik_last_error(void);
@@ -109,12 +122,14 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
 /*
  * Same computation on DEVICE buffers of the current HIP device, enqueued on `hip_stream`
  * (a hipStream_t passed as void*, NULL = default stream) and NOT synchronised; `legs` is a
- * host pointer (copied before return).  This is the entry point the benchmark times.
+ * host pointer (copied before return); `layout` describes d_pose / d_angles (NULL = dense, as
+ * above); d_fk is always [chain][frame][9][3], d_status / d_nfev [chain][frame][4].
+ * This is the entry point the benchmark times.
  */
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
-                           const SeqikOptions *opt, void *hip_stream);
+                           const SeqikLayout *layout, const SeqikOptions *opt, void *hip_stream);
 
 #ifdef __cplusplus
 }

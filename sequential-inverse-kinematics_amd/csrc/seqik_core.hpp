@@ -687,8 +687,10 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
 // Stage driver
 // ---------------------------------------------------------------------------
 struct ChainIO {
-    const double *pose;     // this chain's key points: frame t at pose + t * 15, [5][3] contiguous
-    double *angles;         // [n_frames][7], DOF order yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa
+    const double *pose;     // key point (row, t) of this chain at pose + row * pose_row + t * pose_frame (x, y, z)
+    int64_t pose_row, pose_frame;
+    double *angles;         // angle (dof, t) at angles + dof * ang_dof + t * ang_frame
+    int64_t ang_dof, ang_frame;  // DOF order yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa
     double *fk;             // nullable [n_frames][9][3]
     int32_t *status;        // nullable [n_frames][4]
     int32_t *nfev;          // nullable [n_frames][4]
@@ -698,7 +700,7 @@ struct ChainIO {
 // Prefix frame of STAGE from the angles of the earlier stages: the "fixed" links of
 // kinematic_chain.py:215-241, 276-316, 353-401, multiplied in link order.
 template <int STAGE>
-SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang)
+SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, int64_t ang_dof, double *coxa_end)
 {
     frame_identity(pre);
     if constexpr (STAGE >= 2) {
@@ -706,31 +708,33 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang)
         Frame tmp;
         sincos_cw(ang[0], sn, cs);
         frame_mul_link<AXIS_X>(tmp, pre, sn, cs, lc.st[0].tz_a);
-        sincos_cw(ang[1], sn, cs);
+        sincos_cw(ang[ang_dof], sn, cs);
         frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[0].tz_b);
     }
     if constexpr (STAGE >= 3) {
         double sn, cs;
         Frame tmp;
-        sincos_cw(ang[2], sn, cs);
+        sincos_cw(ang[2 * ang_dof], sn, cs);
         frame_mul_link<AXIS_Z>(tmp, pre, sn, cs, lc.st[1].tz_a);
-        sincos_cw(ang[3], sn, cs);
+        sincos_cw(ang[3 * ang_dof], sn, cs);
         frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[1].tz_b);
+        if (coxa_end) { coxa_end[0] = pre.t[0]; coxa_end[1] = pre.t[1]; coxa_end[2] = pre.t[2]; }
     }
     if constexpr (STAGE >= 4) {
         double sn, cs;
         Frame tmp;
-        sincos_cw(ang[4], sn, cs);
+        sincos_cw(ang[4 * ang_dof], sn, cs);
         frame_mul_link<AXIS_Z>(tmp, pre, sn, cs, lc.st[2].tz_a);
-        sincos_cw(ang[5], sn, cs);
+        sincos_cw(ang[5 * ang_dof], sn, cs);
         frame_mul_link<AXIS_Y>(pre, tmp, sn, cs, lc.st[2].tz_b);
     }
 }
 
 // Runs stage STAGE over all frames of one chain.
-//   WANT_FK   : also write this stage's rows of the stage-4 forward kinematics
-//               (leg_inverse_kinematics.py:279-282): stage 2 -> rows 4, 5 (coxa end),
-//               stage 3 -> row 6 (femur end), stage 4 -> rows 0-3 (origin), 7, 8.
+//   WANT_FK   : (stage 4 only) also write the stage-4 forward kinematics + origin
+//               (leg_inverse_kinematics.py:279-282), all 9 link positions of a frame as one
+//               contiguous 216-byte record: rows 0-3 origin, 4-5 coxa end, 6 femur end (both
+//               fall out of the prefix product), 7 tibia end, 8 claw.
 //   WANT_DIAG : also produce scipy's status / nfev (one extra Jacobian per solve: scipy
 //               re-evaluates it after the last accepted step and may overwrite the status
 //               with 1 = gtol).
@@ -757,15 +761,18 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     double sa = 0.0, ca = 1.0, sb = 0.0, cb = 1.0;  // sin/cos of the active joints at x
     int nfev = 0, status = STATUS_NONE;
     bool first_pass = true, new_solve = true;
+    double coxa_end[3] = {0.0, 0.0, 0.0};  // stage 4 + FK only
     int64_t t = 0;
 
     while (t < io.n_frames) {
         if (new_solve) {
-            const double *kp = io.pose + t * 15;
-            if constexpr (STAGE > 1) build_prefix<STAGE>(P.pre, lc, io.angles + t * 7);
-            P.target[0] = kp[3 * STAGE + 0] - kp[0];
-            P.target[1] = kp[3 * STAGE + 1] - kp[1];
-            P.target[2] = kp[3 * STAGE + 2] - kp[2];
+            const double *org = io.pose + t * io.pose_frame;
+            const double *kp = org + STAGE * io.pose_row;
+            if constexpr (STAGE > 1)
+                build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, (WANT_FK && STAGE == 4) ? coxa_end : nullptr);
+            P.target[0] = kp[0] - org[0];
+            P.target[1] = kp[1] - org[1];
+            P.target[2] = kp[2] - org[2];
             x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
             if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
             eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
@@ -888,55 +895,30 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 
         if (finished) {
             // ---- solve done: store, advance to the next frame -------------------------------
-            double *ang = io.angles + t * 7;
-            ang[DOF0] = x[0];
-            if constexpr (NA == 2) ang[DOF0 + 1] = x[1];
+            double *ang = io.angles + t * io.ang_frame;
+            ang[DOF0 * io.ang_dof] = x[0];
+            if constexpr (NA == 2) ang[(DOF0 + 1) * io.ang_dof] = x[1];
             if constexpr (WANT_DIAG) {
                 if (io.status) io.status[t * 4 + STAGE - 1] = (status == STATUS_NONE) ? 0 : status;
                 if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
             }
-            if constexpr (WANT_FK && STAGE >= 2) {
-                const double *origin = io.pose + t * 15;
+            if constexpr (WANT_FK && STAGE == 4) {
+                const double *origin = io.pose + t * io.pose_frame;
                 double *fk = io.fk + t * 27;
-                Frame after;  // frame after the active links at the solution
+                Frame after;  // frame after the TiTa link at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
-                if constexpr (STAGE == 2) {
-                    for (int a = 0; a < 3; ++a) { fk[12 + a] = after.t[a] + origin[a]; fk[15 + a] = after.t[a] + origin[a]; }
-                } else if constexpr (STAGE == 3) {
-                    for (int a = 0; a < 3; ++a) fk[18 + a] = after.t[a] + origin[a];
-                } else {
-                    for (int i = 0; i < 4; ++i)
-                        for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
-                    for (int a = 0; a < 3; ++a) {
-                        fk[21 + a] = after.t[a] + origin[a];
-                        fk[24 + a] = (after.r[3 * a + 2] * P.tz_last + after.t[a]) + origin[a];
-                    }
+                for (int i = 0; i < 4; ++i)
+                    for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
+                for (int a = 0; a < 3; ++a) {
+                    fk[12 + a] = coxa_end[a] + origin[a];
+                    fk[15 + a] = coxa_end[a] + origin[a];
+                    fk[18 + a] = P.pre.t[a] + origin[a];
+                    fk[21 + a] = after.t[a] + origin[a];
+                    fk[24 + a] = (after.r[3 * a + 2] * P.tz_last + after.t[a]) + origin[a];
                 }
             }
             t += 1;
             new_solve = true;
-        }
-    }
-}
-
-// Stage-4 FK rows that earlier stages would have written, for runs that start at a later
-// stage (first_stage > 2): rows 4, 5 from the stage-3 prefix, row 6 from the stage-4 prefix.
-template <int FIRST_STAGE>
-SEQIK_HD void fill_fk_prefix_rows(const LegConst &lc, const ChainIO &io)
-{
-    for (int64_t t = 0; t < io.n_frames; ++t) {
-        const double *kp = io.pose + t * 15;
-        const double *ang = io.angles + t * 7;
-        double *fk = io.fk + t * 27;
-        if constexpr (FIRST_STAGE >= 3) {
-            Frame pre;
-            build_prefix<3>(pre, lc, ang);
-            for (int a = 0; a < 3; ++a) { fk[12 + a] = pre.t[a] + kp[a]; fk[15 + a] = pre.t[a] + kp[a]; }
-        }
-        if constexpr (FIRST_STAGE >= 4) {
-            Frame pre;
-            build_prefix<4>(pre, lc, ang);
-            for (int a = 0; a < 3; ++a) fk[18 + a] = pre.t[a] + kp[a];
         }
     }
 }

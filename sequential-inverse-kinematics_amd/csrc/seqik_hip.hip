@@ -42,7 +42,9 @@ struct KernelArgs {
     int64_t n_chains;             // n_seq * n_legs
     int64_t n_frames;
     int32_t n_legs;
-    int32_t fill_fk_from;  // > 0: this launch first writes the FK rows owed by stages that are not run
+    // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
+    int64_t pose_chain, pose_row, pose_frame;
+    int64_t ang_chain, ang_dof, ang_frame;
 };
 
 // One lane per chain, one launch per stage (the reference's own loop order,
@@ -67,25 +69,27 @@ seqik_stage_kernel(KernelArgs a)
     const int leg = (int)(c % a.n_legs);
 
     seqik::ChainIO io;
-    io.pose = a.pose + c * a.n_frames * 15;
-    io.angles = a.angles + c * a.n_frames * 7;
+    io.pose = a.pose + c * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
     io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
     io.status = a.status ? a.status + c * a.n_frames * 4 : nullptr;
     io.nfev = a.nfev ? a.nfev + c * a.n_frames * 4 : nullptr;
     io.n_frames = a.n_frames;
-    if (a.fill_fk_from > 0) {
-        if (a.fill_fk_from == 3) seqik::fill_fk_prefix_rows<3>(s_legs[leg], io);
-        else seqik::fill_fk_prefix_rows<4>(s_legs[leg], io);
-    }
     seqik::run_stage<STAGE, WANT_FK, WANT_DIAG>(s_legs[leg], io);
 }
 
 template <int STAGE>
 void launch_stage(const KernelArgs &a, bool fk, bool diag, dim3 grid, dim3 block, hipStream_t stream)
 {
-    if (fk && diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, true>), grid, block, 0, stream, a);
-    else if (fk) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, false>), grid, block, 0, stream, a);
-    else if (diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, true>), grid, block, 0, stream, a);
+    if constexpr (STAGE == 4) {
+        if (fk && diag) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, true>), grid, block, 0, stream, a); return; }
+        if (fk) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, false>), grid, block, 0, stream, a); return; }
+    }
+    if (diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, false>), grid, block, 0, stream, a);
 }
 
@@ -135,15 +139,25 @@ int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegPa
 
 int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
            const seqik::LegConst *d_legs, int32_t first_stage, int32_t last_stage, double *d_angles,
-           double *d_fk, int32_t *d_status, int32_t *d_nfev, const SeqikOptions *opt, hipStream_t stream)
+           double *d_fk, int32_t *d_status, int32_t *d_nfev, const SeqikLayout *layout, const SeqikOptions *opt,
+           hipStream_t stream)
 {
     KernelArgs a;
+    if (layout) {
+        if (layout->pose_chain < 0 || layout->pose_row <= 0 || layout->pose_frame <= 0 || layout->ang_chain < 0 ||
+            layout->ang_dof <= 0 || layout->ang_frame <= 0)
+            return fail(SEQIK_ERR_BAD_ARG, "layout strides must be positive%s");
+        a.pose_chain = layout->pose_chain; a.pose_row = layout->pose_row; a.pose_frame = layout->pose_frame;
+        a.ang_chain = layout->ang_chain; a.ang_dof = layout->ang_dof; a.ang_frame = layout->ang_frame;
+    } else {
+        a.pose_chain = n_frames * 15; a.pose_row = 3; a.pose_frame = 15;
+        a.ang_chain = n_frames * 7; a.ang_dof = 1; a.ang_frame = 7;
+    }
     a.pose = d_pose; a.angles = d_angles; a.fk = d_fk; a.status = d_status; a.nfev = d_nfev;
     a.legs = d_legs;
     a.n_chains = n_seq * (int64_t)n_legs;
     a.n_frames = n_frames;
     a.n_legs = n_legs;
-    a.fill_fk_from = 0;
     if (a.n_chains == 0 || n_frames == 0) return SEQIK_OK;
     int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
@@ -154,12 +168,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
     if (!fk) a.fk = nullptr;
     for (int stage = first_stage; stage <= last_stage; ++stage) {
-        // a run that starts after stage 2 still owes the FK rows of the links solved earlier
-        a.fill_fk_from = (fk && stage == first_stage && first_stage >= 3) ? first_stage : 0;
         switch (stage) {
         case 1: launch_stage<1>(a, false, diag, grid, blk, stream); break;
-        case 2: launch_stage<2>(a, fk, diag, grid, blk, stream); break;
-        case 3: launch_stage<3>(a, fk, diag, grid, blk, stream); break;
+        case 2: launch_stage<2>(a, false, diag, grid, blk, stream); break;
+        case 3: launch_stage<3>(a, false, diag, grid, blk, stream); break;
         default: launch_stage<4>(a, fk, diag, grid, blk, stream); break;
         }
         HIP_TRY(hipGetLastError());
@@ -201,7 +213,7 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
-                           const SeqikOptions *opt, void *hip_stream)
+                           const SeqikLayout *layout, const SeqikOptions *opt, void *hip_stream)
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
     if (rc != SEQIK_OK) return rc;
@@ -210,7 +222,7 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     rc = device_leg_table(legs, n_legs, &d_legs);
     if (rc != SEQIK_OK) return rc;
     return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
-                  d_status, d_nfev, opt, stream);
+                  d_status, d_nfev, layout, opt, stream);
 }
 
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
@@ -245,7 +257,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
         if (d_status) TRY_BREAK(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
         if (d_nfev) TRY_BREAK(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
         out = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
-                                     d_fk, d_status, d_nfev, opt, stream);
+                                     d_fk, d_status, d_nfev, nullptr, opt, stream);
         if (out != SEQIK_OK) break;
         TRY_BREAK(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
         if (want_fk) TRY_BREAK(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));

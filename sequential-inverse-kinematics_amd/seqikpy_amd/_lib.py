@@ -37,6 +37,17 @@ class SeqikOptions(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
 
 
+class SeqikLayout(ctypes.Structure):
+    """Mirror of ``struct SeqikLayout``: element strides of the device buffers."""
+    _fields_ = [("pose_chain", ctypes.c_int64), ("pose_row", ctypes.c_int64), ("pose_frame", ctypes.c_int64),
+                ("ang_chain", ctypes.c_int64), ("ang_dof", ctypes.c_int64), ("ang_frame", ctypes.c_int64)]
+
+
+def planar_layout(n_frames: int) -> SeqikLayout:
+    """pose [chain][5][frame][3], angles [chain][7][frame]: every key-point row / joint a time series."""
+    return SeqikLayout(15 * n_frames, 3 * n_frames, 3, 7 * n_frames, n_frames, 1)
+
+
 class SeqikLibraryError(RuntimeError):
     pass
 
@@ -101,7 +112,8 @@ def load():
         L.seqik_solve_seq_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+                                             ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikOptions),
+                                             ctypes.c_void_p]
         _lib = L
         return _lib
 
@@ -196,14 +208,16 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
-                     first_stage=1, last_stage=4, stream=0, block_size=0):
-    """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``."""
+                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None):
+    """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
+    ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout."""
     arr = (SeqikLegParams * n_legs)(*legs)
     opt = SeqikOptions()
     opt.block_size = block_size
     rc = load().seqik_solve_seq_device(ctypes.c_void_p(d_pose), n_seq, n_legs, n_frames, arr, first_stage,
                                        last_stage, ctypes.c_void_p(d_angles), ctypes.c_void_p(d_fk or None),
                                        ctypes.c_void_p(d_status or None), ctypes.c_void_p(d_nfev or None),
+                                       ctypes.byref(layout) if layout is not None else None,
                                        ctypes.byref(opt), ctypes.c_void_p(stream or None))
     if rc != SEQIK_OK:
         _raise(rc)

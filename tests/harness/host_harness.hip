@@ -16,23 +16,21 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
     seqik::LegConst lc;
     seqik::make_leg_consts(*leg, lc);
     seqik::ChainIO io;
-    io.pose = pose;
-    io.angles = angles;
+    io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
+    io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
     io.fk = (fk && last_stage == 4) ? fk : nullptr;
     io.status = status; io.nfev = nfev;
     io.n_frames = n_frames;
     const bool want_fk = io.fk != nullptr;
     const bool diag = status || nfev;
-    if (want_fk && first_stage == 3) seqik::fill_fk_prefix_rows<3>(lc, io);
-    if (want_fk && first_stage == 4) seqik::fill_fk_prefix_rows<4>(lc, io);
     // same launch sequence as seqik_hip.hip::launch(): one pass over all frames per stage
     for (int stage = first_stage; stage <= last_stage; ++stage) {
 #define RUN(S, FK)                                                        \
     if (diag) seqik::run_stage<S, FK, true>(lc, io);                      \
     else seqik::run_stage<S, FK, false>(lc, io);
         if (stage == 1) { RUN(1, false) }
-        else if (stage == 2) { if (want_fk) { RUN(2, true) } else { RUN(2, false) } }
-        else if (stage == 3) { if (want_fk) { RUN(3, true) } else { RUN(3, false) } }
+        else if (stage == 2) { RUN(2, false) }
+        else if (stage == 3) { RUN(3, false) }
         else { if (want_fk) { RUN(4, true) } else { RUN(4, false) } }
 #undef RUN
     }

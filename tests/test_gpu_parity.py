@@ -201,6 +201,28 @@ def test_device_pointer_entry_point_with_torch(lib):
     assert np.array_equal(d_nfev.cpu().numpy(), host["nfev"])
 
 
+def test_planar_device_layout_equals_dense(lib):
+    """SeqikLayout: pose [chain][5][frame][3] + angles [chain][7][frame] give the same bits as the dense
+    layout, including a later-stage run that reads earlier angles through the strides."""
+    import torch
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = np.concatenate([_stack(z, legs, slice(0, 64)), _stack(z, legs, slice(30, 94))])
+    host = lib.solve_seq(pose, params, want_fk=True)
+    S, L, T = pose.shape[:3]
+    d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+    d_ang = torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda")
+    d_fk = torch.zeros((S, L, T, 9, 3), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for first, last in ((1, 2), (3, 4)):
+        lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, d_ang.data_ptr(), d_fk.data_ptr(),
+                             first_stage=first, last_stage=last, stream=stream, layout=lib.planar_layout(T))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ang.cpu().numpy().transpose(0, 1, 3, 2), host["angles"])
+    assert np.array_equal(d_fk.cpu().numpy(), host["fk"])
+
+
 @pytest.mark.parametrize("variant", ["iid", "smooth"])
 def test_full_size_synthetic_properties(lib, oracle, variant):
     """Config 3 at scale (default 131072 sequences x 6 legs x 8 frames = 6.3 M leg-frames would take
