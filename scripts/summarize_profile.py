@@ -1,0 +1,41 @@
+"""Turns the rocprofv3 CSVs of one bench run (gpurun_out/<tag>_{stats,fetch,write,sq}) into the small
+summaries committed under profiles/ (+ profiles/traffic_rNN.json that bench.py reads)."""
+import glob, json, os, sys
+import pandas as pd
+
+tag, rnd = sys.argv[1], sys.argv[2]           # e.g. r01b r01
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = pd.read_csv(glob.glob(f"{src}/{tag}_stats/*/*_kernel_stats.csv")[0])
+stats.to_csv(f"{dst}/{rnd}_bench_kernel_stats.csv", index=False)
+bench_line = [l for l in open(f"{src}/{tag}_stats.log") if l.startswith('{"metric"')][0]
+open(f"{dst}/{rnd}_bench_under_rocprof.json", "w").write(bench_line)
+
+def pmc(kind):
+    d = pd.read_csv(glob.glob(f"{src}/{tag}_{kind}/*/*_counter_collection.csv")[0])
+    d = d[d.Kernel_Name.str.contains("seqik_stage_kernel")].copy()
+    d["stage"] = d.Kernel_Name.str.extract(r"kernel<(\d), ").astype(int)
+    return d.pivot_table(index="stage", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+
+fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
+pm = pd.concat([fetch, write, sq], axis=1)
+pm.to_csv(f"{dst}/{rnd}_bench_pmc_per_launch.csv")
+b = json.loads(bench_line)
+units = b["config"]["sequences_per_gpu"] * b["config"]["legs"] * b["config"]["frames_per_sequence"]
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`",
+       "units_per_launch": units, "variant": b["config"]["variant"],
+       "note": "FETCH_SIZE / WRITE_SIZE are in KiB; bytes = value * 1024, mean over the launches of the run. "
+               "FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 and under-reports wide (16 B/lane) streaming reads by 2x "
+               "(MI355X_MICROARCH.md); these kernels issue 8-byte per-lane loads, for which the counter is uncalibrated, "
+               "so the raw value is reported."}
+for st in (1, 2, 3, 4):
+    f, w = float(fetch.loc[st, "FETCH_SIZE"]) * 1024, float(write.loc[st, "WRITE_SIZE"]) * 1024
+    out[f"stage{st}_fetch_bytes_per_launch"] = f
+    out[f"stage{st}_write_bytes_per_launch"] = w
+    out[f"stage{st}_hbm_bytes_per_launch"] = f + w
+json.dump(out, open(f"{dst}/traffic_{rnd}.json", "w"), indent=1)
+print(pm.round(0).to_string())
+print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("per_launch") and k != "units_per_launch"}, indent=0))
