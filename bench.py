@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--frames-per-seq", type=int, default=64)
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-seqs", type=int, default=1024)
     return ap.parse_args()
@@ -115,27 +117,33 @@ def main():
     # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
     layout = _lib.planar_layout(T)
     d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
-    d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(2)]
     d_fk = torch.zeros((S, L, T, 9, 3), dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream()
-    gather = sharding.GatherPipeline(dist, world, rank, d_ang[0]) if world > 1 else None
+    main_stream = torch.cuda.current_stream()
+    streams = [main_stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
+    n_buf = max(2, len(streams))
+    d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(n_buf)]
+    d_fks = [d_fk] + [torch.zeros_like(d_fk) for _ in range(len(streams) - 1)]
+    gather = sharding.GatherPipeline(dist, world, rank, d_ang[0], n_buffers=n_buf) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
 
     def step(i, events=None):
-        buf = d_ang[i % 2]
-        if gather:
-            gather.wait_buffer(i % 2)  # the gather that last read this buffer has completed
-        for stage in (1, 2, 3, 4):
+        b = i % n_buf
+        buf = d_ang[b]
+        stream = streams[i % len(streams)]
+        with torch.cuda.stream(stream):
+            if gather:
+                gather.wait_buffer(b)  # the gather that last read this buffer has completed
+            for stage in (1, 2, 3, 4):
+                if events:
+                    events[stage - 1].record(stream)
+                _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
+                                      d_fks[i % len(streams)].data_ptr(), first_stage=stage, last_stage=stage,
+                                      stream=stream.cuda_stream, block_size=args.block, layout=layout)
             if events:
-                events[stage - 1].record(stream)
-            _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(), d_fk.data_ptr(),
-                                  first_stage=stage, last_stage=stage, stream=stream.cuda_stream,
-                                  block_size=args.block, layout=layout)
-        if events:
-            events[4].record(stream)
-        if gather:
-            gather.submit(i % 2, buf)
+                events[4].record(stream)
+            if gather:
+                gather.submit(b, buf)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -193,6 +201,7 @@ def main():
                        "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
                        "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
+                       "streams": len(streams),
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU"},
             "roofline": roofline,
         }

@@ -40,14 +40,21 @@
  *
  * Floating-point conventions (shared with the HIP kernel so that the two can
  * be compared BIT FOR BIT): every operation is a single IEEE-754 binary64
- * + - * / sqrt (compile with -ffp-contract=off), sums run in index order,
- * sin/cos come from oracle_sincos() below (Cody-Waite reduction + the
- * classic fdlibm kernel polynomials), never from libm.
+ * + - * / sqrt or an explicit fused multiply-add FMA(a, b, c) = round(a*b + c)
+ * (compile with -ffp-contract=off so that nothing else is fused), sums run in
+ * index order as acc = FMA(a_i, b_i, acc), several quotients by one denominator
+ * are formed as products with its reciprocal, sin/cos come from oracle_sincos()
+ * below (Cody-Waite reduction + the classic fdlibm kernel polynomials), never
+ * from libm.  numpy / BLAS / LAPACK make the same kind of choices (FMA, SIMD
+ * summation order) inside the reference, unspecified; the differences are at the
+ * 1-ulp level.
  */
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+
+#define FMA(a, b, c) fma((a), (b), (c))
 
 #define MAXN 9
 #define NRES 3
@@ -71,7 +78,6 @@
 /* ------------------------------------------------------------------ */
 static const double INVPIO2 = 6.36619772367581382433e-01;
 static const double PIO2_1 = 1.57079632673412561417e+00;  /* first 33 bits of pi/2 */
-static const double PIO2_1T = 6.07710050650619224932e-11; /* pi/2 - PIO2_1 */
 static const double PIO2_2 = 6.07710050630396597660e-11;  /* second 33 bits */
 static const double PIO2_2T = 2.02226624879595063154e-21; /* pi/2 - (PIO2_1 + PIO2_2) */
 
@@ -85,28 +91,29 @@ static const double C1 = 4.16666666666666019037e-02, C2 = -1.3888888888874109574
 void oracle_sincos(double x, double *sn, double *cs)
 {
     double fn = rint(x * INVPIO2);
-    /* first reduction step */
-    double r = x - fn * PIO2_1;
-    double w = fn * PIO2_1T;
-    /* second step, always taken (branch-free; exact when fn == 0) */
-    double t = r;
-    w = fn * PIO2_2;
-    r = t - w;
-    w = fn * PIO2_2T - ((t - r) - w);
+    /* two-step Cody-Waite reduction (always both steps: branch-free, exact when fn == 0) */
+    double t = FMA(-fn, PIO2_1, x);
+    double w = fn * PIO2_2;
+    double r = t - w;
+    w = FMA(fn, PIO2_2T, -((t - r) - w));
     double y0 = r - w;
     double y1 = (r - y0) - w;
 
     /* kernel sin(y0 + y1) */
     double z = y0 * y0;
     double v = z * y0;
-    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double rs = FMA(z, FMA(z, FMA(z, FMA(z, S6, S5), S4), S3), S2);
+    double sa = FMA(-v, rs, 0.5 * y1);
+    double sb = FMA(z, sa, -y1);
+    double ks = y0 - FMA(-v, S1, sb);
     /* kernel cos(y0 + y1) */
     double zz = z * z;
-    double rc = z * (C1 + z * (C2 + z * C3)) + (zz * zz) * (C4 + z * (C5 + z * C6));
+    double p1 = FMA(z, FMA(z, C3, C2), C1);
+    double p2 = FMA(z, FMA(z, C6, C5), C4);
+    double rc = FMA(zz * zz, p2, z * p1);
     double hz = 0.5 * z;
     double wc = 1.0 - hz;
-    double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    double kc = wc + (((1.0 - wc) - hz) + FMA(z, rc, -(y0 * y1)));
 
     int q = ((int)fn) & 3;
     double s_out, c_out;
@@ -138,16 +145,16 @@ static void mat4_identity(double *m)
     m[0] = m[5] = m[10] = m[15] = 1.0;
 }
 
-/* c = a @ b, inner index ascending: ((a0 b0 + a1 b1) + a2 b2) + a3 b3 */
+/* c = a @ b, inner index ascending: fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0))) */
 static void mat4_mul(const double *a, const double *b, double *c)
 {
     double out[16];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
             double acc = a[4 * i + 0] * b[0 + j];
-            acc = acc + a[4 * i + 1] * b[4 + j];
-            acc = acc + a[4 * i + 2] * b[8 + j];
-            acc = acc + a[4 * i + 3] * b[12 + j];
+            acc = FMA(a[4 * i + 1], b[4 + j], acc);
+            acc = FMA(a[4 * i + 2], b[8 + j], acc);
+            acc = FMA(a[4 * i + 3], b[12 + j], acc);
             out[4 * i + j] = acc;
         }
     memcpy(c, out, sizeof(out));
@@ -159,8 +166,8 @@ static void mat3_mul(const double *a, const double *b, double *c)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             double acc = a[3 * i + 0] * b[0 + j];
-            acc = acc + a[3 * i + 1] * b[3 + j];
-            acc = acc + a[3 * i + 2] * b[6 + j];
+            acc = FMA(a[3 * i + 1], b[3 + j], acc);
+            acc = FMA(a[3 * i + 2], b[6 + j], acc);
             out[3 * i + j] = acc;
         }
     memcpy(c, out, sizeof(out));
@@ -256,14 +263,14 @@ static void residual(const oracle_chain *ch, const double *x, const double *targ
 static double vnorm(const double *x, int n)
 {
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc = acc + x[i] * x[i];
+    for (int i = 0; i < n; ++i) acc = FMA(x[i], x[i], acc);
     return sqrt(acc);
 }
 
 static double vdot(const double *a, const double *b, int n)
 {
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc = acc + a[i] * b[i];
+    for (int i = 0; i < n; ++i) acc = FMA(a[i], b[i], acc);
     return acc;
 }
 
@@ -323,7 +330,8 @@ static void approx_jacobian(const oracle_chain *ch, const double *x, const doubl
         double dx = x1[i] - x[i];
         double f1[NRES];
         residual(ch, x1, target, f1);
-        for (int k = 0; k < NRES; ++k) J[k][i] = (f1[k] - f0[k]) / dx;
+        double inv_dx = 1.0 / dx;
+        for (int k = 0; k < NRES; ++k) J[k][i] = (f1[k] - f0[k]) * inv_dx;
         x1[i] = x[i];
     }
 }
@@ -354,27 +362,27 @@ static void jacobi_svd(int rows, int n, double a[MAXROWS][MAXN], double *s,
             for (int q = p + 1; q < n; ++q) {
                 double alpha = 0.0, beta = 0.0, gamma = 0.0;
                 for (int i = 0; i < rows; ++i) {
-                    alpha = alpha + a[i][p] * a[i][p];
-                    beta = beta + a[i][q] * a[i][q];
-                    gamma = gamma + a[i][p] * a[i][q];
+                    alpha = FMA(a[i][p], a[i][p], alpha);
+                    beta = FMA(a[i][q], a[i][q], beta);
+                    gamma = FMA(a[i][p], a[i][q], gamma);
                 }
                 if (gamma == 0.0) continue;
                 if (fabs(gamma) <= TOL * sqrt(alpha * beta)) continue;
                 rotated = 1;
                 double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double t = 1.0 / (fabs(zeta) + sqrt(FMA(zeta, zeta, 1.0)));
                 if (zeta < 0.0) t = -t;
-                double c = 1.0 / sqrt(1.0 + t * t);
+                double c = 1.0 / sqrt(FMA(t, t, 1.0));
                 double sn = c * t;
                 for (int i = 0; i < rows; ++i) {
                     double ap = a[i][p], aq = a[i][q];
-                    a[i][p] = c * ap - sn * aq;
-                    a[i][q] = sn * ap + c * aq;
+                    a[i][p] = FMA(c, ap, -(sn * aq));
+                    a[i][q] = FMA(sn, ap, c * aq);
                 }
                 for (int i = 0; i < n; ++i) {
                     double vp = v[i][p], vq = v[i][q];
-                    v[i][p] = c * vp - sn * vq;
-                    v[i][q] = sn * vp + c * vq;
+                    v[i][p] = FMA(c, vp, -(sn * vq));
+                    v[i][q] = FMA(sn, vp, c * vq);
                 }
             }
         if (!rotated) break;
@@ -383,7 +391,7 @@ static void jacobi_svd(int rows, int n, double a[MAXROWS][MAXN], double *s,
     int order[MAXN];
     for (int j = 0; j < n; ++j) {
         double acc = 0.0;
-        for (int i = 0; i < rows; ++i) acc = acc + a[i][j] * a[i][j];
+        for (int i = 0; i < rows; ++i) acc = FMA(a[i][j], a[i][j], acc);
         sv[j] = sqrt(acc);
         order[j] = j;
     }
@@ -398,31 +406,35 @@ static void jacobi_svd(int rows, int n, double a[MAXROWS][MAXN], double *s,
     for (int jj = 0; jj < n; ++jj) {
         int j = order[jj];
         s[jj] = sv[j];
-        for (int i = 0; i < rows; ++i) u[i][jj] = (sv[j] > 0.0) ? a[i][j] / sv[j] : 0.0;
+        double inv_sv = (sv[j] > 0.0) ? 1.0 / sv[j] : 0.0;
+        for (int i = 0; i < rows; ++i) u[i][jj] = a[i][j] * inv_sv;
         for (int i = 0; i < n; ++i) vtmp[i][jj] = v[i][j];
     }
     memcpy(v, vtmp, sizeof(vtmp));
 }
 
-/* _lsq/common.py:phi_and_derivative (inner function of solve_lsq_trust_region) */
-static void phi_and_derivative(double alpha, const double *suf, const double *s, int n, double Delta,
-                               double *phi, double *phi_prime)
+/* _lsq/common.py:phi_and_derivative (inner function of solve_lsq_trust_region):
+ *   phi = ||suf / (s^2 + alpha)|| - Delta,  phi' = -sum(suf^2 / (s^2 + alpha)^3) / ||...||.
+ * Returns phi and the Newton ratio phi / phi' = -phi * ||..|| / sum(..); the three quotients
+ * by (s_i^2 + alpha) share one reciprocal. */
+static void phi_and_ratio(double alpha, const double *suf, const double *s, int n, double Delta,
+                          double *phi, double *ratio)
 {
     double tmp[MAXN];
-    for (int i = 0; i < n; ++i) tmp[i] = suf[i] / (s[i] * s[i] + alpha);
-    double p_norm = vnorm(tmp, n);
     double acc = 0.0;
     for (int i = 0; i < n; ++i) {
-        double denom = s[i] * s[i] + alpha;
-        acc = acc + (suf[i] * suf[i]) / (denom * denom * denom);
+        double r = 1.0 / FMA(s[i], s[i], alpha);
+        tmp[i] = suf[i] * r;
+        acc = FMA(tmp[i] * tmp[i], r, acc);
     }
+    double p_norm = vnorm(tmp, n);
     *phi = p_norm - Delta;
-    *phi_prime = -acc / p_norm;
+    *ratio = -(*phi * p_norm) / acc;
 }
 
-/* _lsq/common.py:solve_lsq_trust_region(n, m, uf, s, V, Delta, initial_alpha), verbatim,
- * including the full-rank Gauss-Newton shortcut.  It is called on the ACTIVE columns only
- * (see the note in oracle_least_squares). */
+/* _lsq/common.py:solve_lsq_trust_region(n, m, uf, s, V, Delta, initial_alpha), including the
+ * full-rank Gauss-Newton shortcut.  It is called on the ACTIVE columns only (see the note in
+ * oracle_least_squares); force_deficient = scipy's m < n branch (never full rank). */
 static void solve_lsq_trust_region(int n, int m, const double *uf, const double *s, double v[MAXN][MAXN],
                                    double Delta, double *alpha_io, double *p, int force_deficient)
 {
@@ -438,35 +450,35 @@ static void solve_lsq_trust_region(int n, int m, const double *uf, const double 
         for (int i = 0; i < n; ++i) tmp[i] = uf[i] / s[i];
         for (int i = 0; i < n; ++i) {
             double acc = 0.0;
-            for (int k = 0; k < n; ++k) acc = acc + v[i][k] * tmp[k];
+            for (int k = 0; k < n; ++k) acc = FMA(v[i][k], tmp[k], acc);
             p[i] = -acc;
         }
         if (vnorm(p, n) <= Delta) { *alpha_io = 0.0; return; }
     }
-    double alpha_upper = vnorm(suf, n) / Delta;
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = vnorm(suf, n) * inv_Delta;
     double alpha_lower = 0.0;
     if (full_rank) {
-        double phi, phi_prime;
-        phi_and_derivative(0.0, suf, s, n, Delta, &phi, &phi_prime);
-        alpha_lower = -phi / phi_prime;
+        double phi, ratio;
+        phi_and_ratio(0.0, suf, s, n, Delta, &phi, &ratio);
+        alpha_lower = -ratio;  /* -phi / phi' */
     }
     double alpha = *alpha_io;
     if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-        double phi, phi_prime;
-        phi_and_derivative(alpha, suf, s, n, Delta, &phi, &phi_prime);
+        double phi, ratio;
+        phi_and_ratio(alpha, suf, s, n, Delta, &phi, &ratio);
         if (phi < 0) alpha_upper = alpha;
-        double ratio = phi / phi_prime;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
-        alpha -= (phi + Delta) * ratio / Delta;
+        alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
-    for (int i = 0; i < n; ++i) tmp[i] = suf[i] / (s[i] * s[i] + alpha);
+    for (int i = 0; i < n; ++i) tmp[i] = suf[i] / FMA(s[i], s[i], alpha);
     for (int i = 0; i < n; ++i) {
         double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc = acc + v[i][k] * tmp[k];
+        for (int k = 0; k < n; ++k) acc = FMA(v[i][k], tmp[k], acc);
         p[i] = -acc;
     }
     double scale = Delta / vnorm(p, n);
@@ -481,7 +493,10 @@ static double step_size_to_bound(const double *x, const double *s, const double 
     double steps[MAXN];
     double min_step = INFINITY;
     for (int i = 0; i < n; ++i) {
-        if (s[i] != 0.0) steps[i] = fmax((lb[i] - x[i]) / s[i], (ub[i] - x[i]) / s[i]);
+        if (s[i] != 0.0) {
+            double inv_s = 1.0 / s[i];
+            steps[i] = fmax((lb[i] - x[i]) * inv_s, (ub[i] - x[i]) * inv_s);
+        }
         else steps[i] = INFINITY;
         if (steps[i] < min_step) min_step = steps[i];
     }
@@ -498,8 +513,8 @@ static double intersect_trust_region_pos(const double *x, const double *s, int n
 {
     double a = vdot(s, s, n);
     double b = vdot(x, s, n);
-    double c = vdot(x, x, n) - Delta * Delta;
-    double d = sqrt(b * b - a * c);
+    double c = FMA(-Delta, Delta, vdot(x, x, n));
+    double d = sqrt(FMA(b, b, -(a * c)));
     double q = -(b + copysign(d, b));
     double t1 = q / a;
     double t2 = c / q;
@@ -510,7 +525,7 @@ static void mat_vec(double Jh[NRES][MAXN], const double *s, int n, double *out)
 {
     for (int k = 0; k < NRES; ++k) {
         double acc = 0.0;
-        for (int i = 0; i < n; ++i) acc = acc + Jh[k][i] * s[i];
+        for (int i = 0; i < n; ++i) acc = FMA(Jh[k][i], s[i], acc);
         out[k] = acc;
     }
 }
@@ -523,10 +538,10 @@ static double evaluate_quadratic(double Jh[NRES][MAXN], const double *g, const d
     mat_vec(Jh, s, n, Js);
     double q = vdot(Js, Js, NRES);
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc = acc + (s[i] * diag[i]) * s[i];
+    for (int i = 0; i < n; ++i) acc = FMA(s[i] * diag[i], s[i], acc);
     q = q + acc;
     double l = vdot(s, g, n);
-    return 0.5 * q + l;
+    return FMA(0.5, q, l);
 }
 
 /* _lsq/common.py:build_quadratic_1d */
@@ -538,7 +553,7 @@ static void build_quadratic_1d(double Jh[NRES][MAXN], const double *g, const dou
     mat_vec(Jh, s, n, v);
     double a = vdot(v, v, NRES);
     double acc = 0.0;
-    for (int i = 0; i < n; ++i) acc = acc + (s[i] * diag[i]) * s[i];
+    for (int i = 0; i < n; ++i) acc = FMA(s[i] * diag[i], s[i], acc);
     a = a + acc;
     a = a * 0.5;
     double b = vdot(g, s, n);
@@ -546,13 +561,13 @@ static void build_quadratic_1d(double Jh[NRES][MAXN], const double *g, const dou
         double u[NRES];
         mat_vec(Jh, s0, n, u);
         b = b + vdot(u, v, NRES);
-        double c = 0.5 * vdot(u, u, NRES) + vdot(g, s0, n);
+        double c = FMA(0.5, vdot(u, u, NRES), vdot(g, s0, n));
         acc = 0.0;
-        for (int i = 0; i < n; ++i) acc = acc + (s0[i] * diag[i]) * s[i];
+        for (int i = 0; i < n; ++i) acc = FMA(s0[i] * diag[i], s[i], acc);
         b = b + acc;
         acc = 0.0;
-        for (int i = 0; i < n; ++i) acc = acc + (s0[i] * diag[i]) * s0[i];
-        c = c + 0.5 * acc;
+        for (int i = 0; i < n; ++i) acc = FMA(s0[i] * diag[i], s0[i], acc);
+        c = FMA(0.5, acc, c);
         *c_out = c;
     }
     *a_out = a;
@@ -570,9 +585,9 @@ static double minimize_quadratic_1d(double a, double b, double lb, double ub, do
         if (lb < extremum && extremum < ub) t[nt++] = extremum;
     }
     int best = 0;
-    double ybest = t[0] * (a * t[0] + b) + c;
+    double ybest = FMA(t[0], FMA(a, t[0], b), c);
     for (int i = 1; i < nt; ++i) {
-        double y = t[i] * (a * t[i] + b) + c;
+        double y = FMA(t[i], FMA(a, t[i], b), c);
         if (y < ybest) { ybest = y; best = i; }
     }
     *y_out = ybest;
@@ -689,7 +704,7 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
     double cost = 0.5 * vdot(f, f, NRES);
     for (int i = 0; i < n; ++i) {  /* compute_grad: J.T.dot(f) */
         double acc = 0.0;
-        for (int k = 0; k < NRES; ++k) acc = acc + J[k][i] * f[k];
+        for (int k = 0; k < NRES; ++k) acc = FMA(J[k][i], f[k], acc);
         g[i] = acc;
     }
 
@@ -752,7 +767,7 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
         jacobi_svd(NRES + na, na, A, s, U, V);
         for (int c = 0; c < na; ++c) {  /* uf = U.T.dot(f_augmented) */
             double acc = 0.0;
-            for (int k = 0; k < NRES; ++k) acc = acc + U[k][c] * f[k];
+            for (int k = 0; k < NRES; ++k) acc = FMA(U[k][c], f[k], acc);
             uf[c] = acc;
         }
         double theta = fmax(0.995, 1 - g_norm);
@@ -804,7 +819,7 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
             approx_jacobian(ch, x, f, target, J);
             for (int i = 0; i < n; ++i) {
                 double acc = 0.0;
-                for (int k = 0; k < NRES; ++k) acc = acc + J[k][i] * f[k];
+                for (int k = 0; k < NRES; ++k) acc = FMA(J[k][i], f[k], acc);
                 g[i] = acc;
             }
         }

@@ -87,14 +87,13 @@ inline void make_leg_consts(const SeqikLegParams &lp, LegConst &lc)
             double lb, ub;
             link_bounds(lp, stage, i, lb, ub);
             double xi = strictly_feasible(seed[i], lb, ub, 1e-10);
-            acc = acc + xi * xi;
+            acc = fma_(xi, xi, acc);
         }
         sc.x_pre_sq = acc;
         {
             double lb, ub;
             link_bounds(lp, stage, n - 1, lb, ub);
-            double xi = strictly_feasible(seed[n - 1], lb, ub, 1e-10);
-            sc.x_suf_sq = xi * xi;
+            sc.x_suf = strictly_feasible(seed[n - 1], lb, ub, 1e-10);
         }
     }
 }

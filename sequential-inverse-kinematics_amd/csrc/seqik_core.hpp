@@ -24,11 +24,13 @@
 //     reference does by re-building the whole ikpy chain per frame, kinematic_chain.py:200+;
 //   * every link matrix is [axis rotation | (0,0,-length)]: products are written out per axis.
 //
-// Floating-point contract: every operation below is one IEEE binary64 op, sums run in the
-// same index order as the generic restatement in oracle/seqik_oracle.c (multiplications by
-// exact 0/1 and additions of exact 0 dropped), sin/cos is the same Cody-Waite +
-// fdlibm-polynomial routine.  Built with -ffp-contract=off the kernels therefore reproduce
-// the oracle bit for bit; tests/ check exactly that.
+// Floating-point contract: every operation below is one IEEE binary64 op or an explicit fused
+// multiply-add (fma_ = v_fma_f64); sums run as acc = fma(a_i, b_i, acc) in the same index order
+// as the generic restatement in oracle/seqik_oracle.c (terms that are exactly 0 and factors
+// that are exactly 1 dropped), quotients by a common denominator use one shared reciprocal,
+// sin/cos is the same Cody-Waite + fdlibm-polynomial routine.  Built with -ffp-contract=off
+// (nothing else gets fused) the kernels therefore reproduce the oracle bit for bit; tests/
+// check exactly that.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +41,8 @@
 namespace seqik {
 
 enum : int { AXIS_X = 0, AXIS_Y = 1, AXIS_Z = 2 };
+
+SEQIK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 enum : int { STATUS_NONE = -99 };
 
 // ---------------------------------------------------------------------------
@@ -50,8 +54,8 @@ struct StageConst {
     double tz_a, tz_b;     // origin_translation z of active link a / b (0 or -segment length)
     double tz_last;        // origin_translation z of the last (inert) link
     double x_pre_sq;       // sum of squares of the (strictly feasible) seed entries in FRONT of the
-                           // active links, accumulated in link order from 0.0
-    double x_suf_sq;       // square of the seed entry of the last link
+                           // active links, accumulated in link order as acc = fma(x, x, acc) from 0.0
+    double x_suf;          // (strictly feasible) seed entry of the last link
     int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
     int32_t pad_;
 };
@@ -97,22 +101,26 @@ SEQIK_HD void sincos_cw(double x, double &sn, double &cs)
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     double fn = rint(x * INVPIO2);
-    double t = x - fn * PIO2_1;
+    double t = fma_(-fn, PIO2_1, x);
     double w = fn * PIO2_2;
     double r = t - w;
-    w = fn * PIO2_2T - ((t - r) - w);
+    w = fma_(fn, PIO2_2T, -((t - r) - w));
     double y0 = r - w;
     double y1 = (r - y0) - w;
 
     double z = y0 * y0;
     double v = z * y0;
-    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double rs = fma_(z, fma_(z, fma_(z, fma_(z, S6, S5), S4), S3), S2);
+    double sa = fma_(-v, rs, 0.5 * y1);
+    double sb = fma_(z, sa, -y1);
+    double ks = y0 - fma_(-v, S1, sb);
     double zz = z * z;
-    double rc = z * (C1 + z * (C2 + z * C3)) + (zz * zz) * (C4 + z * (C5 + z * C6));
+    double p1 = fma_(z, fma_(z, C3, C2), C1);
+    double p2 = fma_(z, fma_(z, C6, C5), C4);
+    double rc = fma_(zz * zz, p2, z * p1);
     double hz = 0.5 * z;
     double wc = 1.0 - hz;
-    double kc = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    double kc = wc + (((1.0 - wc) - hz) + fma_(z, rc, -(y0 * y1)));
 
     int q = ((int)fn) & 3;
     double s_sel = (q & 1) ? kc : ks;
@@ -149,15 +157,15 @@ SEQIK_HD void frame_mul_link(Frame &out, const Frame &in, double s, double c, do
         double a0 = in.r[3 * i], a1 = in.r[3 * i + 1], a2 = in.r[3 * i + 2];
         if constexpr (AXIS == AXIS_X) {
             out.r[3 * i] = a0;
-            out.r[3 * i + 1] = a1 * c + a2 * s;
-            out.r[3 * i + 2] = a1 * (-s) + a2 * c;
+            out.r[3 * i + 1] = fma_(a2, s, a1 * c);
+            out.r[3 * i + 2] = fma_(a2, c, a1 * (-s));
         } else if constexpr (AXIS == AXIS_Y) {
-            out.r[3 * i] = a0 * c + a2 * (-s);
+            out.r[3 * i] = fma_(a2, -s, a0 * c);
             out.r[3 * i + 1] = a1;
-            out.r[3 * i + 2] = a0 * s + a2 * c;
+            out.r[3 * i + 2] = fma_(a2, c, a0 * s);
         } else {
-            out.r[3 * i] = a0 * c + a1 * s;
-            out.r[3 * i + 1] = a0 * (-s) + a1 * c;
+            out.r[3 * i] = fma_(a1, s, a0 * c);
+            out.r[3 * i + 1] = fma_(a1, c, a0 * (-s));
             out.r[3 * i + 2] = a2;
         }
     }
@@ -201,28 +209,22 @@ SEQIK_HD double strictly_feasible(double x, double lb, double ub, double rstep)
 template <int NA>
 SEQIK_HD double norm2v(const double *a)
 {
-    double acc = 0.0;
-    acc = acc + a[0] * a[0];
-    if constexpr (NA == 2) acc = acc + a[1] * a[1];
+    double acc = a[0] * a[0];
+    if constexpr (NA == 2) acc = fma_(a[1], a[1], acc);
     return sqrt(acc);
 }
 
 template <int NA>
 SEQIK_HD double dot2v(const double *a, const double *b)
 {
-    double acc = 0.0;
-    acc = acc + a[0] * b[0];
-    if constexpr (NA == 2) acc = acc + a[1] * b[1];
+    double acc = a[0] * b[0];
+    if constexpr (NA == 2) acc = fma_(a[1], b[1], acc);
     return acc;
 }
 
 SEQIK_HD double dot3(const double *a, const double *b)
 {
-    double acc = 0.0;
-    acc = acc + a[0] * b[0];
-    acc = acc + a[1] * b[1];
-    acc = acc + a[2] * b[2];
-    return acc;
+    return fma_(a[2], b[2], fma_(a[1], b[1], a[0] * b[0]));
 }
 
 template <int NA>
@@ -230,9 +232,8 @@ SEQIK_HD void matvec32(const double Jh[3][2], const double *s, double *out)
 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        double acc = 0.0;
-        acc = acc + Jh[k][0] * s[0];
-        if constexpr (NA == 2) acc = acc + Jh[k][1] * s[1];
+        double acc = Jh[k][0] * s[0];
+        if constexpr (NA == 2) acc = fma_(Jh[k][1], s[1], acc);
         out[k] = acc;
     }
 }
@@ -240,9 +241,8 @@ SEQIK_HD void matvec32(const double Jh[3][2], const double *s, double *out)
 template <int NA>
 SEQIK_HD double diag_form(const double *a, const double *diag, const double *b)
 {
-    double acc = 0.0;
-    acc = acc + (a[0] * diag[0]) * b[0];
-    if constexpr (NA == 2) acc = acc + (a[1] * diag[1]) * b[1];
+    double acc = (a[0] * diag[0]) * b[0];
+    if constexpr (NA == 2) acc = fma_(a[1] * diag[1], b[1], acc);
     return acc;
 }
 
@@ -279,18 +279,15 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
 {
     if constexpr (NA == 1) {
         // 4 x 1: singular value = column norm, V = [1]
-        double acc = 0.0;
-        acc = acc + Jh[0][0] * Jh[0][0];
-        acc = acc + Jh[1][0] * Jh[1][0];
-        acc = acc + Jh[2][0] * Jh[2][0];
-        acc = acc + q[0] * q[0];
+        double acc = Jh[0][0] * Jh[0][0];
+        acc = fma_(Jh[1][0], Jh[1][0], acc);
+        acc = fma_(Jh[2][0], Jh[2][0], acc);
+        acc = fma_(q[0], q[0], acc);
         double sv0 = sqrt(acc);
-        double u0 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double e0 = (sv0 > 0.0) ? Jh[k][0] / sv0 : 0.0;
-            u0 = u0 + e0 * f[k];
-        }
+        double inv0 = (sv0 > 0.0) ? 1.0 / sv0 : 0.0;
+        double u0 = (Jh[0][0] * inv0) * f[0];
+        u0 = fma_(Jh[1][0] * inv0, f[1], u0);
+        u0 = fma_(Jh[2][0] * inv0, f[2], u0);
         s[0] = sv0; s[1] = 0.0; uf[0] = u0; uf[1] = 0.0;
         V[0][0] = 1.0; V[0][1] = 0.0; V[1][0] = 0.0; V[1][1] = 1.0;
     } else {
@@ -301,46 +298,55 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
         A[3][0] = q[0]; A[3][1] = 0.0;
         A[4][0] = 0.0;  A[4][1] = q[1];
         V[0][0] = 1.0; V[0][1] = 0.0; V[1][0] = 0.0; V[1][1] = 1.0;
+        // squared column norms of the final A: the sums of the last (non-rotating) sweep are the
+        // same sums the oracle recomputes for the singular values
+        double alpha = 0.0, beta = 0.0;
+        bool have_norms = false;
         for (int sweep = 0; sweep < 30; ++sweep) {
-            double alpha = 0.0, beta = 0.0, gamma = 0.0;
+            double gamma = 0.0;
+            alpha = 0.0; beta = 0.0;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                alpha = alpha + A[i][0] * A[i][0];
-                beta = beta + A[i][1] * A[i][1];
-                gamma = gamma + A[i][0] * A[i][1];
+                alpha = fma_(A[i][0], A[i][0], alpha);
+                beta = fma_(A[i][1], A[i][1], beta);
+                gamma = fma_(A[i][0], A[i][1], gamma);
             }
+            have_norms = true;
             if (gamma == 0.0) break;
             if (fabs(gamma) <= TOL * sqrt(alpha * beta)) break;
+            have_norms = false;
             double zeta = (beta - alpha) / (2.0 * gamma);
-            double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            double t = 1.0 / (fabs(zeta) + sqrt(fma_(zeta, zeta, 1.0)));
             if (zeta < 0.0) t = -t;
-            double c = 1.0 / sqrt(1.0 + t * t);
+            double c = 1.0 / sqrt(fma_(t, t, 1.0));
             double sn = c * t;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 double ap = A[i][0], aq = A[i][1];
-                A[i][0] = c * ap - sn * aq;
-                A[i][1] = sn * ap + c * aq;
+                A[i][0] = fma_(c, ap, -(sn * aq));
+                A[i][1] = fma_(sn, ap, c * aq);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 double vp = V[i][0], vq = V[i][1];
-                V[i][0] = c * vp - sn * vq;
-                V[i][1] = sn * vp + c * vq;
+                V[i][0] = fma_(c, vp, -(sn * vq));
+                V[i][1] = fma_(sn, vp, c * vq);
             }
         }
-        double sv0 = 0.0, sv1 = 0.0;
+        if (!have_norms) {
+            alpha = 0.0; beta = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { sv0 = sv0 + A[i][0] * A[i][0]; sv1 = sv1 + A[i][1] * A[i][1]; }
-        sv0 = sqrt(sv0);
-        sv1 = sqrt(sv1);
-        double u0 = 0.0, u1 = 0.0;
+            for (int i = 0; i < 5; ++i) { alpha = fma_(A[i][0], A[i][0], alpha); beta = fma_(A[i][1], A[i][1], beta); }
+        }
+        double sv0 = sqrt(alpha);
+        double sv1 = sqrt(beta);
+        double inv0 = (sv0 > 0.0) ? 1.0 / sv0 : 0.0;
+        double inv1 = (sv1 > 0.0) ? 1.0 / sv1 : 0.0;
+        double u0 = (A[0][0] * inv0) * f[0], u1 = (A[0][1] * inv1) * f[0];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double e0 = (sv0 > 0.0) ? A[k][0] / sv0 : 0.0;
-            u0 = u0 + e0 * f[k];
-            double e1 = (sv1 > 0.0) ? A[k][1] / sv1 : 0.0;
-            u1 = u1 + e1 * f[k];
+        for (int k = 1; k < 3; ++k) {
+            u0 = fma_(A[k][0] * inv0, f[k], u0);
+            u1 = fma_(A[k][1] * inv1, f[k], u1);
         }
         // descending order (stable): swap only if the second is strictly larger
         if (sv0 < sv1) {
@@ -354,40 +360,35 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
     }
 }
 
+// phi = ||suf / (s^2 + alpha)|| - Delta and the Newton ratio phi / phi' (oracle phi_and_ratio)
 template <int NA>
-SEQIK_HD void phi_and_derivative(double alpha, const double *suf, const double *s, double Delta, double &phi,
-                                 double &phi_prime)
+SEQIK_HD void phi_and_ratio(double alpha, const double *suf, const double *s, double Delta, double &phi, double &ratio)
 {
-    double tmp[2] = {0.0, 0.0};
-    tmp[0] = suf[0] / (s[0] * s[0] + alpha);
-    if constexpr (NA == 2) tmp[1] = suf[1] / (s[1] * s[1] + alpha);
-    double p_norm = norm2v<NA>(tmp);
-    double acc = 0.0;
-    {
-        double denom = s[0] * s[0] + alpha;
-        acc = acc + (suf[0] * suf[0]) / (denom * denom * denom);
-    }
+    double r0 = 1.0 / fma_(s[0], s[0], alpha);
+    double t0 = suf[0] * r0;
+    double acc = (t0 * t0) * r0;
+    double nn = t0 * t0;
     if constexpr (NA == 2) {
-        double denom = s[1] * s[1] + alpha;
-        acc = acc + (suf[1] * suf[1]) / (denom * denom * denom);
+        double r1 = 1.0 / fma_(s[1], s[1], alpha);
+        double t1 = suf[1] * r1;
+        acc = fma_(t1 * t1, r1, acc);
+        nn = fma_(t1, t1, nn);
     }
+    double p_norm = sqrt(nn);
     phi = p_norm - Delta;
-    phi_prime = -acc / p_norm;
+    ratio = -(phi * p_norm) / acc;
 }
 
 template <int NA>
 SEQIK_HD void apply_V_neg(const double V[2][2], const double *tmp, double *p)
 {
     {
-        double acc = 0.0;
-        acc = acc + V[0][0] * tmp[0];
-        if constexpr (NA == 2) acc = acc + V[0][1] * tmp[1];
+        double acc = V[0][0] * tmp[0];
+        if constexpr (NA == 2) acc = fma_(V[0][1], tmp[1], acc);
         p[0] = -acc;
     }
     if constexpr (NA == 2) {
-        double acc = 0.0;
-        acc = acc + V[1][0] * tmp[0];
-        acc = acc + V[1][1] * tmp[1];
+        double acc = fma_(V[1][1], tmp[1], V[1][0] * tmp[0]);
         p[1] = -acc;
     } else {
         p[1] = 0.0;
@@ -414,28 +415,28 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
             if (norm2v<NA>(p) <= Delta) { alpha_io = 0.0; return; }
         }
     }
-    double alpha_upper = norm2v<NA>(suf) / Delta;
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = norm2v<NA>(suf) * inv_Delta;
     double alpha_lower = 0.0;
     if (full_rank) {
-        double phi, phi_prime;
-        phi_and_derivative<NA>(0.0, suf, s, Delta, phi, phi_prime);
-        alpha_lower = -phi / phi_prime;
+        double phi, ratio;
+        phi_and_ratio<NA>(0.0, suf, s, Delta, phi, ratio);
+        alpha_lower = -ratio;
     }
     double alpha = alpha_io;
     if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-        double phi, phi_prime;
-        phi_and_derivative<NA>(alpha, suf, s, Delta, phi, phi_prime);
+        double phi, ratio;
+        phi_and_ratio<NA>(alpha, suf, s, Delta, phi, ratio);
         if (phi < 0) alpha_upper = alpha;
-        double ratio = phi / phi_prime;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
-        alpha -= (phi + Delta) * ratio / Delta;
+        alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
-    tmp[0] = suf[0] / (s[0] * s[0] + alpha);
-    if constexpr (NA == 2) tmp[1] = suf[1] / (s[1] * s[1] + alpha);
+    tmp[0] = suf[0] / fma_(s[0], s[0], alpha);
+    if constexpr (NA == 2) tmp[1] = suf[1] / fma_(s[1], s[1], alpha);
     apply_V_neg<NA>(V, tmp, p);
     double scale = Delta / norm2v<NA>(p);
     p[0] = p[0] * scale;
@@ -457,9 +458,15 @@ SEQIK_HD double step_size_to_bound(const double *x, const double *s, const doubl
 {
     const double INF = __builtin_huge_val();
     double steps[2] = {INF, INF};
-    if (s[0] != 0.0) steps[0] = fmax((lb[0] - x[0]) / s[0], (ub[0] - x[0]) / s[0]);
+    if (s[0] != 0.0) {
+        double inv_s = 1.0 / s[0];
+        steps[0] = fmax((lb[0] - x[0]) * inv_s, (ub[0] - x[0]) * inv_s);
+    }
     if constexpr (NA == 2)
-        if (s[1] != 0.0) steps[1] = fmax((lb[1] - x[1]) / s[1], (ub[1] - x[1]) / s[1]);
+        if (s[1] != 0.0) {
+            double inv_s = 1.0 / s[1];
+            steps[1] = fmax((lb[1] - x[1]) * inv_s, (ub[1] - x[1]) * inv_s);
+        }
     double min_step = fmin(steps[0], steps[1]);
     if (hits) {
         int sg0 = (s[0] > 0) - (s[0] < 0);
@@ -479,22 +486,22 @@ SEQIK_HD double evaluate_quadratic(const double Jh[3][2], const double *g, const
     double q = dot3(Js, Js);
     q = q + diag_form<NA>(s, diag, s);
     double l = dot2v<NA>(s, g);
-    return 0.5 * q + l;
+    return fma_(0.5, q, l);
 }
 
 // _lsq/common.py:minimize_quadratic_1d
 SEQIK_HD double minimize_quadratic_1d(double a, double b, double lb, double ub, double c, double &y_out)
 {
     double tbest = lb;
-    double ybest = lb * (a * lb + b) + c;
+    double ybest = fma_(lb, fma_(a, lb, b), c);
     {
-        double y = ub * (a * ub + b) + c;
+        double y = fma_(ub, fma_(a, ub, b), c);
         if (y < ybest) { ybest = y; tbest = ub; }
     }
     if (a != 0) {
         double extremum = -0.5 * b / a;
         if (lb < extremum && extremum < ub) {
-            double y = extremum * (a * extremum + b) + c;
+            double y = fma_(extremum, fma_(a, extremum, b), c);
             if (y < ybest) { ybest = y; tbest = extremum; }
         }
     }
@@ -530,8 +537,8 @@ SEQIK_HD double select_step_reflective(
     {
         double a = dot2v<NA>(r_h, r_h);
         double b = dot2v<NA>(p_h, r_h);
-        double c = dot2v<NA>(p_h, p_h) - Delta * Delta;
-        double dd = sqrt(b * b - a * c);
+        double c = fma_(-Delta, Delta, dot2v<NA>(p_h, p_h));
+        double dd = sqrt(fma_(b, b, -(a * c)));
         double q = -(b + copysign(dd, b));
         double t1 = q / a;
         double t2 = c / q;
@@ -558,9 +565,9 @@ SEQIK_HD double select_step_reflective(
         double b = dot2v<NA>(g_h, r_h);
         matvec32<NA>(Jh, p_h, u);
         b = b + dot3(u, v);
-        double c = 0.5 * dot3(u, u) + dot2v<NA>(g_h, p_h);
+        double c = fma_(0.5, dot3(u, u), dot2v<NA>(g_h, p_h));
         b = b + diag_form<NA>(p_h, diag_h, r_h);
-        c = c + 0.5 * diag_form<NA>(p_h, diag_h, p_h);
+        c = fma_(0.5, diag_form<NA>(p_h, diag_h, p_h), c);
         r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, r_value);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -665,8 +672,9 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
         double s1, c1, f1[3];
         sincos_cw(x1, s1, c1);
         residual_sc<STAGE>(P, s1, c1, sb, cb, f1);
+        double inv_dx = 1.0 / dx;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) J[i][0] = (f1[i] - f0[i]) / dx;
+        for (int i = 0; i < 3; ++i) J[i][0] = (f1[i] - f0[i]) * inv_dx;
     }
     if constexpr (T::NA == 2) {
         double h = fd_step(x[1], lb[1], ub[1]);
@@ -675,8 +683,9 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
         double s1, c1, f1[3];
         sincos_cw(x1, s1, c1);
         residual_sc<STAGE>(P, sa, ca, s1, c1, f1);
+        double inv_dx = 1.0 / dx;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) J[i][1] = (f1[i] - f0[i]) / dx;
+        for (int i = 0; i < 3; ++i) J[i][1] = (f1[i] - f0[i]) * inv_dx;
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) J[i][1] = 0.0;
@@ -791,11 +800,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                double acc = 0.0;
-                acc = acc + J[0][j] * f[0];
-                acc = acc + J[1][j] * f[1];
-                acc = acc + J[2][j] * f[2];
-                g[j] = acc;
+                g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], J[0][j] * f[0]));
             }
             cl_scaling(x[0], g[0], lb[0], ub[0], v[0], dv[0]);
             if constexpr (NA == 2) cl_scaling(x[1], g[1], lb[1], ub[1], v[1], dv[1]);
@@ -805,9 +810,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double acc = sc.x_pre_sq;
                 // (x is still the start point x0 here: no step has been taken yet)
                 double t0 = x[0] / sqrt(v[0]);
-                acc = acc + t0 * t0;
-                if constexpr (NA == 2) { double t1 = x[1] / sqrt(v[1]); acc = acc + t1 * t1; }
-                acc = acc + sc.x_suf_sq;
+                acc = fma_(t0, t0, acc);
+                if constexpr (NA == 2) { double t1 = x[1] / sqrt(v[1]); acc = fma_(t1, t1, acc); }
+                acc = fma_(sc.x_suf, sc.x_suf, acc);
                 Delta = sqrt(acc);
                 if (Delta == 0) Delta = 1.0;
                 first_pass = false;
@@ -868,9 +873,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double step_norm = norm2v<NA>(step);
                 // ||x|| over all links: inert prefix, active, inert last link
                 double xn = sc.x_pre_sq;
-                xn = xn + x[0] * x[0];
-                if constexpr (NA == 2) xn = xn + x[1] * x[1];
-                xn = xn + sc.x_suf_sq;
+                xn = fma_(x[0], x[0], xn);
+                if constexpr (NA == 2) xn = fma_(x[1], x[1], xn);
+                xn = fma_(sc.x_suf, sc.x_suf, xn);
                 xn = sqrt(xn);
                 bool ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
                 bool xtol_ok = step_norm < xtol * (xtol + xn);

@@ -48,17 +48,18 @@ def solve_sharded(pose_all: np.ndarray, solve_fn: Callable[[np.ndarray], np.ndar
 class GatherPipeline:
     """Per-step "final joint-angle gather" to rank 0, overlapped with the next step's kernels.
 
-    Two angle buffers alternate: ``submit(b, tensor)`` starts an asynchronous gather of buffer ``b``
+    ``n_buffers`` angle buffers alternate: ``submit(b, tensor)`` starts an asynchronous gather of buffer ``b``
     (ordered after the work already queued on the current stream), ``wait_buffer(b)`` must be called
     before buffer ``b`` is overwritten again, ``drain()`` at the end.  On the "nccl" (RCCL) backend the
     waits are stream-side; on "gloo" they block the host.  Rank 0 keeps the most recent gather of
     each buffer in ``self.recv[b]`` (list of ``world`` tensors)."""
 
-    def __init__(self, dist, world: int, rank: int, like, dst: int = 0):
+    def __init__(self, dist, world: int, rank: int, like, dst: int = 0, n_buffers: int = 2):
         import torch
         self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
-        self.work = [None, None]
-        self.recv = [[torch.empty_like(like) for _ in range(world)] if rank == dst else None for _ in range(2)]
+        self.work = [None] * n_buffers
+        self.recv = [[torch.empty_like(like) for _ in range(world)] if rank == dst else None
+                     for _ in range(n_buffers)]
 
     def wait_buffer(self, b: int):
         if self.work[b] is not None:
@@ -70,5 +71,5 @@ class GatherPipeline:
         self.work[b] = self.dist.gather(tensor, gather_list=self.recv[b], dst=self.dst, async_op=True)
 
     def drain(self):
-        for b in (0, 1):
+        for b in range(len(self.work)):
             self.wait_buffer(b)
