@@ -88,6 +88,19 @@ typedef struct SeqikLayout {
     int64_t ang_chain, ang_dof, ang_frame;
 } SeqikLayout;
 
+/* Optional fused alignment of one leg (AlignPose.align_leg, seqikpy/alignment.py:436-487).  When an
+ * array of these is passed, `pose` holds RAW (un-aligned) key points and the kernels compute
+ *     aligned[row] = (raw[row] - fixed_coxa) * scale + template_coxa   (rows 1..4),  aligned[0] = template_coxa
+ * in their prologue, with the reference's rounding sequence, before forming the stage target.
+ *   fixed_coxa     AlignPose.get_fixed_pos(raw[:, 0, :])   (quantile statistics, computed by the caller)
+ *   scale          AlignPose.find_scale_leg(...)
+ *   template_coxa  body_template["<leg>_Coxa"]                                                         */
+typedef struct SeqikAffine {
+    double fixed_coxa[3];
+    double scale;
+    double template_coxa[3];
+} SeqikAffine;
+
 int seqik_abi_version(void);
 int seqik_device_count(void);
 const char *seqik_last_error(void);
@@ -112,12 +125,13 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
  *   status, nfev  nullable int32 [n_seq][n_legs][n_frames][4]: scipy termination status /
  *           trial-evaluation count per (frame, stage); requesting either costs one extra
  *           Jacobian per solve
+ *   affine  nullable [n_legs]: fuse AlignPose.align_leg into the kernels (pose is then RAW)
  * Frame t of a chain is warm-started from frame t-1 of the same chain; frame 0 from the seeds.
  */
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                     const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                     double *angles, double *fk, int32_t *status, int32_t *nfev,
-                    const SeqikOptions *opt);
+                    const SeqikAffine *affine /* nullable [n_legs] */, const SeqikOptions *opt);
 
 /*
  * Same computation on DEVICE buffers of the current HIP device, enqueued on `hip_stream`
@@ -129,7 +143,8 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
-                           const SeqikLayout *layout, const SeqikOptions *opt, void *hip_stream);
+                           const SeqikLayout *layout, const SeqikAffine *affine /* nullable [n_legs] */,
+                           const SeqikOptions *opt, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -55,8 +55,15 @@ inline int validate_leg(const SeqikLegParams &lp, int first_stage, int last_stag
     return SEQIK_OK;
 }
 
-inline void make_leg_consts(const SeqikLegParams &lp, LegConst &lc)
+inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, LegConst &lc)
 {
+    lc.aff.enabled = aff ? 1 : 0;
+    lc.aff.pad_ = 0;
+    lc.aff.scale = aff ? aff->scale : 1.0;
+    for (int a = 0; a < 3; ++a) {
+        lc.aff.fixed_coxa[a] = aff ? aff->fixed_coxa[a] : 0.0;
+        lc.aff.template_coxa[a] = aff ? aff->template_coxa[a] : 0.0;
+    }
     for (int stage = 1; stage <= 4; ++stage) {
         StageConst &sc = lc.st[stage - 1];
         const int n = kStageLinks[stage - 1];

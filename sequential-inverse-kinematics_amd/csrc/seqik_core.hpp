@@ -60,8 +60,20 @@ struct StageConst {
     int32_t pad_;
 };
 
+// Optional fused alignment (AlignPose.align_leg, seqikpy/alignment.py:436-487): the key points
+// handed to the kernel are RAW and  aligned = (raw - fixed_coxa) * scale + template_coxa  for rows
+// 1..4, aligned row 0 = template_coxa.
+struct LegAffine {
+    double fixed_coxa[3];
+    double scale;
+    double template_coxa[3];
+    int32_t enabled;
+    int32_t pad_;
+};
+
 struct LegConst {
     StageConst st[4];
+    LegAffine aff;
 };
 
 // Compile-time description of a stage chain (kinematic_chain.py:152-421):
@@ -779,9 +791,19 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             const double *kp = org + STAGE * io.pose_row;
             if constexpr (STAGE > 1)
                 build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, (WANT_FK && STAGE == 4) ? coxa_end : nullptr);
-            P.target[0] = kp[0] - org[0];
-            P.target[1] = kp[1] - org[1];
-            P.target[2] = kp[2] - org[2];
+            if (lc.aff.enabled) {
+                // fused AlignPose.align_leg, then target = aligned key point - aligned origin
+                // (three separately rounded operations, as numpy evaluates them)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    double al = (kp[a] - lc.aff.fixed_coxa[a]) * lc.aff.scale + lc.aff.template_coxa[a];
+                    P.target[a] = al - lc.aff.template_coxa[a];
+                }
+            } else {
+                P.target[0] = kp[0] - org[0];
+                P.target[1] = kp[1] - org[1];
+                P.target[2] = kp[2] - org[2];
+            }
             x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
             if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
             eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
@@ -908,7 +930,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
             }
             if constexpr (WANT_FK && STAGE == 4) {
-                const double *origin = io.pose + t * io.pose_frame;
+                const double *origin = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
                 double *fk = io.fk + t * 27;
                 Frame after;  // frame after the TiTa link at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);

@@ -104,11 +104,11 @@ struct LegTableCache {
 };
 thread_local LegTableCache g_cache;
 
-int device_leg_table(const SeqikLegParams *legs, int32_t n_legs, const seqik::LegConst **out)
+int device_leg_table(const SeqikLegParams *legs, const SeqikAffine *affine, int32_t n_legs, const seqik::LegConst **out)
 {
     std::vector<seqik::LegConst> h(n_legs);
     memset(h.data(), 0, sizeof(seqik::LegConst) * n_legs);
-    for (int l = 0; l < n_legs; ++l) seqik::make_leg_consts(legs[l], h[l]);
+    for (int l = 0; l < n_legs; ++l) seqik::make_leg_consts(legs[l], affine ? affine + l : nullptr, h[l]);
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     LegTableCache &c = g_cache;
@@ -213,13 +213,14 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
-                           const SeqikLayout *layout, const SeqikOptions *opt, void *hip_stream)
+                           const SeqikLayout *layout, const SeqikAffine *affine, const SeqikOptions *opt,
+                           void *hip_stream)
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
     if (rc != SEQIK_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const seqik::LegConst *d_legs = nullptr;
-    rc = device_leg_table(legs, n_legs, &d_legs);
+    rc = device_leg_table(legs, affine, n_legs, &d_legs);
     if (rc != SEQIK_OK) return rc;
     return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
                   d_status, d_nfev, layout, opt, stream);
@@ -227,7 +228,8 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
 
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                     const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
-                    double *angles, double *fk, int32_t *status, int32_t *nfev, const SeqikOptions *opt)
+                    double *angles, double *fk, int32_t *status, int32_t *nfev, const SeqikAffine *affine,
+                    const SeqikOptions *opt)
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, pose, angles);
     if (rc != SEQIK_OK) return rc;
@@ -257,7 +259,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
         if (d_status) TRY_BREAK(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
         if (d_nfev) TRY_BREAK(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
         out = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
-                                     d_fk, d_status, d_nfev, nullptr, opt, stream);
+                                     d_fk, d_status, d_nfev, nullptr, affine, opt, stream);
         if (out != SEQIK_OK) break;
         TRY_BREAK(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
         if (want_fk) TRY_BREAK(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));

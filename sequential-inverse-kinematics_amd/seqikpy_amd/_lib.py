@@ -48,6 +48,21 @@ def planar_layout(n_frames: int) -> SeqikLayout:
     return SeqikLayout(15 * n_frames, 3 * n_frames, 3, 7 * n_frames, n_frames, 1)
 
 
+class SeqikAffine(ctypes.Structure):
+    """Mirror of ``struct SeqikAffine``: fused AlignPose.align_leg of one leg."""
+    _fields_ = [("fixed_coxa", ctypes.c_double * 3), ("scale", ctypes.c_double),
+                ("template_coxa", ctypes.c_double * 3)]
+
+
+def make_affine(fixed_coxa, scale, template_coxa) -> SeqikAffine:
+    a = SeqikAffine()
+    for i in range(3):
+        a.fixed_coxa[i] = float(fixed_coxa[i])
+        a.template_coxa[i] = float(template_coxa[i])
+    a.scale = float(scale)
+    return a
+
+
 class SeqikLibraryError(RuntimeError):
     pass
 
@@ -107,13 +122,14 @@ def load():
         L.seqik_solve_seq.restype = ctypes.c_int
         L.seqik_solve_seq.argtypes = [_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
-                                      _dp, _dp, _ip, _ip, ctypes.POINTER(SeqikOptions)]
+                                      _dp, _dp, _ip, _ip, ctypes.POINTER(SeqikAffine),
+                                      ctypes.POINTER(SeqikOptions)]
         L.seqik_solve_seq_device.restype = ctypes.c_int
         L.seqik_solve_seq_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikOptions),
-                                             ctypes.c_void_p]
+                                             ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
+                                             ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
         _lib = L
         return _lib
 
@@ -168,13 +184,22 @@ def validate_legs(legs, first_stage=1, last_stage=4):
         _raise(rc)
 
 
+def _affine_array(affine, n_legs):
+    if affine is None:
+        return None
+    if len(affine) != n_legs:
+        raise ValueError("one SeqikAffine per leg expected")
+    return (SeqikAffine * n_legs)(*affine)
+
+
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
-              device=0, block_size=0):
+              device=0, block_size=0, affine=None):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
     (S, L, N, 7) with earlier-stage columns filled when ``first_stage > 1``.
-    Returns dict(angles, fk or None, status or None, nfev or None).
+    ``affine``: optional list of L ``SeqikAffine`` -- ``pose`` then holds RAW key points and the
+    alignment is fused into the kernels.  Returns dict(angles, fk or None, status or None, nfev or None).
     """
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
@@ -201,14 +226,14 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
                              fk.ctypes.data_as(_dp) if fk is not None else None,
                              status.ctypes.data_as(_ip) if status is not None else None,
                              nfev.ctypes.data_as(_ip) if nfev is not None else None,
-                             ctypes.byref(opt))
+                             _affine_array(affine, L), ctypes.byref(opt))
     if rc != SEQIK_OK:
         _raise(rc)
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
-                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None):
+                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout."""
     arr = (SeqikLegParams * n_legs)(*legs)
@@ -218,6 +243,7 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
                                        last_stage, ctypes.c_void_p(d_angles), ctypes.c_void_p(d_fk or None),
                                        ctypes.c_void_p(d_status or None), ctypes.c_void_p(d_nfev or None),
                                        ctypes.byref(layout) if layout is not None else None,
+                                       _affine_array(affine, n_legs),
                                        ctypes.byref(opt), ctypes.c_void_p(stream or None))
     if rc != SEQIK_OK:
         _raise(rc)

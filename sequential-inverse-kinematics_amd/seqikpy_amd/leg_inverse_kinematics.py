@@ -164,9 +164,13 @@ class LegInvKinSeq(LegInvKinBase):
 
     def __init__(self, aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainSeq,
                  initial_angles: Optional[Dict[str, np.ndarray]] = None,
-                 log_level: Literal["DEBUG", "INFO", "WARNING", "ERROR"] = "INFO") -> None:
+                 log_level: Literal["DEBUG", "INFO", "WARNING", "ERROR"] = "INFO",
+                 leg_affine: Optional[Dict[str, tuple]] = None) -> None:
         super().__init__(aligned_pos, kinematic_chain_class, initial_angles, log_level)
         self.joint_angles_dict = {}
+        #: optional ``{leg: (fixed_coxa, scale, template_coxa)}`` (``AlignPose.leg_affines()``): when
+        #: given, ``aligned_pos`` holds RAW key points and the alignment is fused into the kernels
+        self.leg_affine = leg_affine
         #: scipy termination status / nfev of the last run when ``diagnostics=True`` was passed
         self.solver_status = {}
         self.solver_nfev = {}
@@ -246,8 +250,11 @@ class LegInvKinSeq(LegInvKinBase):
             legs = [self._leg_params(leg_name) for _, leg_name, _ in items]
             pose = np.stack([np.asarray(arr, dtype=np.float64)[:, :5, :] for _, _, arr in items])[None]
             prior = np.stack([self._prior_angles(leg_name, n_frames, first_stage) for _, leg_name, _ in items])[None]
+            affine = None
+            if self.leg_affine is not None:
+                affine = [_lib.make_affine(*self.leg_affine[leg_name]) for _, leg_name, _ in items]
             out = _lib.solve_seq(pose, legs, first_stage, last_stage, angles=prior, want_fk=True,
-                                 want_diag=diagnostics, device=self.device)
+                                 want_diag=diagnostics, device=self.device, affine=affine)
             for li, (segment_name, leg_name, _) in enumerate(items):
                 for stage in stages:
                     for dof in STAGE_DOFS[stage]:

@@ -54,6 +54,10 @@ class LegParamsC(ctypes.Structure):
     _fields_ = [("seg", ctypes.c_double * 4), ("bounds", (ctypes.c_double * 2) * 7), ("seeds", ctypes.c_double * 27)]
 
 
+class AffineC(ctypes.Structure):
+    _fields_ = [("fixed_coxa", ctypes.c_double * 3), ("scale", ctypes.c_double), ("template_coxa", ctypes.c_double * 3)]
+
+
 class HostHarness:
     """ctypes front end of tests/harness/host_harness.hip (device core compiled for the host)."""
 
@@ -63,10 +67,10 @@ class HostHarness:
         ip = ctypes.POINTER(ctypes.c_int32)
         self.lib.harness_run_chain.restype = ctypes.c_int
         self.lib.harness_run_chain.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
-                                               ctypes.c_int32, dp, dp, ip, ip]
+                                               ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC)]
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
 
-    def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True):
+    def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True, affine=None):
         dp = ctypes.POINTER(ctypes.c_double)
         ip = ctypes.POINTER(ctypes.c_int32)
         pose = np.ascontiguousarray(pose, dtype=np.float64)
@@ -83,10 +87,18 @@ class HostHarness:
             lp.bounds[i][1] = bounds[i][1]
         for i in range(27):
             lp.seeds[i] = seeds[i]
+        aff = None
+        if affine is not None:
+            aff = AffineC()
+            for i in range(3):
+                aff.fixed_coxa[i] = affine[0][i]
+                aff.template_coxa[i] = affine[2][i]
+            aff.scale = affine[1]
+            aff = ctypes.byref(aff)
         rc = self.lib.harness_run_chain(pose.ctypes.data_as(dp), n, ctypes.byref(lp), first, last,
                                         ang.ctypes.data_as(dp), fk.ctypes.data_as(dp) if want_fk else None,
                                         st.ctypes.data_as(ip) if diag else None,
-                                        nf.ctypes.data_as(ip) if diag else None)
+                                        nf.ctypes.data_as(ip) if diag else None, aff)
         if rc != 0:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)

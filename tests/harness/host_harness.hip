@@ -9,12 +9,12 @@
 
 extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const SeqikLegParams *leg,
                                  int32_t first_stage, int32_t last_stage, double *angles, double *fk,
-                                 int32_t *status, int32_t *nfev)
+                                 int32_t *status, int32_t *nfev, const SeqikAffine *affine)
 {
     int rc = seqik::validate_leg(*leg, first_stage, last_stage);
     if (rc != SEQIK_OK) return rc;
     seqik::LegConst lc;
-    seqik::make_leg_consts(*leg, lc);
+    seqik::make_leg_consts(*leg, affine, lc);
     seqik::ChainIO io;
     io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
     io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;

@@ -1,0 +1,78 @@
+"""Alignment row: host AlignPose vs the reference's (fixture df3d_1000.npz holds the
+un-aligned key points and the output of the reference's AlignPose.align_pose), and the fused
+kernel prologue vs aligning first (bit for bit)."""
+import numpy as np
+import pytest
+
+from conftest import leg_arrays, load_golden
+
+from seqikpy_amd import data
+from seqikpy_amd.alignment import AlignPose
+
+
+@pytest.fixture(scope="module")
+def df3d():
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    raw = {f"{l}_leg": z[f"{l}_raw"] for l in legs}
+    return z, legs, raw
+
+
+def test_host_alignment_reproduces_the_reference_bit_for_bit(df3d):
+    z, legs, raw = df3d
+    al = AlignPose(raw, legs_list=legs, include_claw=False, body_template=data.TEMPLATE_NMF_LOCOMOTION,
+                   log_level="ERROR")
+    aligned = al.align_pose()
+    for leg in legs:
+        assert np.array_equal(aligned[f"{leg}_leg"], z[f"{leg}_pose"]), leg
+        assert aligned[f"{leg}_leg"].shape == (1000, 5, 3)
+    fixed, scale, tc = al.leg_affine(raw["RF_leg"], "RF")
+    assert fixed.shape == (3,) and scale > 0 and np.array_equal(tc, data.TEMPLATE_NMF_LOCOMOTION["RF_Coxa"])
+
+
+def test_include_claw_changes_the_scale(df3d):
+    _, legs, raw = df3d
+    a = AlignPose(raw, legs, include_claw=False, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    b = AlignPose(raw, legs, include_claw=True, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    assert a.leg_affine(raw["LM_leg"], "LM")[1] != b.leg_affine(raw["LM_leg"], "LM")[1]
+
+
+def test_fused_alignment_equals_align_then_solve_on_host(df3d, oracle, host_harness):
+    """Device core (host build) with the affine fused == oracle on the host-aligned key points."""
+    z, legs, raw = df3d
+    al = AlignPose(raw, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    for leg in ("RF", "LH"):
+        _, seg, b, seeds = leg_arrays(z, leg)
+        aff = al.leg_affine(raw[f"{leg}_leg"], leg)
+        fused = host_harness.run(raw[f"{leg}_leg"][:300], seg, b, seeds, affine=aff)
+        ref = oracle.seq_leg(z[f"{leg}_pose"][:300], seg, b, seeds)
+        assert np.array_equal(fused["angles"], ref["angles"])
+        assert np.array_equal(fused["fk"], ref["fk"])
+        assert np.array_equal(fused["nfev"], ref["nfev"])
+
+
+@pytest.mark.gpu
+def test_fused_alignment_on_gpu(df3d, hiplib, oracle):
+    """Config 5 in small: RAW key points + SeqikAffine through the C ABI == align first, then solve."""
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    from seqikpy_amd.utils import calculate_body_size
+    z, legs, raw = df3d
+    al = AlignPose(raw, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    affs = [hiplib.make_affine(*al.leg_affine(raw[f"{l}_leg"], l)) for l in legs]
+    pose_raw = np.stack([raw[f"{l}_leg"] for l in legs])[None]
+    pose_al = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    fused = hiplib.solve_seq(pose_raw, params, want_fk=True, affine=affs)
+    plain = hiplib.solve_seq(pose_al, params, want_fk=True)
+    assert np.array_equal(fused["angles"], plain["angles"])
+    assert np.array_equal(fused["fk"], plain["fk"])
+    ref = oracle.seq_leg(*leg_arrays(z, "RM"))
+    assert np.array_equal(fused["angles"][0, legs.index("RM")], ref["angles"])
+    # Python API: LegInvKinSeq(raw, ..., leg_affine=AlignPose.leg_affines())
+    body = calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    ik = LegInvKinSeq(raw, KinematicChainSeq(data.BOUNDS_LOCOMOTION, legs, body), data.INITIAL_ANGLES_LOCOMOTION,
+                      log_level="ERROR", leg_affine=al.leg_affines())
+    ang, fk = ik.run_ik_and_fk()
+    assert np.array_equal(ang["Angle_RM_FTi_pitch"], ref["angles"][:, 5])
+    assert np.array_equal(fk["RM_leg"], ref["fk"])

@@ -34,6 +34,7 @@ def test_library_exports_every_declared_symbol(hiplib):
 def test_struct_layout_matches_header(hiplib):
     assert ctypes.sizeof(hiplib.SeqikLegParams) == 8 * (4 + 14 + 27)
     assert ctypes.sizeof(hiplib.SeqikOptions) == 32
+    assert ctypes.sizeof(hiplib.SeqikLayout) == 48 and ctypes.sizeof(hiplib.SeqikAffine) == 56
 
 
 def test_validate_legs_error_codes(hiplib):
