@@ -146,6 +146,26 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
                            const SeqikLayout *layout, const SeqikAffine *affine /* nullable [n_legs] */,
                            const SeqikOptions *opt, void *hip_stream);
 
+/*
+ * HeadInverseKinematics.compute_head_angles (seqikpy/head_inverse_kinematics.py:103-140) for n_frames
+ * frames: closed-form head roll / pitch / yaw and, per side, antenna yaw / pitch.
+ *   r_head, l_head  [n_frames][2][3]  aligned antenna base and tip (aligned_pos["R_head"], ["L_head"])
+ *   neck            [3] (neck_stride = 0: the template's fixed neck, the usual case) or
+ *                   [n_frames][3] (neck_stride = 3)
+ *   rest_head_pitch, rest_antenna_pitch   zero-pose angles of the body template
+ *                   (get_rest_head_pitch / get_rest_antenna_pitch, :304-328; computed by the caller)
+ *   compute_ant     0: only the three head angles
+ *   angles          [7][n_frames] (or [3][n_frames]): rows in the reference's dict order -- head roll,
+ *                   head pitch, head yaw, antenna yaw L, antenna pitch L, antenna yaw R, antenna pitch R
+ * The _device variant takes device pointers, enqueues on `hip_stream` and does not synchronise.
+ */
+int seqik_head_angles(const double *r_head, const double *l_head, int64_t n_frames, const double *neck,
+                      int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch, int32_t compute_ant,
+                      double *angles, const SeqikOptions *opt);
+int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int64_t n_frames, const double *d_neck,
+                             int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch,
+                             int32_t compute_ant, double *d_angles, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

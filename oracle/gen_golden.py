@@ -21,6 +21,7 @@ Fixtures (all float64 unless noted; DOF order = c_oracle.DOFS):
   df3d_1000.npz         full 1000-frame df3d recording aligned here with the
                         reference's AlignPose + reference run here
   generic_rf_100.npz    LegInvKinGeneric on anipose RF frames 0:100, run here
+  anipose_head.npz      aligned head key points, shipped head_joint_angles.pkl, HeadInverseKinematics run here
 """
 import argparse
 import importlib.util
@@ -178,12 +179,33 @@ def gen_generic_rf_100():
     return run_reference("generic", poses, BOUNDS, body, INITIAL_ANGLES)
 
 
+def gen_anipose_head():
+    """Head / antenna row: aligned R_head, L_head, Neck of the shipped anipose recording,
+    the shipped head_joint_angles.pkl and the reference's HeadInverseKinematics re-run here."""
+    import_reference()
+    from seqikpy.data import NMF_TEMPLATE
+    from seqikpy.head_inverse_kinematics import HeadInverseKinematics
+    pose = load_pickle(os.path.join(ANIPOSE, "pose3d_aligned.pkl"))
+    gold = load_pickle(os.path.join(ANIPOSE, "head_joint_angles.pkl"))
+    names = ["Angle_head_roll", "Angle_head_pitch", "Angle_head_yaw", "Angle_antenna_yaw_L",
+             "Angle_antenna_pitch_L", "Angle_antenna_yaw_R", "Angle_antenna_pitch_R"]
+    hk = HeadInverseKinematics(aligned_pos=pose, body_template=NMF_TEMPLATE, log_level="ERROR")
+    live = hk.compute_head_angles()
+    return {"R_head": pose["R_head"], "L_head": pose["L_head"], "Neck": pose["Neck"],
+            "names": np.array(names),
+            "shipped": np.stack([gold[n] for n in names], axis=1),
+            "ref_run": np.stack([live[n] for n in names], axis=1),
+            "rest_head_pitch": np.asarray(hk.rest_head_pitch, dtype=np.float64).reshape(-1)[:1],
+            "rest_antenna_pitch": np.asarray(hk.rest_antenna_pitch, dtype=np.float64).reshape(-1)[:1]}
+
+
 GENERATORS = {
     "anipose_shipped": gen_anipose_shipped,
     "anipose_scipy_cut": gen_anipose_scipy_cut,
     "df3d_100": gen_df3d_100,
     "df3d_1000": gen_df3d_1000,
     "generic_rf_100": gen_generic_rf_100,
+    "anipose_head": gen_anipose_head,
 }
 
 

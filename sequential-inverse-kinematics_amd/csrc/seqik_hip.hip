@@ -195,6 +195,9 @@ int seqik_device_count(void)
 
 const char *seqik_last_error(void) { return g_err; }
 
+// used by the other translation units of the library (seqik_head.hip)
+void seqik_set_error(int code, const char *msg) { (void)fail(code, "%s", msg); }
+
 int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage)
 {
     if (!legs || n_legs <= 0) return fail(SEQIK_ERR_BAD_ARG, "null legs%s");

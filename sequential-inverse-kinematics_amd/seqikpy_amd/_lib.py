@@ -16,7 +16,8 @@ from .data import DOFS, SEGMENTS
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
-SOURCES = ["seqik_hip.hip", "seqik_core.hpp", "seqik_consts.hpp"]
+SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_core.hpp", "seqik_consts.hpp", "seqik_head.hpp"]
+COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 SEQIK_OK = 0
@@ -88,7 +89,7 @@ def is_stale() -> bool:
 def build(force: bool = False) -> str:
     """Compiles ``csrc/seqik_hip.hip`` -> ``csrc/libseqik_hip.so`` (gfx950)."""
     if force or is_stale():
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH, os.path.join(CSRC, "seqik_hip.hip")]
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, u) for u in COMPILE_UNITS]
         subprocess.check_call(cmd, cwd=CSRC)
     return LIB_PATH
 
@@ -130,12 +131,42 @@ def load():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+        L.seqik_head_angles.restype = ctypes.c_int
+        L.seqik_head_angles.argtypes = [_dp, _dp, ctypes.c_int64, _dp, ctypes.c_int64, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_int32, _dp, ctypes.POINTER(SeqikOptions)]
+        L.seqik_head_angles_device.restype = ctypes.c_int
+        L.seqik_head_angles_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
+                                               ctypes.c_void_p, ctypes.c_void_p]
         _lib = L
         return _lib
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_validate_legs",
-                    "seqik_solve_seq", "seqik_solve_seq_device"]
+                    "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device"]
+
+
+def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=0):
+    """``seqik_head_angles`` on host arrays: (N, 2, 3), (N, 2, 3), neck (3,) or (N, 3) -> (7 or 3, N)."""
+    r_head = np.ascontiguousarray(r_head, dtype=np.float64)
+    l_head = np.ascontiguousarray(l_head, dtype=np.float64)
+    n = r_head.shape[0]
+    if r_head.shape != (n, 2, 3) or l_head.shape != (n, 2, 3):
+        raise ValueError("R_head / L_head must have shape (N, 2, 3)")
+    neck = np.ascontiguousarray(neck, dtype=np.float64).reshape(-1, 3)
+    if neck.shape[0] not in (1, n):
+        raise ValueError("Neck must hold one point or one point per frame")
+    stride = 3 if (neck.shape[0] == n and n > 1) else 0
+    out = np.zeros((7 if compute_ant else 3, n))
+    opt = SeqikOptions()
+    opt.device = device
+    rc = load().seqik_head_angles(r_head.ctypes.data_as(_dp), l_head.ctypes.data_as(_dp), n,
+                                  neck.ctypes.data_as(_dp), stride, float(rest_head_pitch),
+                                  float(rest_antenna_pitch), 1 if compute_ant else 0, out.ctypes.data_as(_dp),
+                                  ctypes.byref(opt))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return out
 
 
 def make_leg_params(leg, bounds_dof, body_size, initial_angles) -> SeqikLegParams:

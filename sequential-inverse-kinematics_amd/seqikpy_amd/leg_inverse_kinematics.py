@@ -99,10 +99,11 @@ class LegInvKinBase(ABC):
         lo = np.array([l.bounds[0] for l in kinematic_chain.links])
         hi = np.array([l.bounds[1] for l in kinematic_chain.links])
         # scipy shifts start entries that sit on a bound inwards by 1e-10 * max(1, |bound|)
-        near_lo = np.isfinite(lo) & (res - lo <= np.minimum(hi - res, 1e-10 * np.maximum(1, np.abs(lo))))
-        near_hi = np.isfinite(hi) & (hi - res <= np.minimum(res - lo, 1e-10 * np.maximum(1, np.abs(hi))))
-        res[near_lo] = (lo + 1e-10 * np.maximum(1, np.abs(lo)))[near_lo]
-        res[near_hi] = (hi - 1e-10 * np.maximum(1, np.abs(hi)))[near_hi]
+        with np.errstate(invalid="ignore"):  # the base link is unbounded (-inf, inf)
+            near_lo = np.isfinite(lo) & (res - lo <= np.minimum(hi - res, 1e-10 * np.maximum(1, np.abs(lo))))
+            near_hi = np.isfinite(hi) & (hi - res <= np.minimum(res - lo, 1e-10 * np.maximum(1, np.abs(hi))))
+            res[near_lo] = (lo + 1e-10 * np.maximum(1, np.abs(lo)))[near_lo]
+            res[near_hi] = (hi - 1e-10 * np.maximum(1, np.abs(hi)))[near_hi]
         names = [l.name for l in kinematic_chain.links]
         for dof in STAGE_DOFS[stage]:
             res[names.index(f"{leg}_{dof}")] = out["angles"][0, 0, 0, DOFS.index(dof)]

@@ -69,6 +69,8 @@ class HostHarness:
         self.lib.harness_run_chain.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
                                                ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC)]
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
+        self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
+                                                 ctypes.c_double, ctypes.c_int32, dp]
 
     def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True, affine=None):
         dp = ctypes.POINTER(ctypes.c_double)
@@ -103,6 +105,18 @@ class HostHarness:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
 
+    def head_angles(self, r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True):
+        dp = ctypes.POINTER(ctypes.c_double)
+        r_head = np.ascontiguousarray(r_head, dtype=np.float64)
+        l_head = np.ascontiguousarray(l_head, dtype=np.float64)
+        neck = np.ascontiguousarray(neck, dtype=np.float64).reshape(-1, 3)
+        n = r_head.shape[0]
+        out = np.zeros((7, n))
+        self.lib.harness_head_angles(r_head.ctypes.data_as(dp), l_head.ctypes.data_as(dp), n, neck.ctypes.data_as(dp),
+                                     3 if neck.shape[0] == n and n > 1 else 0, rest_head_pitch, rest_antenna_pitch,
+                                     1 if compute_ant else 0, out.ctypes.data_as(dp))
+        return out
+
     def sincos(self, x):
         s = ctypes.c_double()
         c = ctypes.c_double()
@@ -119,7 +133,8 @@ def host_harness():
     out_dir = os.path.join(ROOT, "tests", "harness", "_build")
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhost_harness.so")
-    deps = [src] + [os.path.join(PKG_PARENT, "csrc", f) for f in ("seqik_core.hpp", "seqik_consts.hpp")]
+    deps = [src] + [os.path.join(PKG_PARENT, "csrc", f) for f in ("seqik_core.hpp", "seqik_consts.hpp",
+                                                                 "seqik_head.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call([hipcc, "--offload-host-only", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC",
                                "-shared", "-o", so, src])

@@ -6,6 +6,7 @@
 // without a GPU.  Built by tests/conftest.py with `hipcc --offload-host-only`.
 #include "../../sequential-inverse-kinematics_amd/csrc/seqik_core.hpp"
 #include "../../sequential-inverse-kinematics_amd/csrc/seqik_consts.hpp"
+#include "../../sequential-inverse-kinematics_amd/csrc/seqik_head.hpp"
 
 extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const SeqikLegParams *leg,
                                  int32_t first_stage, int32_t last_stage, double *angles, double *fk,
@@ -38,3 +39,15 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
 }
 
 extern "C" void harness_sincos(double x, double *s, double *c) { seqik::sincos_cw(x, *s, *c); }
+
+// head / antenna angles: the kernel's per-frame device function, run on the host
+extern "C" void harness_head_angles(const double *r_head, const double *l_head, int64_t n, const double *neck,
+                                    int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch,
+                                    int32_t compute_ant, double *angles)
+{
+    seqik::HeadArgs a;
+    a.r_head = r_head; a.l_head = l_head; a.neck = neck; a.neck_stride = neck_stride;
+    a.rest_head_pitch = rest_head_pitch; a.rest_antenna_pitch = rest_antenna_pitch;
+    a.angles = angles; a.n_frames = n; a.compute_ant = compute_ant;
+    for (int64_t t = 0; t < n; ++t) seqik::head_angles_frame(a, t);
+}
