@@ -125,12 +125,16 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
  *   status, nfev  nullable int32 [n_seq][n_legs][n_frames][4]: scipy termination status /
  *           trial-evaluation count per (frame, stage); requesting either costs one extra
  *           Jacobian per solve
+ *   init_angles  nullable [n_seq][n_legs][7]: joint angles of the frame that PRECEDES frame 0 of each
+ *           chain; frame 0 is then warm-started from them instead of from the seeds (continuation of a
+ *           recording that is processed in pieces; the inert seed entries still come from `legs`)
  *   affine  nullable [n_legs]: fuse AlignPose.align_leg into the kernels (pose is then RAW)
  * Frame t of a chain is warm-started from frame t-1 of the same chain; frame 0 from the seeds.
  */
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                     const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                     double *angles, double *fk, int32_t *status, int32_t *nfev,
+                    const double *init_angles /* nullable [n_seq][n_legs][7] */,
                     const SeqikAffine *affine /* nullable [n_legs] */, const SeqikOptions *opt);
 
 /*
@@ -143,6 +147,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
+                           const double *d_init_angles /* nullable [n_seq][n_legs][7] */,
                            const SeqikLayout *layout, const SeqikAffine *affine /* nullable [n_legs] */,
                            const SeqikOptions *opt, void *hip_stream);
 

@@ -42,7 +42,7 @@ def lib():
         lp = ctypes.POINTER(ctypes.c_int64)
         L.oracle_seq_leg.restype = ctypes.c_int
         L.oracle_seq_leg.argtypes = [dp, ctypes.c_int64, dp, dp, dp, ctypes.c_int, ctypes.c_int,
-                                     dp, dp, ip, ip, lp, ip]
+                                     dp, dp, ip, ip, lp, ip, dp]
         L.oracle_generic_leg.restype = ctypes.c_int
         L.oracle_generic_leg.argtypes = [dp, ctypes.c_int64, dp, dp, dp, dp, dp, ip, ip, lp]
         L.oracle_stage_solve.restype = ctypes.c_int
@@ -75,7 +75,7 @@ def leg_params(leg, bounds_dof, body_size, initial_angles):
     return seg, bounds, seeds
 
 
-def seq_leg(pose, seg, bounds, seeds, first_stage=1, last_stage=4, prior_angles=None, want_fk=True):
+def seq_leg(pose, seg, bounds, seeds, first_stage=1, last_stage=4, prior_angles=None, want_fk=True, init=None):
     """Runs one leg through the C oracle.  Returns dict(angles[N,7], fk[N,9,3], status[N,4], nfev[N,4])."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     n = pose.shape[0]
@@ -90,7 +90,8 @@ def seq_leg(pose, seg, bounds, seeds, first_stage=1, last_stage=4, prior_angles=
     bounds = np.ascontiguousarray(bounds, dtype=np.float64)
     seeds = np.ascontiguousarray(seeds, dtype=np.float64)
     rc = lib().oracle_seq_leg(_dp(pose), n, _dp(seg), _dp(bounds), _dp(seeds), first_stage, last_stage,
-                              _dp(angles), _dp(fk), _ip(status), _ip(nfev), ctypes.byref(ef), ctypes.byref(es))
+                              _dp(angles), _dp(fk), _ip(status), _ip(nfev), ctypes.byref(ef), ctypes.byref(es),
+                              _dp(np.ascontiguousarray(init, dtype=np.float64)) if init is not None else None)
     if rc != 0:
         raise ValueError(f"{ERRORS.get(rc, rc)} (frame {ef.value}, stage {es.value})")
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)

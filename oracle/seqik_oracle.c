@@ -946,6 +946,8 @@ static const int STAGE_STORE_DOF[5][2] = {{0, 0}, {D_YAW, D_PITCH}, {D_ROLL, D_C
  * seeds     4+6+8+9 doubles, initial_angles["stage_1..4"]
  * angles    [N][7]  in/out: columns of stages < first_stage are read, stages
  *           first_stage..last_stage are written (DOF order above)
+ * init_angles nullable [7]: frame 0 is warm-started from these joint angles (the solution of the frame
+ *           preceding this piece of the recording) instead of from the seeds
  * fk        nullable [N][9][3], written when last_stage == 4
  * status/nfev nullable [N][4]
  * Returns 0, or a negative code; err_frame / err_stage locate the failure.
@@ -953,7 +955,7 @@ static const int STAGE_STORE_DOF[5][2] = {{0, 0}, {D_YAW, D_PITCH}, {D_ROLL, D_C
 int oracle_seq_leg(const double *pose, int64_t N, const double *seg, const double *bounds /*[7][2]*/,
                    const double *seeds, int first_stage, int last_stage,
                    double *angles, double *fk, int32_t *status, int32_t *nfev,
-                   int64_t *err_frame, int32_t *err_stage)
+                   int64_t *err_frame, int32_t *err_stage, const double *init_angles /* nullable [7] */)
 {
     if (first_stage < 1 || last_stage > 4 || first_stage > last_stage) return SEQIK_ERR_BAD_ARG;
     const double (*bnd)[2] = (const double (*)[2])bounds;
@@ -963,6 +965,9 @@ int oracle_seq_leg(const double *pose, int64_t N, const double *seg, const doubl
         int n = STAGE_NLINK[stage];
         double prev[MAXN], sol[MAXN];
         memcpy(prev, seed_ptr[stage], n * sizeof(double));
+        if (init_angles)  /* continuation: frame 0 starts from the angles of the preceding frame */
+            for (int k = 0; k < 2; ++k)
+                if (STAGE_STORE_LINK[stage][k] >= 0) prev[STAGE_STORE_LINK[stage][k]] = init_angles[STAGE_STORE_DOF[stage][k]];
         if (stage == 1) build_seq_chain(&ch, 1, seg, bnd, NULL);
         for (int64_t t = 0; t < N; ++t) {
             const double *kp = pose + t * 15;
@@ -1071,7 +1076,7 @@ int oracle_seq_batch(const double *pose, int64_t n_seq, int32_t n_legs, int64_t 
         for (int32_t l = 0; l < n_legs; ++l) {
             int64_t c = s * n_legs + l;
             int rc = oracle_seq_leg(pose + c * N * 15, N, seg + 4 * l, bounds + 14 * l, seeds + 27 * l, 1, 4,
-                                    angles + c * N * 7, fk ? fk + c * N * 27 : NULL, NULL, NULL, NULL, NULL);
+                                    angles + c * N * 7, fk ? fk + c * N * 27 : NULL, NULL, NULL, NULL, NULL, NULL);
             if (rc != SEQIK_OK) return rc;
         }
     return SEQIK_OK;

@@ -715,6 +715,8 @@ struct ChainIO {
     double *fk;             // nullable [n_frames][9][3]
     int32_t *status;        // nullable [n_frames][4]
     int32_t *nfev;          // nullable [n_frames][4]
+    const double *init;     // nullable [7]: warm start of frame 0 (the joint angles of the frame that
+                            // precedes this chain's first frame) instead of the stage seeds
     int64_t n_frames;
 };
 
@@ -778,6 +780,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 
     // x carries the solution from frame to frame: it is the warm start of the next solve
     double x[2] = {sc.seed[0], (NA == 2) ? sc.seed[1] : 0.0}, f[3] = {0.0, 0.0, 0.0};
+    if (io.init) {
+        x[0] = io.init[DOF0];
+        if constexpr (NA == 2) x[1] = io.init[DOF0 + 1];
+    }
     double cost = 0.0, Delta = 0.0, alpha = 0.0;
     double sa = 0.0, ca = 1.0, sb = 0.0, cb = 1.0;  // sin/cos of the active joints at x
     int nfev = 0, status = STATUS_NONE;

@@ -39,6 +39,7 @@ struct KernelArgs {
     int32_t *status;
     int32_t *nfev;
     const seqik::LegConst *legs;  // device, [n_legs]
+    const double *init;           // nullable [n_chains][7]
     int64_t n_chains;             // n_seq * n_legs
     int64_t n_frames;
     int32_t n_legs;
@@ -78,6 +79,7 @@ seqik_stage_kernel(KernelArgs a)
     io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
     io.status = a.status ? a.status + c * a.n_frames * 4 : nullptr;
     io.nfev = a.nfev ? a.nfev + c * a.n_frames * 4 : nullptr;
+    io.init = a.init ? a.init + c * 7 : nullptr;
     io.n_frames = a.n_frames;
     seqik::run_stage<STAGE, WANT_FK, WANT_DIAG>(s_legs[leg], io);
 }
@@ -139,10 +141,11 @@ int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegPa
 
 int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
            const seqik::LegConst *d_legs, int32_t first_stage, int32_t last_stage, double *d_angles,
-           double *d_fk, int32_t *d_status, int32_t *d_nfev, const SeqikLayout *layout, const SeqikOptions *opt,
-           hipStream_t stream)
+           double *d_fk, int32_t *d_status, int32_t *d_nfev, const double *d_init, const SeqikLayout *layout,
+           const SeqikOptions *opt, hipStream_t stream)
 {
     KernelArgs a;
+    a.init = d_init;
     if (layout) {
         if (layout->pose_chain < 0 || layout->pose_row <= 0 || layout->pose_frame <= 0 || layout->ang_chain < 0 ||
             layout->ang_dof <= 0 || layout->ang_frame <= 0)
@@ -216,8 +219,8 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,
-                           const SeqikLayout *layout, const SeqikAffine *affine, const SeqikOptions *opt,
-                           void *hip_stream)
+                           const double *d_init_angles, const SeqikLayout *layout, const SeqikAffine *affine,
+                           const SeqikOptions *opt, void *hip_stream)
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
     if (rc != SEQIK_OK) return rc;
@@ -226,13 +229,13 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     rc = device_leg_table(legs, affine, n_legs, &d_legs);
     if (rc != SEQIK_OK) return rc;
     return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
-                  d_status, d_nfev, layout, opt, stream);
+                  d_status, d_nfev, d_init_angles, layout, opt, stream);
 }
 
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                     const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
-                    double *angles, double *fk, int32_t *status, int32_t *nfev, const SeqikAffine *affine,
-                    const SeqikOptions *opt)
+                    double *angles, double *fk, int32_t *status, int32_t *nfev, const double *init_angles,
+                    const SeqikAffine *affine, const SeqikOptions *opt)
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, pose, angles);
     if (rc != SEQIK_OK) return rc;
@@ -241,7 +244,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     if (opt) HIP_TRY(hipSetDevice(opt->device));
     hipStream_t stream;
     HIP_TRY(hipStreamCreate(&stream));
-    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr;
+    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr, *d_init = nullptr;
     int32_t *d_status = nullptr, *d_nfev = nullptr;
     const bool want_fk = fk && last_stage == 4;
     int out = SEQIK_OK;
@@ -256,13 +259,18 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
         if (want_fk) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_fk), sizeof(double) * 27 * n_lf));
         if (status) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_status), sizeof(int32_t) * 4 * n_lf));
         if (nfev) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_nfev), sizeof(int32_t) * 4 * n_lf));
+        if (init_angles) {
+            const size_t ib = sizeof(double) * 7 * n_seq * n_legs;
+            TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_init), ib));
+            TRY_BREAK(hipMemcpyAsync(d_init, init_angles, ib, hipMemcpyHostToDevice, stream));
+        }
         TRY_BREAK(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
         // angles is in/out: earlier-stage columns are inputs when first_stage > 1
         TRY_BREAK(hipMemcpyAsync(d_angles, angles, sizeof(double) * 7 * n_lf, hipMemcpyHostToDevice, stream));
         if (d_status) TRY_BREAK(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
         if (d_nfev) TRY_BREAK(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
         out = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
-                                     d_fk, d_status, d_nfev, nullptr, affine, opt, stream);
+                                     d_fk, d_status, d_nfev, d_init, nullptr, affine, opt, stream);
         if (out != SEQIK_OK) break;
         TRY_BREAK(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
         if (want_fk) TRY_BREAK(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
@@ -271,7 +279,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
         TRY_BREAK(hipStreamSynchronize(stream));
 #undef TRY_BREAK
     } while (0);
-    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev);
+    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev); (void)hipFree(d_init);
     (void)hipStreamDestroy(stream);
     return out;
 }

@@ -123,13 +123,13 @@ def load():
         L.seqik_solve_seq.restype = ctypes.c_int
         L.seqik_solve_seq.argtypes = [_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                       ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
-                                      _dp, _dp, _ip, _ip, ctypes.POINTER(SeqikAffine),
+                                      _dp, _dp, _ip, _ip, _dp, ctypes.POINTER(SeqikAffine),
                                       ctypes.POINTER(SeqikOptions)]
         L.seqik_solve_seq_device.restype = ctypes.c_int
         L.seqik_solve_seq_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
+                                             ctypes.c_void_p, ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
         L.seqik_head_angles.restype = ctypes.c_int
         L.seqik_head_angles.argtypes = [_dp, _dp, ctypes.c_int64, _dp, ctypes.c_int64, ctypes.c_double,
@@ -224,7 +224,7 @@ def _affine_array(affine, n_legs):
 
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
-              device=0, block_size=0, affine=None):
+              device=0, block_size=0, affine=None, init_angles=None):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
@@ -251,12 +251,17 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt = SeqikOptions()
     opt.device = device
     opt.block_size = block_size
+    if init_angles is not None:
+        init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
+        if init_angles.shape != (S, L, 7):
+            raise ValueError(f"init_angles must have shape {(S, L, 7)}")
     lib = load()
     rc = lib.seqik_solve_seq(pose.ctypes.data_as(_dp), S, L, N, arr, first_stage, last_stage,
                              angles.ctypes.data_as(_dp),
                              fk.ctypes.data_as(_dp) if fk is not None else None,
                              status.ctypes.data_as(_ip) if status is not None else None,
                              nfev.ctypes.data_as(_ip) if nfev is not None else None,
+                             init_angles.ctypes.data_as(_dp) if init_angles is not None else None,
                              _affine_array(affine, L), ctypes.byref(opt))
     if rc != SEQIK_OK:
         _raise(rc)
@@ -264,7 +269,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
-                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None):
+                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout."""
     arr = (SeqikLegParams * n_legs)(*legs)
@@ -273,6 +278,7 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     rc = load().seqik_solve_seq_device(ctypes.c_void_p(d_pose), n_seq, n_legs, n_frames, arr, first_stage,
                                        last_stage, ctypes.c_void_p(d_angles), ctypes.c_void_p(d_fk or None),
                                        ctypes.c_void_p(d_status or None), ctypes.c_void_p(d_nfev or None),
+                                       ctypes.c_void_p(d_init or None),
                                        ctypes.byref(layout) if layout is not None else None,
                                        _affine_array(affine, n_legs),
                                        ctypes.byref(opt), ctypes.c_void_p(stream or None))

@@ -67,12 +67,12 @@ class HostHarness:
         ip = ctypes.POINTER(ctypes.c_int32)
         self.lib.harness_run_chain.restype = ctypes.c_int
         self.lib.harness_run_chain.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
-                                               ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC)]
+                                               ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC), dp]
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
         self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_double, ctypes.c_int32, dp]
 
-    def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True, affine=None):
+    def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True, affine=None, init=None):
         dp = ctypes.POINTER(ctypes.c_double)
         ip = ctypes.POINTER(ctypes.c_int32)
         pose = np.ascontiguousarray(pose, dtype=np.float64)
@@ -100,7 +100,8 @@ class HostHarness:
         rc = self.lib.harness_run_chain(pose.ctypes.data_as(dp), n, ctypes.byref(lp), first, last,
                                         ang.ctypes.data_as(dp), fk.ctypes.data_as(dp) if want_fk else None,
                                         st.ctypes.data_as(ip) if diag else None,
-                                        nf.ctypes.data_as(ip) if diag else None, aff)
+                                        nf.ctypes.data_as(ip) if diag else None, aff,
+                                        np.ascontiguousarray(init, dtype=np.float64).ctypes.data_as(dp) if init is not None else None)
         if rc != 0:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)

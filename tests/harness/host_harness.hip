@@ -10,7 +10,7 @@
 
 extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const SeqikLegParams *leg,
                                  int32_t first_stage, int32_t last_stage, double *angles, double *fk,
-                                 int32_t *status, int32_t *nfev, const SeqikAffine *affine)
+                                 int32_t *status, int32_t *nfev, const SeqikAffine *affine, const double *init)
 {
     int rc = seqik::validate_leg(*leg, first_stage, last_stage);
     if (rc != SEQIK_OK) return rc;
@@ -21,6 +21,7 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
     io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
     io.fk = (fk && last_stage == 4) ? fk : nullptr;
     io.status = status; io.nfev = nfev;
+    io.init = init;
     io.n_frames = n_frames;
     const bool want_fk = io.fk != nullptr;
     const bool diag = status || nfev;

@@ -86,3 +86,18 @@ def test_core_rejects_bad_parameters(host_harness):
     bb[6] = (0.0, 0.0)
     with pytest.raises(ValueError):
         host_harness.run(pose[:2], seg, bb, seeds)
+
+
+def test_continuation_with_init_angles(oracle, host_harness):
+    """A recording solved in two pieces, the second started from the last angles of the first, equals the
+    one-piece run bit for bit (oracle and device core)."""
+    z = load_golden("df3d_1000")
+    pose, seg, b, seeds = leg_arrays(z, "LF")
+    full = oracle.seq_leg(pose[:200], seg, b, seeds)
+    cut = 83
+    for run in (lambda p, init: oracle.seq_leg(p, seg, b, seeds, init=init),
+                lambda p, init: host_harness.run(p, seg, b, seeds, init=init)):
+        a = run(pose[:cut], None)
+        c = run(pose[cut:200], a["angles"][-1])
+        assert np.array_equal(np.concatenate([a["angles"], c["angles"]]), full["angles"])
+        assert np.array_equal(np.concatenate([a["fk"], c["fk"]]), full["fk"])
