@@ -35,9 +35,9 @@ from seqikpy_amd import _lib, data, sharding, synthetic, utils  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # Algorithmic HBM bytes per leg-frame (DESIGN.md "Kernels"):
 BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
-BYTES_STAGE = {1: 48 + 16, 2: 48 + 16 + 16, 3: 48 + 32 + 16, 4: 48 + 48 + 8 + 216}
-# stage k reads the origin + its key point (48 B) and the angles of the earlier stages, writes its own
-# angles; stage 4 also writes the 9 x 3 FK record (216 B)
+BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 + 24, 4: 48 + 96 + 8 + 144}
+# stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
+# the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
 
 
 def parse():
@@ -126,6 +126,9 @@ def main():
     gather = sharding.GatherPipeline(dist, world, rank, d_ang[0], n_buffers=n_buf) if world > 1 else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
+        for e in row:
+            e.record(main_stream)
 
     def step(i, events=None):
         b = i % n_buf
@@ -134,14 +137,11 @@ def main():
         with torch.cuda.stream(stream):
             if gather:
                 gather.wait_buffer(b)  # the gather that last read this buffer has completed
-            for stage in (1, 2, 3, 4):
-                if events:
-                    events[stage - 1].record(stream)
-                _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
-                                      d_fks[i % len(streams)].data_ptr(), first_stage=stage, last_stage=stage,
-                                      stream=stream.cuda_stream, block_size=args.block, layout=layout)
-            if events:
-                events[4].record(stream)
+            # ONE C-ABI call = the four stage kernels; the library records the given HIP events between them
+            _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
+                                  d_fks[i % len(streams)].data_ptr(), stream=stream.cuda_stream,
+                                  block_size=args.block, layout=layout,
+                                  stage_events=[e.cuda_event for e in events] if events else None)
             if gather:
                 gather.submit(b, buf)
 

@@ -1,0 +1,53 @@
+"""End-to-end pipeline on MI355X: align -> head / antenna angles -> sequential leg IK -> one pickle.
+
+Counterpart of the reference's examples/example_entire_pipeline.py (which notes "takes about 40 minutes"
+for the shipped 6000-frame recording).  Input: a pickled anipose pose (pose3d.h5) or an already
+converted segment dictionary (converted_dict.pkl) under --path.
+
+    python examples/entire_pipeline.py -p <dir with pose3d.* or converted_dict.pkl> [--frame-parallel]
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+from pathlib import Path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+
+from seqikpy_amd.alignment import AlignPose, convert_from_anipose_to_dict  # noqa: E402
+from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE, PTS2ALIGN  # noqa: E402
+from seqikpy_amd.head_inverse_kinematics import HeadInverseKinematics  # noqa: E402
+from seqikpy_amd.kinematic_chain import KinematicChainSeq  # noqa: E402
+from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq  # noqa: E402
+from seqikpy_amd.utils import save_file  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-p", "--path", required=True)
+    ap.add_argument("--frame-parallel", action="store_true", help="verified chunked mode (low latency)")
+    args = ap.parse_args()
+    data_path = Path(args.path)
+    t0 = time.time()
+    if list(data_path.rglob("converted_dict.pkl")):
+        align = AlignPose.from_file_path(data_path, file_name="converted_dict.pkl", legs_list=["RF", "LF"],
+                                         include_claw=False, body_template=NMF_TEMPLATE, log_level="INFO")
+    else:
+        align = AlignPose.from_file_path(data_path, file_name="pose3d.*", legs_list=["RF", "LF"],
+                                         convert_func=convert_from_anipose_to_dict, pts2align=PTS2ALIGN,
+                                         include_claw=False, body_template=NMF_TEMPLATE, log_level="INFO")
+    aligned_pos = align.align_pose(export_path=data_path)
+    head = HeadInverseKinematics(aligned_pos=aligned_pos, body_template=NMF_TEMPLATE, log_level="INFO")
+    head_angles = head.compute_head_angles(export_path=data_path)
+    seq_ik = LegInvKinSeq(aligned_pos=aligned_pos,
+                          kinematic_chain_class=KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None),
+                          initial_angles=INITIAL_ANGLES, log_level="INFO")
+    leg_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=data_path, frame_parallel=args.frame_parallel)
+    save_file(data_path / "body_joint_angles.pkl", {**head_angles, **leg_angles})
+    print(f"Total time taken to execute the code: {time.time() - t0:.2f} s")
+
+
+if __name__ == "__main__":
+    main()

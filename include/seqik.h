@@ -70,9 +70,12 @@ typedef struct SeqikLegParams {
 } SeqikLegParams;
 
 typedef struct SeqikOptions {
-    int32_t device;      /* HIP device ordinal (host-buffer entry point only) */
-    int32_t block_size;  /* threads per workgroup, multiple of 64; 0 = default (64) */
-    int32_t reserved[6];
+    int32_t device;       /* HIP device ordinal (host-buffer entry point only) */
+    int32_t block_size;   /* threads per workgroup, multiple of 64; 0 = default (64) */
+    void **stage_events;  /* nullable: 5 hipEvent_t handles, recorded on the launch stream in front of the
+                             stage-1..4 kernels ([0]..[3], only for stages that run) and behind the last one
+                             ([4]) -- lets a caller time the individual kernels of one call */
+    int32_t reserved[4];
 } SeqikOptions;
 
 /* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.

@@ -21,6 +21,7 @@ Fixtures (all float64 unless noted; DOF order = c_oracle.DOFS):
   df3d_1000.npz         full 1000-frame df3d recording aligned here with the
                         reference's AlignPose + reference run here
   generic_rf_100.npz    LegInvKinGeneric on anipose RF frames 0:100, run here
+  anipose_raw_cut.npz   converted_dict.pkl[:1500] (un-aligned legs, antennae, thorax) + reference AlignPose output
   anipose_head.npz      aligned head key points, shipped head_joint_angles.pkl, HeadInverseKinematics run here
 """
 import argparse
@@ -199,6 +200,23 @@ def gen_anipose_head():
             "rest_antenna_pitch": np.asarray(hk.rest_antenna_pitch, dtype=np.float64).reshape(-1)[:1]}
 
 
+def gen_anipose_raw_cut():
+    """Alignment row incl. antennae: first 1500 frames of the shipped converted_dict.pkl (un-aligned
+    segments) and the reference's AlignPose.align_pose output on exactly that cut."""
+    import_reference()
+    from seqikpy.alignment import AlignPose
+    from seqikpy.data import NMF_TEMPLATE
+    raw = load_pickle(os.path.join(ANIPOSE, "converted_dict.pkl"))
+    cut = {k: np.ascontiguousarray(v[:1500]) for k, v in raw.items()}
+    al = AlignPose(pose_data_dict=cut, legs_list=["RF", "LF"], include_claw=False, body_template=NMF_TEMPLATE,
+                   log_level="ERROR")
+    aligned = al.align_pose()
+    out = {f"raw_{k}": v for k, v in cut.items()}
+    out.update({f"aligned_{k}": np.asarray(v) for k, v in aligned.items()})
+    out["segments"] = np.array(list(cut.keys()))
+    return out
+
+
 GENERATORS = {
     "anipose_shipped": gen_anipose_shipped,
     "anipose_scipy_cut": gen_anipose_scipy_cut,
@@ -206,6 +224,7 @@ GENERATORS = {
     "df3d_1000": gen_df3d_1000,
     "generic_rf_100": gen_generic_rf_100,
     "anipose_head": gen_anipose_head,
+    "anipose_raw_cut": gen_anipose_raw_cut,
 }
 
 

@@ -717,6 +717,8 @@ struct ChainIO {
     int32_t *nfev;          // nullable [n_frames][4]
     const double *init;     // nullable [7]: warm start of frame 0 (the joint angles of the frame that
                             // precedes this chain's first frame) instead of the stage seeds
+    double *frames;         // workspace [n_frames][12]: the frame after the active links at the solution of
+                            // stage k (rotation 9 + translation 3) = prefix frame of stage k + 1
     int64_t n_frames;
 };
 
@@ -754,16 +756,22 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 }
 
 // Runs stage STAGE over all frames of one chain.
-//   WANT_FK   : (stage 4 only) also write the stage-4 forward kinematics + origin
-//               (leg_inverse_kinematics.py:279-282), all 9 link positions of a frame as one
-//               contiguous 216-byte record: rows 0-3 origin, 4-5 coxa end, 6 femur end (both
-//               fall out of the prefix product), 7 tibia end, 8 claw.
+//   WANT_FK   : also write this stage's rows of the stage-4 forward kinematics + origin
+//               (leg_inverse_kinematics.py:279-282): stage 2 -> rows 4, 5 (coxa end), stage 3 ->
+//               row 6 (femur end), stage 4 -> rows 0-3 (origin), 7 (tibia end), 8 (claw).
+//   FROM_ANGLES : the prefix frame is rebuilt from the stored angles of the earlier stages
+//               (first stage of a run that starts after stage 1); otherwise it is read from the
+//               workspace where the previous stage's kernel left it.  With WANT_FK such a
+//               first stage also writes the FK rows of the stages that are not run.
+//   HANDOFF   : leave the frame after the active links in the workspace for the next stage.
 //   WANT_DIAG : also produce scipy's status / nfev (one extra Jacobian per solve: scipy
 //               re-evaluates it after the last accepted step and may overwrite the status
 //               with 1 = gtol).
-template <int STAGE, bool WANT_FK, bool WANT_DIAG>
+template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
+    static_assert(STAGE > 1 || !FROM_ANGLES, "stage 1 has no prefix");
+    static_assert(STAGE < 4 || !HANDOFF, "stage 4 is the last one");
     using T = StageTraits<STAGE>;
     constexpr int NA = T::NA;
     constexpr int DOF0 = 2 * (STAGE - 1);  // angle columns written: DOF0 (and DOF0 + 1)
@@ -795,8 +803,17 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         if (new_solve) {
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + STAGE * io.pose_row;
-            if constexpr (STAGE > 1)
-                build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, (WANT_FK && STAGE == 4) ? coxa_end : nullptr);
+            if constexpr (STAGE > 1) {
+                if constexpr (FROM_ANGLES) {
+                    build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, WANT_FK ? coxa_end : nullptr);
+                } else {
+                    const double *w = io.frames + t * 12;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) P.pre.r[i] = w[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) P.pre.t[i] = w[9 + i];
+                }
+            }
             if (lc.aff.enabled) {
                 // fused AlignPose.align_leg, then target = aligned key point - aligned origin
                 // (three separately rounded operations, as numpy evaluates them)
@@ -935,19 +952,39 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if (io.status) io.status[t * 4 + STAGE - 1] = (status == STATUS_NONE) ? 0 : status;
                 if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
             }
-            if constexpr (WANT_FK && STAGE == 4) {
-                const double *origin = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
-                double *fk = io.fk + t * 27;
-                Frame after;  // frame after the TiTa link at the solution
+            if constexpr ((WANT_FK && STAGE >= 2) || HANDOFF) {
+                Frame after;  // frame after the active links at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
-                for (int i = 0; i < 4; ++i)
-                    for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
-                for (int a = 0; a < 3; ++a) {
-                    fk[12 + a] = coxa_end[a] + origin[a];
-                    fk[15 + a] = coxa_end[a] + origin[a];
-                    fk[18 + a] = P.pre.t[a] + origin[a];
-                    fk[21 + a] = after.t[a] + origin[a];
-                    fk[24 + a] = (after.r[3 * a + 2] * P.tz_last + after.t[a]) + origin[a];
+                if constexpr (HANDOFF) {
+                    double *w = io.frames + t * 12;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) w[i] = after.r[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) w[9 + i] = after.t[i];
+                }
+                if constexpr (WANT_FK && STAGE >= 2) {
+                    const double *origin = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
+                    double *fk = io.fk + t * 27;
+                    if constexpr (STAGE == 2) {
+                        for (int a = 0; a < 3; ++a) { fk[12 + a] = after.t[a] + origin[a]; fk[15 + a] = after.t[a] + origin[a]; }
+                    } else if constexpr (STAGE == 3) {
+                        if constexpr (FROM_ANGLES)  // stage 2 was not run: its rows (coxa end) come from the prefix
+                            for (int a = 0; a < 3; ++a) { fk[12 + a] = P.pre.t[a] + origin[a]; fk[15 + a] = P.pre.t[a] + origin[a]; }
+                        for (int a = 0; a < 3; ++a) fk[18 + a] = after.t[a] + origin[a];
+                    } else {
+                        if constexpr (FROM_ANGLES)
+                            for (int a = 0; a < 3; ++a) {
+                                fk[12 + a] = coxa_end[a] + origin[a];
+                                fk[15 + a] = coxa_end[a] + origin[a];
+                                fk[18 + a] = P.pre.t[a] + origin[a];
+                            }
+                        for (int i = 0; i < 4; ++i)
+                            for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
+                        for (int a = 0; a < 3; ++a) {
+                            fk[21 + a] = after.t[a] + origin[a];
+                            fk[24 + a] = (after.r[3 * a + 2] * P.tz_last + after.t[a]) + origin[a];
+                        }
+                    }
                 }
             }
             t += 1;

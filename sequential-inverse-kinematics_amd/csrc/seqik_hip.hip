@@ -40,6 +40,7 @@ struct KernelArgs {
     int32_t *nfev;
     const seqik::LegConst *legs;  // device, [n_legs]
     const double *init;           // nullable [n_chains][7]
+    double *frames;               // workspace [n_chains][n_frames][12] (stage hand-off), may be null
     int64_t n_chains;             // n_seq * n_legs
     int64_t n_frames;
     int32_t n_legs;
@@ -53,7 +54,7 @@ struct KernelArgs {
 // the only shared data is the read-only per-leg constant table, staged once into LDS.
 // Chains of a wave are consecutive (sequence, leg) pairs, so a 64-lane wave owns
 // 64 * n_frames * 120 B of contiguous key points.
-template <int STAGE, bool WANT_FK, bool WANT_DIAG>
+template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
 seqik_stage_kernel(KernelArgs a)
 {
@@ -80,19 +81,39 @@ seqik_stage_kernel(KernelArgs a)
     io.status = a.status ? a.status + c * a.n_frames * 4 : nullptr;
     io.nfev = a.nfev ? a.nfev + c * a.n_frames * 4 : nullptr;
     io.init = a.init ? a.init + c * 7 : nullptr;
+    io.frames = a.frames ? a.frames + c * a.n_frames * 12 : nullptr;
     io.n_frames = a.n_frames;
-    seqik::run_stage<STAGE, WANT_FK, WANT_DIAG>(s_legs[leg], io);
+    seqik::run_stage<STAGE, WANT_FK, WANT_DIAG, FROM_ANGLES, HANDOFF>(s_legs[leg], io);
+}
+
+// from_angles: first stage of a run that starts after stage 1; handoff: a later stage follows
+template <int STAGE, bool FROM_ANGLES, bool HANDOFF>
+void launch_stage2(const KernelArgs &a, bool fk, bool diag, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if constexpr (STAGE >= 2) {
+        if (fk && diag) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, true, FROM_ANGLES, HANDOFF>), grid, block, 0, stream, a); return; }
+        if (fk) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, false, FROM_ANGLES, HANDOFF>), grid, block, 0, stream, a); return; }
+    }
+    if (diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, true, FROM_ANGLES, HANDOFF>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, false, FROM_ANGLES, HANDOFF>), grid, block, 0, stream, a);
 }
 
 template <int STAGE>
-void launch_stage(const KernelArgs &a, bool fk, bool diag, dim3 grid, dim3 block, hipStream_t stream)
+void launch_stage(const KernelArgs &a, bool fk, bool diag, bool from_angles, bool handoff, dim3 grid, dim3 block,
+                  hipStream_t stream)
 {
-    if constexpr (STAGE == 4) {
-        if (fk && diag) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, true>), grid, block, 0, stream, a); return; }
-        if (fk) { hipLaunchKernelGGL((seqik_stage_kernel<STAGE, true, false>), grid, block, 0, stream, a); return; }
+    if constexpr (STAGE == 1) {
+        if (handoff) launch_stage2<1, false, true>(a, fk, diag, grid, block, stream);
+        else launch_stage2<1, false, false>(a, fk, diag, grid, block, stream);
+    } else if constexpr (STAGE == 4) {
+        if (from_angles) launch_stage2<4, true, false>(a, fk, diag, grid, block, stream);
+        else launch_stage2<4, false, false>(a, fk, diag, grid, block, stream);
+    } else {
+        if (from_angles && handoff) launch_stage2<STAGE, true, true>(a, fk, diag, grid, block, stream);
+        else if (from_angles) launch_stage2<STAGE, true, false>(a, fk, diag, grid, block, stream);
+        else if (handoff) launch_stage2<STAGE, false, true>(a, fk, diag, grid, block, stream);
+        else launch_stage2<STAGE, false, false>(a, fk, diag, grid, block, stream);
     }
-    if (diag) hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((seqik_stage_kernel<STAGE, false, false>), grid, block, 0, stream, a);
 }
 
 // Device copy of the per-leg constant table.  Callers almost always pass the same legs on
@@ -170,16 +191,24 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     const bool diag = d_status || d_nfev;
     const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
     if (!fk) a.fk = nullptr;
+    // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
+    a.frames = nullptr;
+    if (last_stage > first_stage)
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), sizeof(double) * 12 * a.n_chains * n_frames, stream));
     for (int stage = first_stage; stage <= last_stage; ++stage) {
+        const bool from_angles = (stage == first_stage) && stage > 1;
+        const bool handoff = stage < last_stage;
+        if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[stage - 1]), stream));
         switch (stage) {
-        case 1: launch_stage<1>(a, false, diag, grid, blk, stream); break;
-        case 2: launch_stage<2>(a, false, diag, grid, blk, stream); break;
-        case 3: launch_stage<3>(a, false, diag, grid, blk, stream); break;
-        default: launch_stage<4>(a, fk, diag, grid, blk, stream); break;
+        case 1: launch_stage<1>(a, false, diag, from_angles, handoff, grid, blk, stream); break;
+        case 2: launch_stage<2>(a, fk, diag, from_angles, handoff, grid, blk, stream); break;
+        case 3: launch_stage<3>(a, fk, diag, from_angles, handoff, grid, blk, stream); break;
+        default: launch_stage<4>(a, fk, diag, from_angles, handoff, grid, blk, stream); break;
         }
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
+    if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[4]), stream));
+    if (a.frames) HIP_TRY(hipFreeAsync(a.frames, stream));
     return SEQIK_OK;
 }
 

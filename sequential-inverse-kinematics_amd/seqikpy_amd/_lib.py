@@ -35,7 +35,8 @@ class SeqikLegParams(ctypes.Structure):
 
 
 class SeqikOptions(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+    _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32),
+                ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("reserved", ctypes.c_int32 * 4)]
 
 
 class SeqikLayout(ctypes.Structure):
@@ -269,12 +270,18 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
-                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0):
+                     first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
+                     stage_events=None):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
-    ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout."""
+    ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
+    ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
+    first ``record()``), recorded in front of each stage kernel and behind the last one."""
     arr = (SeqikLegParams * n_legs)(*legs)
     opt = SeqikOptions()
     opt.block_size = block_size
+    if stage_events is not None:
+        ev = (ctypes.c_void_p * 5)(*[ctypes.c_void_p(int(e)) for e in stage_events])
+        opt.stage_events = ctypes.cast(ev, ctypes.POINTER(ctypes.c_void_p))
     rc = load().seqik_solve_seq_device(ctypes.c_void_p(d_pose), n_seq, n_legs, n_frames, arr, first_stage,
                                        last_stage, ctypes.c_void_p(d_angles), ctypes.c_void_p(d_fk or None),
                                        ctypes.c_void_p(d_status or None), ctypes.c_void_p(d_nfev or None),

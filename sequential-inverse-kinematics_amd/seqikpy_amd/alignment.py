@@ -9,8 +9,9 @@ the host by ``align_pose()`` -- bit-identical to the reference -- or handed to t
 ``leg_affine()`` / ``LegInvKinSeq(..., leg_affine=...)`` so that RAW key points go straight to the
 GPU and the map is fused into the solve prologue (``include/seqik.h``: ``SeqikAffine``).
 
-Head / antenna alignment (``align_head``) and the anipose / df3d converters are not part of this
-round.
+Also here: the antenna alignment (``align_head``, host only -- it feeds the closed-form head kernel)
+and the three input converters (anipose, DeepFly3D, DeepFly3DPostProcessing -> the segment dictionary
+every class of this package consumes), reference ``seqikpy/alignment.py:103-226``.
 """
 import logging
 from pathlib import Path
@@ -18,8 +19,34 @@ from typing import Dict, List, Literal, Optional, Tuple, Union
 
 import numpy as np
 
-from .data import NMF_TEMPLATE
-from .utils import calculate_body_size, save_file
+import pickle
+
+from .data import NMF_TEMPLATE, PTS2ALIGN
+from .utils import calculate_body_size, dict_to_nparray_pose, save_file
+
+
+def convert_from_anipose_to_dict(pose_3d: Dict[str, np.ndarray], pts2align: Dict[str, List[str]]) -> Dict[str, np.ndarray]:
+    """anipose columns ``"<keypoint>_x|_y|_z" -> (N,)`` to ``{segment: (N, n_key_points, 3)}``."""
+    out = {}
+    for segment, names in pts2align.items():
+        arr = np.empty((np.asarray(pose_3d[f"{names[0]}_x"]).shape[0], len(names), 3))
+        for i, kp in enumerate(names):
+            for a, axis in enumerate("xyz"):
+                arr[:, i, a] = pose_3d[f"{kp}_{axis}"]
+        out[segment] = arr
+    return out
+
+
+def convert_from_df3d_to_dict(pose_3d: np.ndarray, pts2align: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """DeepFly3D ``(N, n_key_points, 3)`` array + ``{segment: key point indices}``."""
+    return {segment: pose_3d[:, idx, :].copy() for segment, idx in pts2align.items()}
+
+
+def convert_from_df3dpp_to_dict(pose_3d: Dict[str, Dict[str, np.ndarray]],
+                                pts2align: Optional[List[str]] = None) -> Dict[str, np.ndarray]:
+    """DeepFly3DPostProcessing nested dictionary -> ``{"<leg>_leg": (N, 5, 3)}``."""
+    segments = list(pose_3d.keys()) if pts2align is None else pts2align
+    return {segment: dict_to_nparray_pose(pose_3d[segment], claw_is_end_effector=True) for segment in segments}
 
 
 def _mean_quantile(vector: np.ndarray, quantile_diff: float = 0.05) -> float:
@@ -44,6 +71,20 @@ class AlignPose:
         self.body_size = calculate_body_size(self.body_template, legs_list) if body_size is None else body_size
         self.logger = logging.getLogger(self.__class__.__name__)
         self.logger.setLevel(getattr(logging, log_level.upper(), None))
+
+    @classmethod
+    def from_file_path(cls, main_dir: Union[str, Path], file_name: Optional[str] = "pose3d.*",
+                       convert_func=None, pts2align: Optional[Dict[str, List[str]]] = None, **kwargs):
+        """Loads a pickled 3D pose (the newest match of ``file_name`` under ``main_dir``), optionally
+        converts it with ``convert_func(pose, pts2align)``; ``FileNotFoundError`` if nothing matches."""
+        paths = list(Path(main_dir).rglob(file_name))
+        if not paths:
+            raise FileNotFoundError(f"{file_name} does not exits in {main_dir}")
+        with open(paths[-1].as_posix(), "rb") as f:
+            pose_3d = pickle.load(f)
+        if convert_func is not None:
+            return cls(convert_func(pose_3d, PTS2ALIGN if pts2align is None else pts2align), **kwargs)
+        return cls(pose_3d, **kwargs)
 
     # -- statistics (host) ---------------------------------------------------------------
     @staticmethod
@@ -84,13 +125,43 @@ class AlignPose:
             aligned[:, i, :] = (leg_array[:, i, :] - fixed_coxa).reshape(-1, 3) * scale + template_coxa
         return aligned
 
+    # -- antenna alignment (host) -----------------------------------------------------------
+    @property
+    def thorax_mid_pts(self) -> np.ndarray:
+        assert "Thorax" in self.pose_data_dict, "To align the head, you need to have a `Thorax` key point"
+        thorax = self.pose_data_dict["Thorax"]
+        return 0.5 * (thorax[:, 0, :] + thorax[:, -1, :])
+
+    def find_stationary_indices(self, array: np.ndarray, threshold: Optional[float] = 5e-5) -> np.ndarray:
+        """Frames where the second difference of ``array`` is below ``threshold``."""
+        return np.where(np.diff(np.diff(array)) < threshold)[0]
+
+    def align_head(self, head_array: np.ndarray, side: str) -> np.ndarray:
+        """Scales / translates antenna base and tip to the template (reference :489-555): the base by the
+        antenna-base-to-thorax distance, the tip by the antenna length, both about a fixed antenna origin
+        estimated on the frames where that distance is stationary."""
+        base_to_thorax = np.linalg.norm(head_array[:, 0, :] - self.thorax_mid_pts, axis=1)
+        ant_len = np.linalg.norm(np.diff(head_array, axis=1), axis=2)[:, 0]
+        if not (self.body_size.get("Antenna_mid_thorax") and self.body_size.get("Antenna")):
+            raise KeyError("body_size must hold <Antenna_mid_thorax> and <Antenna>")
+        stat = self.find_stationary_indices(base_to_thorax)
+        origin = AlignPose.get_fixed_pos(head_array[stat, 0, :])
+        scale_base = self.body_size["Antenna_mid_thorax"] / _mean_quantile(base_to_thorax[stat])
+        scale_tip = self.body_size["Antenna"] / _mean_quantile(ant_len)
+        self.logger.info("Scale factor antenna base %s: %s, ant itself: %s", side, scale_base, scale_tip)
+        aligned = np.empty_like(head_array)
+        tmpl = self.body_template[f"{side}_Antenna_base"]
+        aligned[:, 0, :] = (head_array[:, 0, :] - origin) * scale_base + tmpl
+        aligned[:, 1, :] = (head_array[:, 1, :] - origin) * scale_tip + tmpl
+        return aligned
+
     def align_pose(self, export_path: Optional[Union[str, Path]] = None) -> Dict[str, np.ndarray]:
         aligned_pose = {}
         for segment, segment_array in self.pose_data_dict.items():
             if "leg" in segment:
                 aligned_pose[segment] = self.align_leg(segment_array, segment[:2])
             elif "head" in segment:
-                raise NotImplementedError("head alignment is not part of this build yet (SURVEY.md 8f-2)")
+                aligned_pose[segment] = self.align_head(segment_array, segment[0])
             else:
                 self.logger.debug("%s is not aligned", segment)
         if "Neck" in self.body_template:

@@ -77,6 +77,15 @@ NMF_TEMPLATE = {
     "R_dorsal_hum": np.array([0.41, -0.37, 1.32]),
 }
 
+# Key points to align per segment (anipose naming; reference ``seqikpy/data.py:80-101``)
+PTS2ALIGN = {
+    "R_head": ["base_anten_R", "tip_anten_R"],
+    "RF_leg": ["thorax_coxa_R", "coxa_femur_R", "femur_tibia_R", "tibia_tarsus_R", "claw_R"],
+    "Thorax": ["thorax_wing_R", "thorax_midpoint_tether", "thorax_wing_L"],
+    "L_head": ["base_anten_L", "tip_anten_L"],
+    "LF_leg": ["thorax_coxa_L", "coxa_femur_L", "femur_tibia_L", "tibia_tarsus_L", "claw_L"],
+}
+
 # ---------------------------------------------------------------------------
 # Six-leg locomotion setup (df3d recording)
 # ---------------------------------------------------------------------------

@@ -46,3 +46,14 @@ def save_file(out_fname, data):
 def load_file(output_fname):
     with open(output_fname, "rb") as f:
         return pickle.load(f)
+
+
+def dict_to_nparray_pose(pose_dict, claw_is_end_effector: bool):
+    """DeepFly3DPostProcessing leg dictionary (``{"Coxa": {"raw_pos_aligned": (N, 3)}, ...}``) ->
+    ``(N, 4 or 5, 3)`` key-point array (reference ``seqikpy/utils.py:293-310``)."""
+    key_points = ["Coxa", "Femur", "Tibia", "Tarsus"] + (["Claw"] if claw_is_end_effector else [])
+    n = np.asarray(pose_dict["Coxa"]["raw_pos_aligned"]).shape[0]
+    out = np.empty((n, len(key_points), 3))
+    for i, kp in enumerate(key_points):
+        out[:, i, :] = np.array(pose_dict[kp]["raw_pos_aligned"])
+    return out

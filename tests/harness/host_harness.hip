@@ -7,6 +7,7 @@
 #include "../../sequential-inverse-kinematics_amd/csrc/seqik_core.hpp"
 #include "../../sequential-inverse-kinematics_amd/csrc/seqik_consts.hpp"
 #include "../../sequential-inverse-kinematics_amd/csrc/seqik_head.hpp"
+#include <vector>
 
 extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const SeqikLegParams *leg,
                                  int32_t first_stage, int32_t last_stage, double *angles, double *fk,
@@ -25,16 +26,28 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
     io.n_frames = n_frames;
     const bool want_fk = io.fk != nullptr;
     const bool diag = status || nfev;
-    // same launch sequence as seqik_hip.hip::launch(): one pass over all frames per stage
+    std::vector<double> ws((size_t)n_frames * 12 + 1);
+    io.frames = ws.data();
+    // same launch sequence as seqik_hip.hip::launch(): one pass over all frames per stage; the first stage of a
+    // run that starts after stage 1 rebuilds its prefix from the angles, later ones read the hand-off workspace
     for (int stage = first_stage; stage <= last_stage; ++stage) {
-#define RUN(S, FK)                                                        \
-    if (diag) seqik::run_stage<S, FK, true>(lc, io);                      \
-    else seqik::run_stage<S, FK, false>(lc, io);
-        if (stage == 1) { RUN(1, false) }
-        else if (stage == 2) { RUN(2, false) }
-        else if (stage == 3) { RUN(3, false) }
-        else { if (want_fk) { RUN(4, true) } else { RUN(4, false) } }
-#undef RUN
+        const bool fa = (stage == first_stage) && stage > 1;
+        const bool ho = stage < last_stage;
+#define RUN4(S, FK, FA, HO)                                                   \
+    do { if (diag) seqik::run_stage<S, FK, true, FA, HO>(lc, io);             \
+         else seqik::run_stage<S, FK, false, FA, HO>(lc, io); } while (0)
+#define RUNS(S)                                                               \
+    do { if (want_fk) { if (fa && ho) RUN4(S, true, true, true); else if (fa) RUN4(S, true, true, false);      \
+                        else if (ho) RUN4(S, true, false, true); else RUN4(S, true, false, false); }           \
+         else { if (fa && ho) RUN4(S, false, true, true); else if (fa) RUN4(S, false, true, false);            \
+                else if (ho) RUN4(S, false, false, true); else RUN4(S, false, false, false); } } while (0)
+        if (stage == 1) { if (ho) RUN4(1, false, false, true); else RUN4(1, false, false, false); }
+        else if (stage == 2) RUNS(2);
+        else if (stage == 3) RUNS(3);
+        else { if (want_fk) { if (fa) RUN4(4, true, true, false); else RUN4(4, true, false, false); }
+               else { if (fa) RUN4(4, false, true, false); else RUN4(4, false, false, false); } }
+#undef RUNS
+#undef RUN4
     }
     return SEQIK_OK;
 }

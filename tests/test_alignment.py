@@ -76,3 +76,41 @@ def test_fused_alignment_on_gpu(df3d, hiplib, oracle):
     ang, fk = ik.run_ik_and_fk()
     assert np.array_equal(ang["Angle_RM_FTi_pitch"], ref["angles"][:, 5])
     assert np.array_equal(fk["RM_leg"], ref["fk"])
+
+
+def test_full_alignment_incl_antennae_bit_identical_to_reference():
+    """anipose_raw_cut.npz: un-aligned legs / antennae / thorax and the reference's align_pose output."""
+    from seqikpy_amd.data import NMF_TEMPLATE
+    z = load_golden("anipose_raw_cut")
+    raw = {str(k): z[f"raw_{k}"] for k in z["segments"]}
+    out = AlignPose(raw, ["RF", "LF"], body_template=NMF_TEMPLATE, log_level="ERROR").align_pose()
+    assert list(out.keys()) == ["R_head", "RF_leg", "L_head", "LF_leg", "Neck"]
+    for k, v in out.items():
+        assert np.array_equal(v, z[f"aligned_{k}"]), k
+    assert out["Neck"].shape == (1, 1, 3)
+
+
+def test_converters(tmp_path):
+    from seqikpy_amd.alignment import (convert_from_anipose_to_dict, convert_from_df3d_to_dict,
+                                       convert_from_df3dpp_to_dict)
+    from seqikpy_amd.data import PTS2ALIGN
+    rng = np.random.default_rng(3)
+    names = sorted({kp for kps in PTS2ALIGN.values() for kp in kps})
+    ani = {f"{kp}_{ax}": rng.normal(size=11) for kp in names for ax in "xyz"}
+    d = convert_from_anipose_to_dict(ani, PTS2ALIGN)
+    assert list(d.keys()) == list(PTS2ALIGN.keys()) and d["RF_leg"].shape == (11, 5, 3) and d["R_head"].shape == (11, 2, 3)
+    assert np.array_equal(d["LF_leg"][:, 3, 1], ani["tibia_tarsus_L_y"])
+    arr = rng.normal(size=(7, 38, 3))
+    d = convert_from_df3d_to_dict(arr, {"RF_leg": np.arange(0, 5), "LH_leg": np.arange(29, 34)})
+    assert np.array_equal(d["LH_leg"], arr[:, 29:34])
+    pp = {"RM_leg": {kp: {"raw_pos_aligned": rng.normal(size=(9, 3))} for kp in ["Coxa", "Femur", "Tibia", "Tarsus", "Claw"]}}
+    d = convert_from_df3dpp_to_dict(pp)
+    assert d["RM_leg"].shape == (9, 5, 3) and np.array_equal(d["RM_leg"][:, 4], pp["RM_leg"]["Claw"]["raw_pos_aligned"])
+    with pytest.raises(FileNotFoundError):
+        AlignPose.from_file_path(tmp_path, file_name="pose3d.*", legs_list=["RF"])
+    import pickle
+    with open(tmp_path / "pose3d.h5", "wb") as f:
+        pickle.dump(ani, f)
+    al = AlignPose.from_file_path(tmp_path, file_name="pose3d.*", convert_func=convert_from_anipose_to_dict,
+                                  legs_list=["RF", "LF"], log_level="ERROR")
+    assert al.pose_data_dict["Thorax"].shape == (11, 3, 3)
