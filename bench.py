@@ -65,12 +65,31 @@ def make_workload(n_seq, n_frames, variant, seed):
     return legs, body, pose, params
 
 
+def usable_cores():
+    """Hardware threads this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box reports 256 logical CPUs but grants a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(pose, legs, body, n_seq_sample):
     """The C oracle (oracle/seqik_oracle.c) on the host cores: one task per (sequence, leg), the
     shape of the reference's parallel example (examples/example_leg_inv_kinematics_parallel.py:186)."""
     from oracle import c_oracle
     c_oracle.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n_seq_sample = min(n_seq_sample, pose.shape[0])
     par = [c_oracle.leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
     segs, bnds, seeds = (np.stack([p[i] for p in par]) for i in range(3))
