@@ -155,6 +155,24 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
                            const SeqikOptions *opt, void *hip_stream);
 
 /*
+ * LegInvKinGeneric.run_ik_and_fk (seqikpy/leg_inverse_kinematics.py:545-613): one 9-link chain per leg
+ * (KinematicChainGeneric, seqikpy/kinematic_chain.py:464-530), 7 unknowns, target = the claw (pose row 4),
+ * frame t warm-started from frame t-1, frame 0 from legs[l].seeds[18..26] = initial_angles["stage_4"]
+ * applied positionally to the links Base, ThC_roll, ThC_yaw, ThC_pitch, CTr_pitch, CTr_roll, FTi, TiTa, Claw.
+ * Arrays and options as for seqik_solve_seq; angles come back in this ABI's DOF order; status / nfev are
+ * [n_seq][n_legs][n_frames] (one solve per frame).  The problem is rank-deficient (3 equations): the
+ * reference's angles depend on LAPACK round-off, only the claw position is comparable.
+ */
+int seqik_validate_legs_generic(const SeqikLegParams *legs, int32_t n_legs);
+int seqik_solve_generic(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                        const SeqikLegParams *legs, double *angles, double *fk, int32_t *status, int32_t *nfev,
+                        const double *init_angles, const SeqikAffine *affine, const SeqikOptions *opt);
+int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                               const SeqikLegParams *legs, double *d_angles, double *d_fk, int32_t *d_status,
+                               int32_t *d_nfev, const double *d_init_angles, const SeqikLayout *layout,
+                               const SeqikAffine *affine, const SeqikOptions *opt, void *hip_stream);
+
+/*
  * HeadInverseKinematics.compute_head_angles (seqikpy/head_inverse_kinematics.py:103-140) for n_frames
  * frames: closed-form head roll / pitch / yaw and, per side, antenna yaw / pitch.
  *   r_head, l_head  [n_frames][2][3]  aligned antenna base and tip (aligned_pos["R_head"], ["L_head"])

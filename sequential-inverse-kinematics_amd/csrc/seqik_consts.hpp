@@ -4,6 +4,7 @@
 // which links are revolute, their axes, translations and bounds.
 #pragma once
 #include "seqik_core.hpp"
+#include "seqik_generic.hpp"
 #include "../../include/seqik.h"
 
 namespace seqik {
@@ -103,6 +104,55 @@ inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, Le
             sc.x_suf = strictly_feasible(seed[n - 1], lb, ub, 1e-10);
         }
     }
+}
+
+// ---- generic chain (KinematicChainGeneric.create_leg_chain, kinematic_chain.py:464-530) -------------
+// link i (1..7) of the generic chain carries DOF: roll, yaw, pitch, CTr_pitch, CTr_roll, FTi, TiTa
+static const int kGenericLinkDof[GN] = {2, 0, 1, 3, 4, 5, 6};
+
+inline void generic_link_bounds(const SeqikLegParams &lp, int link /*0..8*/, double &lb, double &ub)
+{
+    const double PI = 3.141592653589793;
+    if (link == 0) { lb = -__builtin_huge_val(); ub = __builtin_huge_val(); }
+    else if (link == 8) { lb = -PI; ub = PI; }
+    else { lb = lp.bounds[kGenericLinkDof[link - 1]][0]; ub = lp.bounds[kGenericLinkDof[link - 1]][1]; }
+}
+
+// LegInvKinGeneric seeds the chain with initial_angles["stage_4"] (leg_inverse_kinematics.py:588),
+// applied positionally: seeds[18 + i] is the start value of link i.
+inline int validate_leg_generic(const SeqikLegParams &lp)
+{
+    for (int i = 0; i < 9; ++i) {
+        double lb, ub;
+        generic_link_bounds(lp, i, lb, ub);
+        if (!(lb < ub)) return SEQIK_ERR_BAD_BOUNDS;
+    }
+    for (int i = 0; i < 9; ++i) {
+        double lb, ub;
+        generic_link_bounds(lp, i, lb, ub);
+        double x = lp.seeds[18 + i];
+        if (!(x >= lb && x <= ub)) return SEQIK_ERR_X0_OUT_OF_BOUNDS;
+    }
+    return SEQIK_OK;
+}
+
+inline void make_generic_consts(const SeqikLegParams &lp, GenericConst &gc)
+{
+    const double tz[GN] = {0.0, 0.0, 0.0, -lp.seg[0], 0.0, -lp.seg[1], -lp.seg[2]};
+    for (int i = 0; i < GN; ++i) {
+        generic_link_bounds(lp, i + 1, gc.lb[i], gc.ub[i]);
+        gc.seed[i] = lp.seeds[18 + 1 + i];
+        gc.tz[i] = tz[i];
+    }
+    gc.tz_claw = -lp.seg[3];
+    double lb, ub;
+    generic_link_bounds(lp, 0, lb, ub);
+    double xb = strictly_feasible(lp.seeds[18], lb, ub, 1e-10);
+    gc.x_pre_sq = fma_(xb, xb, 0.0);
+    generic_link_bounds(lp, 8, lb, ub);
+    gc.x_suf = strictly_feasible(lp.seeds[26], lb, ub, 1e-10);
+    gc.max_nfev = 900;
+    gc.pad_ = 0;
 }
 
 }  // namespace seqik

@@ -1,0 +1,512 @@
+// seqik_generic.hpp -- "generic" (single-chain) leg inverse kinematics, one lane per chain.
+//
+// Replaces LegInvKinGeneric.calculate_ik_stage / run_ik_and_fk
+// (seqikpy/leg_inverse_kinematics.py:406-613) over the 9-link chain of
+// KinematicChainGeneric.create_leg_chain (seqikpy/kinematic_chain.py:464-530):
+//   Base | ThC_roll(Z) ThC_yaw(X) ThC_pitch(Y) CTr_pitch(Y,-coxa) CTr_roll(Z) FTi(Y,-femur) TiTa(Y,-tibia) | Claw(-tarsus)
+// One bounded trust-region least-squares solve per frame with 7 unknowns and 3 residuals (the claw
+// position), warm-started from the previous frame.
+//
+// The problem is rank-deficient by construction (7 unknowns, 3 equations).  In the reference the
+// step inside the null space is decided by LAPACK round-off, so only the claw position
+// -- not the individual angles -- can be compared with the reference.  What IS exact: this file
+// mirrors the generic code path of oracle/seqik_oracle.c (oracle_generic_leg) operation for
+// operation, so kernel == oracle bit for bit, as for the sequential stages.
+#pragma once
+#include "seqik_core.hpp"
+
+namespace seqik {
+
+constexpr int GN = 7;  // active links
+
+struct GenericConst {
+    double lb[GN], ub[GN];   // bounds in LINK order: roll, yaw, pitch, CTr_pitch, CTr_roll, FTi, TiTa
+    double seed[GN];         // initial_angles["stage_4"][1..7], applied positionally to the links
+    double tz[GN];           // origin_translation z per link: 0, 0, 0, -coxa, 0, -femur, -tibia
+    double tz_claw;          // -tarsus
+    double x_pre_sq;         // fma(x_base, x_base, 0)
+    double x_suf;            // strictly feasible seed of the claw link
+    int32_t max_nfev;        // 900
+    int32_t pad_;
+};
+
+// cumulative chain for given sin/cos of the 7 joints; returns the frame after TiTa and, optionally,
+// the translations after CTr_pitch (coxa end) and FTi (femur end) for the FK output
+SEQIK_HD void generic_chain(const GenericConst &gc, const double *sn, const double *cs, Frame &out, double *coxa_end,
+                            double *femur_end)
+{
+    Frame a, b;
+    frame_identity(a);
+    frame_mul_link<AXIS_Z>(b, a, sn[0], cs[0], gc.tz[0]);
+    frame_mul_link<AXIS_X>(a, b, sn[1], cs[1], gc.tz[1]);
+    frame_mul_link<AXIS_Y>(b, a, sn[2], cs[2], gc.tz[2]);
+    frame_mul_link<AXIS_Y>(a, b, sn[3], cs[3], gc.tz[3]);
+    if (coxa_end) { coxa_end[0] = a.t[0]; coxa_end[1] = a.t[1]; coxa_end[2] = a.t[2]; }
+    frame_mul_link<AXIS_Z>(b, a, sn[4], cs[4], gc.tz[4]);
+    frame_mul_link<AXIS_Y>(a, b, sn[5], cs[5], gc.tz[5]);
+    if (femur_end) { femur_end[0] = a.t[0]; femur_end[1] = a.t[1]; femur_end[2] = a.t[2]; }
+    frame_mul_link<AXIS_Y>(out, a, sn[6], cs[6], gc.tz[6]);
+}
+
+SEQIK_HD void generic_residual(const GenericConst &gc, const double *sn, const double *cs, const double *target, double *f)
+{
+    Frame e;
+    generic_chain(gc, sn, cs, e, nullptr, nullptr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f[i] = (e.r[3 * i + 2] * gc.tz_claw + e.t[i]) - target[i];
+}
+
+SEQIK_HD double vnorm7(const double *a)
+{
+    double acc = 0.0;
+    for (int i = 0; i < GN; ++i) acc = fma_(a[i], a[i], acc);
+    return sqrt(acc);
+}
+
+SEQIK_HD double vdot7(const double *a, const double *b)
+{
+    double acc = 0.0;
+    for (int i = 0; i < GN; ++i) acc = fma_(a[i], b[i], acc);
+    return acc;
+}
+
+SEQIK_HD void matvec37(const double Jh[3][GN], const double *s, double *out)
+{
+    for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+        for (int i = 0; i < GN; ++i) acc = fma_(Jh[k][i], s[i], acc);
+        out[k] = acc;
+    }
+}
+
+SEQIK_HD double diag_form7(const double *a, const double *diag, const double *b)
+{
+    double acc = 0.0;
+    for (int i = 0; i < GN; ++i) acc = fma_(a[i] * diag[i], b[i], acc);
+    return acc;
+}
+
+// oracle jacobi_svd for a (3 + 7) x 7 matrix: singular values (descending), the first three rows of U
+// folded into uf = U^T f, and V (columns = right singular vectors)
+SEQIK_HD void svd7(double A[3 + GN][GN], const double *f, double *s, double V[GN][GN], double *uf)
+{
+    const double TOL = 8.881784197001252e-16;
+    constexpr int ROWS = 3 + GN;
+    for (int i = 0; i < GN; ++i)
+        for (int j = 0; j < GN; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < GN - 1; ++p)
+            for (int q = p + 1; q < GN; ++q) {
+                double alpha = 0.0, beta = 0.0, gamma = 0.0;
+                for (int i = 0; i < ROWS; ++i) {
+                    alpha = fma_(A[i][p], A[i][p], alpha);
+                    beta = fma_(A[i][q], A[i][q], beta);
+                    gamma = fma_(A[i][p], A[i][q], gamma);
+                }
+                if (gamma == 0.0) continue;
+                if (fabs(gamma) <= TOL * sqrt(alpha * beta)) continue;
+                rotated = true;
+                double zeta = (beta - alpha) / (2.0 * gamma);
+                double t = 1.0 / (fabs(zeta) + sqrt(fma_(zeta, zeta, 1.0)));
+                if (zeta < 0.0) t = -t;
+                double c = 1.0 / sqrt(fma_(t, t, 1.0));
+                double sn = c * t;
+                for (int i = 0; i < ROWS; ++i) {
+                    double ap = A[i][p], aq = A[i][q];
+                    A[i][p] = fma_(c, ap, -(sn * aq));
+                    A[i][q] = fma_(sn, ap, c * aq);
+                }
+                for (int i = 0; i < GN; ++i) {
+                    double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = fma_(c, vp, -(sn * vq));
+                    V[i][q] = fma_(sn, vp, c * vq);
+                }
+            }
+        if (!rotated) break;
+    }
+    double sv[GN];
+    int order[GN];
+    for (int j = 0; j < GN; ++j) {
+        double acc = 0.0;
+        for (int i = 0; i < ROWS; ++i) acc = fma_(A[i][j], A[i][j], acc);
+        sv[j] = sqrt(acc);
+        order[j] = j;
+    }
+    for (int i = 1; i < GN; ++i) {  // stable insertion sort, descending
+        int k = order[i];
+        int j = i - 1;
+        while (j >= 0 && sv[order[j]] < sv[k]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = k;
+    }
+    double Vt[GN][GN];
+    for (int jj = 0; jj < GN; ++jj) {
+        int j = order[jj];
+        s[jj] = sv[j];
+        double inv_sv = (sv[j] > 0.0) ? 1.0 / sv[j] : 0.0;
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) acc = fma_(A[k][j] * inv_sv, f[k], acc);
+        uf[jj] = acc;
+        for (int i = 0; i < GN; ++i) Vt[i][jj] = V[i][j];
+    }
+    for (int i = 0; i < GN; ++i)
+        for (int j = 0; j < GN; ++j) V[i][j] = Vt[i][j];
+}
+
+SEQIK_HD void phi_and_ratio7(double alpha, const double *suf, const double *s, double Delta, double &phi, double &ratio)
+{
+    double tmp[GN];
+    double acc = 0.0;
+    for (int i = 0; i < GN; ++i) {
+        double r = 1.0 / fma_(s[i], s[i], alpha);
+        tmp[i] = suf[i] * r;
+        acc = fma_(tmp[i] * tmp[i], r, acc);
+    }
+    double p_norm = vnorm7(tmp);
+    phi = p_norm - Delta;
+    ratio = -(phi * p_norm) / acc;
+}
+
+// solve_lsq_trust_region with m = 3 < n = 7: never full rank
+SEQIK_HD void solve_lsq7(const double *uf, const double *s, const double V[GN][GN], double Delta, double &alpha_io, double *p)
+{
+    double suf[GN], tmp[GN];
+    for (int i = 0; i < GN; ++i) suf[i] = s[i] * uf[i];
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = vnorm7(suf) * inv_Delta;
+    double alpha_lower = 0.0;
+    double alpha = alpha_io;
+    if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double phi, ratio;
+        phi_and_ratio7(alpha, suf, s, Delta, phi, ratio);
+        if (phi < 0) alpha_upper = alpha;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio * inv_Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    for (int i = 0; i < GN; ++i) tmp[i] = suf[i] / fma_(s[i], s[i], alpha);
+    for (int i = 0; i < GN; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < GN; ++k) acc = fma_(V[i][k], tmp[k], acc);
+        p[i] = -acc;
+    }
+    double scale = Delta / vnorm7(p);
+    for (int i = 0; i < GN; ++i) p[i] = p[i] * scale;
+    alpha_io = alpha;
+}
+
+SEQIK_HD double step_size_to_bound7(const double *x, const double *s, const double *lb, const double *ub, int *hits)
+{
+    const double INF = __builtin_huge_val();
+    double steps[GN];
+    double min_step = INF;
+    for (int i = 0; i < GN; ++i) {
+        steps[i] = INF;
+        if (s[i] != 0.0) {
+            double inv_s = 1.0 / s[i];
+            steps[i] = fmax((lb[i] - x[i]) * inv_s, (ub[i] - x[i]) * inv_s);
+        }
+        if (steps[i] < min_step) min_step = steps[i];
+    }
+    if (hits)
+        for (int i = 0; i < GN; ++i) {
+            int sg = (s[i] > 0) - (s[i] < 0);
+            hits[i] = (steps[i] == min_step) ? sg : 0;
+        }
+    return min_step;
+}
+
+SEQIK_HD double evaluate_quadratic7(const double Jh[3][GN], const double *g, const double *s, const double *diag)
+{
+    double Js[3];
+    matvec37(Jh, s, Js);
+    double q = dot3(Js, Js);
+    q = q + diag_form7(s, diag, s);
+    return fma_(0.5, q, vdot7(s, g));
+}
+
+// _lsq/trf.py:select_step (in-bounds case included); p, p_h are clobbered
+SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const double *diag_h, const double *g_h, double *p,
+                             double *p_h, const double *d, double Delta, const double *lb, const double *ub, double theta,
+                             double *step, double *step_h)
+{
+    const double INF = __builtin_huge_val();
+    bool inb = true;
+    for (int i = 0; i < GN; ++i) {
+        double xp = x[i] + p[i];
+        if (!(xp >= lb[i] && xp <= ub[i])) inb = false;
+    }
+    if (inb) {
+        double p_value = evaluate_quadratic7(Jh, g_h, p_h, diag_h);
+        for (int i = 0; i < GN; ++i) { step[i] = p[i]; step_h[i] = p_h[i]; }
+        return -p_value;
+    }
+    int hits[GN];
+    double p_stride = step_size_to_bound7(x, p, lb, ub, hits);
+    double r_h[GN], r[GN], x_on_bound[GN];
+    for (int i = 0; i < GN; ++i) {
+        r_h[i] = p_h[i];
+        if (hits[i] != 0) r_h[i] = r_h[i] * -1.0;
+        r[i] = d[i] * r_h[i];
+    }
+    for (int i = 0; i < GN; ++i) {
+        p[i] = p[i] * p_stride;
+        p_h[i] = p_h[i] * p_stride;
+        x_on_bound[i] = x[i] + p[i];
+    }
+    double to_tr;
+    {
+        double a = vdot7(r_h, r_h);
+        double b = vdot7(p_h, r_h);
+        double c = fma_(-Delta, Delta, vdot7(p_h, p_h));
+        double dd = sqrt(fma_(b, b, -(a * c)));
+        double q = -(b + copysign(dd, b));
+        double t1 = q / a;
+        double t2 = c / q;
+        to_tr = (t1 < t2) ? t2 : t1;
+    }
+    double to_bound = step_size_to_bound7(x_on_bound, r, lb, ub, nullptr);
+    double r_stride = fmin(to_bound, to_tr);
+    double r_stride_l, r_stride_u;
+    if (r_stride > 0) {
+        r_stride_l = (1 - theta) * p_stride / r_stride;
+        r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
+    } else {
+        r_stride_l = 0;
+        r_stride_u = -1;
+    }
+    double r_value;
+    if (r_stride_l <= r_stride_u) {
+        double v[3], u[3];
+        matvec37(Jh, r_h, v);
+        double a = dot3(v, v);
+        a = a + diag_form7(r_h, diag_h, r_h);
+        a = a * 0.5;
+        double b = vdot7(g_h, r_h);
+        matvec37(Jh, p_h, u);
+        b = b + dot3(u, v);
+        double c = fma_(0.5, dot3(u, u), vdot7(g_h, p_h));
+        b = b + diag_form7(p_h, diag_h, r_h);
+        c = fma_(0.5, diag_form7(p_h, diag_h, p_h), c);
+        r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, r_value);
+        for (int i = 0; i < GN; ++i) {
+            r_h[i] = r_h[i] * r_stride;
+            r_h[i] = r_h[i] + p_h[i];
+            r[i] = r_h[i] * d[i];
+        }
+    } else {
+        r_value = INF;
+    }
+    for (int i = 0; i < GN; ++i) { p[i] = p[i] * theta; p_h[i] = p_h[i] * theta; }
+    double p_value = evaluate_quadratic7(Jh, g_h, p_h, diag_h);
+
+    double ag_h[GN], ag[GN];
+    for (int i = 0; i < GN; ++i) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
+    to_tr = Delta / vnorm7(ag_h);
+    to_bound = step_size_to_bound7(x, ag, lb, ub, nullptr);
+    double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
+    double ag_value;
+    {
+        double v[3];
+        matvec37(Jh, ag_h, v);
+        double a = dot3(v, v);
+        a = a + diag_form7(ag_h, diag_h, ag_h);
+        a = a * 0.5;
+        double b = vdot7(g_h, ag_h);
+        ag_stride = minimize_quadratic_1d(a, b, 0.0, ag_stride, 0.0, ag_value);
+    }
+    for (int i = 0; i < GN; ++i) { ag_h[i] = ag_h[i] * ag_stride; ag[i] = ag[i] * ag_stride; }
+
+    const double *bs = ag, *bh = ag_h;
+    double value = ag_value;
+    if (p_value < r_value && p_value < ag_value) { bs = p; bh = p_h; value = p_value; }
+    else if (r_value < p_value && r_value < ag_value) { bs = r; bh = r_h; value = r_value; }
+    for (int i = 0; i < GN; ++i) { step[i] = bs[i]; step_h[i] = bh[i]; }
+    return -value;
+}
+
+struct GenericIO {
+    const double *pose;     // key point (row, t) at pose + row * pose_row + t * pose_frame
+    int64_t pose_row, pose_frame;
+    double *angles;         // angle (dof, t) at angles + dof * ang_dof + t * ang_frame, DOF order of seqik.h
+    int64_t ang_dof, ang_frame;
+    double *fk;             // nullable [n_frames][9][3]
+    int32_t *status;        // nullable [n_frames]
+    int32_t *nfev;          // nullable [n_frames]
+    const double *init;     // nullable [7] in DOF order: warm start of frame 0
+    int64_t n_frames;
+};
+
+// link index -> DOF index of the ABI (yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa)
+SEQIK_HD int generic_link_dof(int link)
+{
+    return link == 0 ? 2 : (link == 1 ? 0 : (link == 2 ? 1 : link));
+}
+
+template <bool WANT_DIAG>
+SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const GenericIO &io)
+{
+    const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    double x[GN], f[3] = {0.0, 0.0, 0.0}, sn[GN], cs[GN], target[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < GN; ++i) {
+        x[i] = io.init ? io.init[generic_link_dof(i)] : gc.seed[i];
+        sn[i] = 0.0; cs[i] = 1.0;
+    }
+    double cost = 0.0, Delta = 0.0, alpha = 0.0;
+    int nfev = 0, status = STATUS_NONE;
+    bool first_pass = true, new_solve = true;
+    int64_t t = 0;
+
+    while (t < io.n_frames) {
+        if (new_solve) {
+            const double *org = io.pose + t * io.pose_frame;
+            const double *kp = org + 4 * io.pose_row;  // the claw is the end effector (:587)
+            if (aff.enabled) {
+                for (int a = 0; a < 3; ++a) {
+                    double al = (kp[a] - aff.fixed_coxa[a]) * aff.scale + aff.template_coxa[a];
+                    target[a] = al - aff.template_coxa[a];
+                }
+            } else {
+                for (int a = 0; a < 3; ++a) target[a] = kp[a] - org[a];
+            }
+            for (int i = 0; i < GN; ++i) {
+                x[i] = strictly_feasible(x[i], gc.lb[i], gc.ub[i], 1e-10);
+                sincos_cw(x[i], sn[i], cs[i]);
+            }
+            generic_residual(gc, sn, cs, target, f);
+            cost = 0.5 * dot3(f, f);
+            nfev = 1;
+            alpha = 0.0;
+            status = STATUS_NONE;
+            first_pass = true;
+            new_solve = false;
+        }
+
+        bool finished = false;
+        if (WANT_DIAG || status == STATUS_NONE) {
+            // ---- 2-point finite-difference Jacobian: column j perturbs joint j only ---------------
+            double J[3][GN], g[GN], v[GN], dv[GN];
+            for (int j = 0; j < GN; ++j) {
+                double h = fd_step(x[j], gc.lb[j], gc.ub[j]);
+                double x1 = x[j] + h;
+                double dx = x1 - x[j];
+                double s_keep = sn[j], c_keep = cs[j], f1[3];
+                sincos_cw(x1, sn[j], cs[j]);
+                generic_residual(gc, sn, cs, target, f1);
+                sn[j] = s_keep; cs[j] = c_keep;
+                double inv_dx = 1.0 / dx;
+                for (int k = 0; k < 3; ++k) J[k][j] = (f1[k] - f[k]) * inv_dx;
+            }
+            for (int j = 0; j < GN; ++j) {
+                g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
+                cl_scaling(x[j], g[j], gc.lb[j], gc.ub[j], v[j], dv[j]);
+            }
+            if (first_pass) {
+                double acc = gc.x_pre_sq;
+                for (int j = 0; j < GN; ++j) { double tj = x[j] / sqrt(v[j]); acc = fma_(tj, tj, acc); }
+                acc = fma_(gc.x_suf, gc.x_suf, acc);
+                Delta = sqrt(acc);
+                if (Delta == 0) Delta = 1.0;
+                first_pass = false;
+            }
+            double g_norm = 0.0;
+            for (int j = 0; j < GN; ++j) { double a = fabs(g[j] * v[j]); if (a > g_norm) g_norm = a; }
+            if (g_norm < gtol) status = 1;
+
+            if (status != STATUS_NONE || nfev == gc.max_nfev) {
+                finished = true;
+            } else {
+                double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
+                double A[3 + GN][GN];
+                for (int j = 0; j < GN; ++j) {
+                    d[j] = sqrt(v[j]) * 1.0;
+                    diag_h[j] = g[j] * dv[j] * 1.0;
+                    g_h[j] = d[j] * g[j];
+                }
+                for (int k = 0; k < 3; ++k)
+                    for (int j = 0; j < GN; ++j) { Jh[k][j] = J[k][j] * d[j]; A[k][j] = Jh[k][j]; }
+                for (int r = 0; r < GN; ++r)
+                    for (int j = 0; j < GN; ++j) A[3 + r][j] = (r == j) ? sqrt(diag_h[j]) : 0.0;
+                double s[GN], V[GN][GN], uf[GN];
+                svd7(A, f, s, V, uf);
+                double theta = fmax(0.995, 1 - g_norm);
+
+                double p_h[GN], p[GN], step[GN], step_h[GN];
+                solve_lsq7(uf, s, V, Delta, alpha, p_h);
+                for (int j = 0; j < GN; ++j) p[j] = d[j] * p_h[j];
+                double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h);
+                double x_new[GN], sn_n[GN], cs_n[GN], f_new[3];
+                for (int j = 0; j < GN; ++j) {
+                    x_new[j] = strictly_feasible(x[j] + step[j], gc.lb[j], gc.ub[j], 0.0);
+                    sincos_cw(x_new[j], sn_n[j], cs_n[j]);
+                }
+                generic_residual(gc, sn_n, cs_n, target, f_new);
+                nfev += 1;
+                double step_h_norm = vnorm7(step_h);
+                double cost_new = 0.5 * dot3(f_new, f_new);
+                double actual_reduction = cost - cost_new;
+                double ratio;
+                if (predicted_reduction > 0) ratio = actual_reduction / predicted_reduction;
+                else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
+                else ratio = 0;
+                double Delta_new = Delta;
+                if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
+                else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
+                double step_norm = vnorm7(step);
+                double xn = gc.x_pre_sq;
+                for (int j = 0; j < GN; ++j) xn = fma_(x[j], x[j], xn);
+                xn = fma_(gc.x_suf, gc.x_suf, xn);
+                xn = sqrt(xn);
+                bool ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
+                bool xtol_ok = step_norm < xtol * (xtol + xn);
+                if (ftol_ok && xtol_ok) status = 4;
+                else if (ftol_ok) status = 2;
+                else if (xtol_ok) status = 3;
+                if (status == STATUS_NONE) {
+                    alpha = alpha * (Delta / Delta_new);
+                    Delta = Delta_new;
+                }
+                if (actual_reduction > 0) {
+                    for (int j = 0; j < GN; ++j) { x[j] = x_new[j]; sn[j] = sn_n[j]; cs[j] = cs_n[j]; }
+                    f[0] = f_new[0]; f[1] = f_new[1]; f[2] = f_new[2];
+                    cost = cost_new;
+                }
+                if (!WANT_DIAG && (status != STATUS_NONE || nfev == gc.max_nfev)) finished = true;
+            }
+        } else {
+            finished = true;
+        }
+
+        if (finished) {
+            double *ang = io.angles + t * io.ang_frame;
+            for (int j = 0; j < GN; ++j) ang[generic_link_dof(j) * io.ang_dof] = x[j];
+            if constexpr (WANT_DIAG) {
+                if (io.status) io.status[t] = (status == STATUS_NONE) ? 0 : status;
+                if (io.nfev) io.nfev[t] = nfev;
+            }
+            if (io.fk) {
+                const double *origin = aff.enabled ? aff.template_coxa : io.pose + t * io.pose_frame;
+                double *fk = io.fk + t * 27;
+                Frame e;
+                double coxa_end[3], femur_end[3];
+                generic_chain(gc, sn, cs, e, coxa_end, femur_end);
+                for (int i = 0; i < 4; ++i)
+                    for (int a = 0; a < 3; ++a) fk[3 * i + a] = 0.0 + origin[a];
+                for (int a = 0; a < 3; ++a) {
+                    fk[12 + a] = coxa_end[a] + origin[a];
+                    fk[15 + a] = coxa_end[a] + origin[a];
+                    fk[18 + a] = femur_end[a] + origin[a];
+                    fk[21 + a] = e.t[a] + origin[a];
+                    fk[24 + a] = (e.r[3 * a + 2] * gc.tz_claw + e.t[a]) + origin[a];
+                }
+            }
+            t += 1;
+            new_solve = true;
+        }
+    }
+}
+
+}  // namespace seqik

@@ -116,6 +116,51 @@ void launch_stage(const KernelArgs &a, bool fk, bool diag, bool from_angles, boo
     }
 }
 
+struct GenericLegTable {
+    seqik::GenericConst gc;
+    seqik::LegAffine aff;
+};
+
+struct GenericKernelArgs {
+    const double *pose;
+    double *angles;
+    double *fk;
+    int32_t *status;
+    int32_t *nfev;
+    const GenericLegTable *legs;
+    const double *init;
+    int64_t n_chains, n_frames;
+    int32_t n_legs;
+    int64_t pose_chain, pose_row, pose_frame;
+    int64_t ang_chain, ang_dof, ang_frame;
+};
+
+// Generic (single 9-link chain, 7 unknowns) IK: one lane per chain, one launch.
+template <bool WANT_DIAG>
+__global__ void __launch_bounds__(kMaxBlock) seqik_generic_kernel(GenericKernelArgs a)
+{
+    __shared__ GenericLegTable s_legs[kMaxLegs];
+    {
+        const int words = a.n_legs * (int)(sizeof(GenericLegTable) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_chains) return;
+    const int leg = (int)(c % a.n_legs);
+    seqik::GenericIO io;
+    io.pose = a.pose + c * a.pose_chain; io.pose_row = a.pose_row; io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain; io.ang_dof = a.ang_dof; io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
+    io.status = a.status ? a.status + c * a.n_frames : nullptr;
+    io.nfev = a.nfev ? a.nfev + c * a.n_frames : nullptr;
+    io.init = a.init ? a.init + c * 7 : nullptr;
+    io.n_frames = a.n_frames;
+    seqik::run_generic<WANT_DIAG>(s_legs[leg].gc, s_legs[leg].aff, io);
+}
+
 // Device copy of the per-leg constant table.  Callers almost always pass the same legs on
 // every call, so the table is cached per host thread and device: a repeat call is a pure
 // kernel launch (no allocation, no copy).  When the contents change, the device is drained
@@ -142,6 +187,41 @@ int device_leg_table(const SeqikLegParams *legs, const SeqikAffine *affine, int3
         if (c.d && c.device != dev) c.d = nullptr;  // belongs to another device: leave it (tiny)
         if (!c.d) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d), sizeof(seqik::LegConst) * kMaxLegs));
         HIP_TRY(hipMemcpy(c.d, h.data(), sizeof(seqik::LegConst) * n_legs, hipMemcpyHostToDevice));
+        c.device = dev;
+        c.h = h;
+    }
+    *out = c.d;
+    return SEQIK_OK;
+}
+
+struct GenericTableCache {
+    GenericLegTable *d = nullptr;
+    int device = -1;
+    std::vector<GenericLegTable> h;
+};
+thread_local GenericTableCache g_gen_cache;
+
+int device_generic_table(const SeqikLegParams *legs, const SeqikAffine *affine, int32_t n_legs, const GenericLegTable **out)
+{
+    std::vector<GenericLegTable> h(n_legs);
+    memset(h.data(), 0, sizeof(GenericLegTable) * n_legs);
+    for (int l = 0; l < n_legs; ++l) {
+        seqik::make_generic_consts(legs[l], h[l].gc);
+        seqik::LegConst tmp;
+        memset(&tmp, 0, sizeof(tmp));
+        seqik::make_leg_consts(legs[l], affine ? affine + l : nullptr, tmp);
+        h[l].aff = tmp.aff;
+    }
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    GenericTableCache &c = g_gen_cache;
+    const bool same = c.d && c.device == dev && c.h.size() == h.size() &&
+                      memcmp(c.h.data(), h.data(), sizeof(GenericLegTable) * n_legs) == 0;
+    if (!same) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c.d && c.device != dev) c.d = nullptr;
+        if (!c.d) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d), sizeof(GenericLegTable) * kMaxLegs));
+        HIP_TRY(hipMemcpy(c.d, h.data(), sizeof(GenericLegTable) * n_legs, hipMemcpyHostToDevice));
         c.device = dev;
         c.h = h;
     }
@@ -259,6 +339,94 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     if (rc != SEQIK_OK) return rc;
     return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
                   d_status, d_nfev, d_init_angles, layout, opt, stream);
+}
+
+int seqik_validate_legs_generic(const SeqikLegParams *legs, int32_t n_legs)
+{
+    if (!legs || n_legs <= 0) return fail(SEQIK_ERR_BAD_ARG, "null legs%s");
+    for (int l = 0; l < n_legs; ++l) {
+        int rc = seqik::validate_leg_generic(legs[l]);
+        if (rc == SEQIK_ERR_BAD_BOUNDS)
+            return fail(rc, "Each lower bound must be strictly less than each upper bound.%s");
+        if (rc == SEQIK_ERR_X0_OUT_OF_BOUNDS)
+            return fail(rc, "Initial guess is outside of provided bounds%s");
+    }
+    return SEQIK_OK;
+}
+
+int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                               const SeqikLegParams *legs, double *d_angles, double *d_fk, int32_t *d_status,
+                               int32_t *d_nfev, const double *d_init_angles, const SeqikLayout *layout,
+                               const SeqikAffine *affine, const SeqikOptions *opt, void *hip_stream)
+{
+    if (!legs || !d_pose || !d_angles) return fail(SEQIK_ERR_BAD_ARG, "null pointer argument%s");
+    if (n_seq < 0 || n_frames < 0 || n_legs <= 0 || n_legs > kMaxLegs)
+        return fail(SEQIK_ERR_BAD_ARG, "bad sizes (n_legs must be 1..8)%s");
+    int rc = seqik_validate_legs_generic(legs, n_legs);
+    if (rc != SEQIK_OK) return rc;
+    GenericKernelArgs a;
+    a.pose = d_pose; a.angles = d_angles; a.fk = d_fk; a.status = d_status; a.nfev = d_nfev; a.init = d_init_angles;
+    a.n_chains = n_seq * (int64_t)n_legs; a.n_frames = n_frames; a.n_legs = n_legs;
+    if (layout) {
+        a.pose_chain = layout->pose_chain; a.pose_row = layout->pose_row; a.pose_frame = layout->pose_frame;
+        a.ang_chain = layout->ang_chain; a.ang_dof = layout->ang_dof; a.ang_frame = layout->ang_frame;
+    } else {
+        a.pose_chain = n_frames * 15; a.pose_row = 3; a.pose_frame = 15;
+        a.ang_chain = n_frames * 7; a.ang_dof = 1; a.ang_frame = 7;
+    }
+    if (a.n_chains == 0 || n_frames == 0) return SEQIK_OK;
+    rc = device_generic_table(legs, affine, n_legs, &a.legs);
+    if (rc != SEQIK_OK) return rc;
+    int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
+    if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
+    const dim3 grid((unsigned)((a.n_chains + block - 1) / block)), blk(block);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (d_status || d_nfev) hipLaunchKernelGGL(seqik_generic_kernel<true>, grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL(seqik_generic_kernel<false>, grid, blk, 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return SEQIK_OK;
+}
+
+int seqik_solve_generic(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+                        const SeqikLegParams *legs, double *angles, double *fk, int32_t *status, int32_t *nfev,
+                        const double *init_angles, const SeqikAffine *affine, const SeqikOptions *opt)
+{
+    if (!legs || !pose || !angles) return fail(SEQIK_ERR_BAD_ARG, "null pointer argument%s");
+    if (n_seq < 0 || n_frames < 0 || n_legs <= 0 || n_legs > kMaxLegs)
+        return fail(SEQIK_ERR_BAD_ARG, "bad sizes (n_legs must be 1..8)%s");
+    int rc = seqik_validate_legs_generic(legs, n_legs);
+    if (rc != SEQIK_OK) return rc;
+    const int64_t n_lf = n_seq * (int64_t)n_legs * n_frames;
+    if (n_lf == 0) return SEQIK_OK;
+    if (opt) HIP_TRY(hipSetDevice(opt->device));
+    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr, *d_init = nullptr;
+    int32_t *d_status = nullptr, *d_nfev = nullptr;
+    int out = SEQIK_OK;
+    do {
+#define TB(expr) { hipError_t e_ = (expr); if (e_ != hipSuccess) { out = fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); break; } }
+        TB(hipMalloc(reinterpret_cast<void **>(&d_pose), sizeof(double) * 15 * n_lf));
+        TB(hipMalloc(reinterpret_cast<void **>(&d_angles), sizeof(double) * 7 * n_lf));
+        if (fk) TB(hipMalloc(reinterpret_cast<void **>(&d_fk), sizeof(double) * 27 * n_lf));
+        if (status) TB(hipMalloc(reinterpret_cast<void **>(&d_status), sizeof(int32_t) * n_lf));
+        if (nfev) TB(hipMalloc(reinterpret_cast<void **>(&d_nfev), sizeof(int32_t) * n_lf));
+        if (init_angles) {
+            TB(hipMalloc(reinterpret_cast<void **>(&d_init), sizeof(double) * 7 * n_seq * n_legs));
+            TB(hipMemcpy(d_init, init_angles, sizeof(double) * 7 * n_seq * n_legs, hipMemcpyHostToDevice));
+        }
+        TB(hipMemcpy(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice));
+        out = seqik_solve_generic_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk, d_status, d_nfev, d_init,
+                                         nullptr, affine, opt, nullptr);
+        if (out != SEQIK_OK) break;
+        TB(hipDeviceSynchronize());
+        TB(hipMemcpy(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost));
+        if (fk) TB(hipMemcpy(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost));
+        if (status) TB(hipMemcpy(status, d_status, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost));
+        if (nfev) TB(hipMemcpy(nfev, d_nfev, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost));
+#undef TB
+    } while (0);
+    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev);
+    (void)hipFree(d_init);
+    return out;
 }
 
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,

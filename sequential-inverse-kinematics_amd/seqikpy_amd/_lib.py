@@ -16,7 +16,8 @@ from .data import DOFS, SEGMENTS
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
-SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_core.hpp", "seqik_consts.hpp", "seqik_head.hpp"]
+SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_core.hpp", "seqik_consts.hpp", "seqik_head.hpp",
+           "seqik_generic.hpp"]
 COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
@@ -132,6 +133,18 @@ def load():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+        L.seqik_validate_legs_generic.restype = ctypes.c_int
+        L.seqik_validate_legs_generic.argtypes = [ctypes.POINTER(SeqikLegParams), ctypes.c_int32]
+        L.seqik_solve_generic.restype = ctypes.c_int
+        L.seqik_solve_generic.argtypes = [_dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                          ctypes.POINTER(SeqikLegParams), _dp, _dp, _ip, _ip, _dp,
+                                          ctypes.POINTER(SeqikAffine), ctypes.POINTER(SeqikOptions)]
+        L.seqik_solve_generic_device.restype = ctypes.c_int
+        L.seqik_solve_generic_device.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64,
+                                                 ctypes.POINTER(SeqikLegParams), ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
+                                                 ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
         L.seqik_head_angles.restype = ctypes.c_int
         L.seqik_head_angles.argtypes = [_dp, _dp, ctypes.c_int64, _dp, ctypes.c_int64, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_int32, _dp, ctypes.POINTER(SeqikOptions)]
@@ -144,7 +157,39 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_validate_legs",
-                    "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device"]
+                    "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
+                    "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device"]
+
+
+def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_size=0, affine=None, init_angles=None):
+    """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
+    fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None)."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    if pose.ndim != 5 or pose.shape[3:] != (5, 3):
+        raise ValueError(f"pose must have shape (S, L, N, 5, 3), got {pose.shape}")
+    S, L, N = pose.shape[:3]
+    if len(legs) != L:
+        raise ValueError("one SeqikLegParams per leg expected")
+    angles = np.zeros((S, L, N, 7))
+    fk = np.full((S, L, N, 9, 3), np.nan) if want_fk else None
+    status = np.full((S, L, N), -1, dtype=np.int32) if want_diag else None
+    nfev = np.zeros((S, L, N), dtype=np.int32) if want_diag else None
+    if init_angles is not None:
+        init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
+        if init_angles.shape != (S, L, 7):
+            raise ValueError(f"init_angles must have shape {(S, L, 7)}")
+    opt = SeqikOptions()
+    opt.device = device
+    opt.block_size = block_size
+    rc = load().seqik_solve_generic(pose.ctypes.data_as(_dp), S, L, N, (SeqikLegParams * L)(*legs),
+                                    angles.ctypes.data_as(_dp), fk.ctypes.data_as(_dp) if fk is not None else None,
+                                    status.ctypes.data_as(_ip) if status is not None else None,
+                                    nfev.ctypes.data_as(_ip) if nfev is not None else None,
+                                    init_angles.ctypes.data_as(_dp) if init_angles is not None else None,
+                                    _affine_array(affine, L), ctypes.byref(opt))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return dict(angles=angles, fk=fk, status=status, nfev=nfev)
 
 
 def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=0):

@@ -288,17 +288,73 @@ class LegInvKinSeq(LegInvKinBase):
 
 
 class LegInvKinGeneric(LegInvKinBase):
-    """Generic (single 9-link chain, claw only) inverse kinematics -- reference :406-613.
+    """Generic inverse kinematics: one 9-link chain per leg that only follows the claw
+    (reference ``seqikpy/leg_inverse_kinematics.py:406-613``).
 
-    Listed as a follow-up row in SURVEY.md 8(f)-3; not implemented in this round."""
+    The problem has 7 unknowns and 3 equations; which of the infinitely many solutions the
+    reference reports is decided by LAPACK round-off inside scipy, so this class
+    matches the reference in the claw position and respects the joint bounds, but the individual
+    angles are *a* solution, not necessarily the reference's.
 
-    def __init__(self, aligned_pos, kinematic_chain_class: KinematicChainGeneric, initial_angles=None,
-                 log_level="INFO") -> None:
+    >>> gen_ik = LegInvKinGeneric(aligned_pos, KinematicChainGeneric(BOUNDS, ["RF", "LF"]), INITIAL_ANGLES)
+    >>> leg_joint_angles, forward_kinematics = gen_ik.run_ik_and_fk(export_path=DATA_PATH)
+    """
+
+    def __init__(self, aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainGeneric,
+                 initial_angles: Optional[Dict[str, np.ndarray]] = None,
+                 log_level: Literal["DEBUG", "INFO", "WARNING", "ERROR"] = "INFO") -> None:
         super().__init__(aligned_pos, kinematic_chain_class, initial_angles, log_level)
         self.joint_angles_dict = {}
 
-    def calculate_ik_stage(self, end_effector_pos, origin, initial_angles, segment_name, **kwargs):
-        raise NotImplementedError("LegInvKinGeneric is not implemented yet (SURVEY.md 8f-3)")
+    def _leg_params(self, leg_name, seed9):
+        kc = self.kinematic_chain_class
+        seeds = {leg_name: {f"stage_{k}": np.zeros(STAGE_LINKS[k]) for k in (1, 2, 3)}}
+        seeds[leg_name]["stage_4"] = np.asarray(seed9, dtype=np.float64)
+        return _lib.make_leg_params(leg_name, kc.bounds_dof, kc.body_size, seeds)
 
-    def run_ik_and_fk(self, export_path=None, **kwargs):
-        raise NotImplementedError("LegInvKinGeneric is not implemented yet (SURVEY.md 8f-3)")
+    def _store(self, leg_name, angles):
+        # key order of the reference: the chain's link order, Base and Claw skipped (:533-539)
+        for dof in ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]:
+            self.joint_angles_dict[f"Angle_{leg_name}_{dof}"] = angles[:, DOFS.index(dof)].copy()
+
+    def calculate_ik_stage(self, end_effector_pos: np.ndarray, origin: np.ndarray, initial_angles: np.ndarray,
+                           segment_name: str, **kwargs) -> np.ndarray:
+        """Inverse kinematics of one leg over all frames; returns the joint positions ``(N, 9, 3)``."""
+        if segment_name not in LEG_NAMES:
+            raise ValueError(f"Segment name ({segment_name}) is not valid.")
+        end_effector_pos = np.asarray(end_effector_pos, dtype=np.float64)
+        frames_no = end_effector_pos.shape[0]
+        origin = np.asarray(origin, dtype=np.float64)
+        if origin.size == 3:
+            origin = np.tile(origin.reshape(3), (frames_no, 1))
+        if len(initial_angles) != 9:
+            raise ValueError(f"Your joints vector length is {len(initial_angles)} but you have 9 links")
+        pose = np.zeros((1, 1, frames_no, 5, 3))
+        pose[0, 0, :, 0] = origin
+        pose[0, 0, :, 4] = end_effector_pos
+        out = _lib.solve_generic(pose, [self._leg_params(segment_name, initial_angles)], device=self.device)
+        self._store(segment_name, out["angles"][0, 0])
+        return out["fk"][0, 0]
+
+    def run_ik_and_fk(self, export_path: Union[Path, str] = None, **kwargs
+                      ) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+        """Inverse and forward kinematics of every leg with the generic chain."""
+        forward_kinematics_dict = {}
+        self.logger.info("Computing joint angles and forward kinematics...")
+        segments = self._leg_segments()
+        groups = {}
+        for item in segments:
+            groups.setdefault(np.asarray(item[2]).shape[0], []).append(item)
+        for n_frames, items in groups.items():
+            legs = [self._leg_params(leg, self.initial_angles[leg]["stage_4"]) for _, leg, _ in items]
+            # the claw (last key point) is the end effector (:587)
+            pose = np.stack([np.asarray(arr, dtype=np.float64)[:, [0, 1, 2, 3, -1], :] if np.asarray(arr).shape[1] >= 5
+                             else np.asarray(arr, dtype=np.float64) for _, _, arr in items])[None]
+            out = _lib.solve_generic(pose, legs, device=self.device)
+            for li, (segment_name, leg_name, _) in enumerate(items):
+                self._store(leg_name, out["angles"][0, li])
+                forward_kinematics_dict[segment_name] = out["fk"][0, li].copy()
+        forward_kinematics_dict = {name: forward_kinematics_dict[name] for name, _, _ in segments}
+        self.logger.debug("Joint angles and forward kinematics are computed.")
+        self._export(export_path, forward_kinematics_dict)
+        return self.joint_angles_dict, forward_kinematics_dict

@@ -69,6 +69,8 @@ class HostHarness:
         self.lib.harness_run_chain.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
                                                ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC), dp]
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
+        self.lib.harness_run_generic.restype = ctypes.c_int
+        self.lib.harness_run_generic.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), dp, dp, ip, ip, dp]
         self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
                                                  ctypes.c_double, ctypes.c_int32, dp]
 
@@ -106,6 +108,29 @@ class HostHarness:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
 
+    def run_generic(self, pose, seg, bounds, seeds, init=None):
+        dp = ctypes.POINTER(ctypes.c_double)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        n = pose.shape[0]
+        ang, fk = np.zeros((n, 7)), np.zeros((n, 9, 3))
+        st, nf = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        lp = LegParamsC()
+        for i in range(4):
+            lp.seg[i] = seg[i]
+        for i in range(7):
+            lp.bounds[i][0] = bounds[i][0]
+            lp.bounds[i][1] = bounds[i][1]
+        for i in range(27):
+            lp.seeds[i] = seeds[i]
+        rc = self.lib.harness_run_generic(pose.ctypes.data_as(dp), n, ctypes.byref(lp), ang.ctypes.data_as(dp),
+                                          fk.ctypes.data_as(dp), st.ctypes.data_as(ip), nf.ctypes.data_as(ip),
+                                          np.ascontiguousarray(init, dtype=np.float64).ctypes.data_as(dp)
+                                          if init is not None else None)
+        if rc != 0:
+            raise ValueError(f"harness rc={rc}")
+        return dict(angles=ang, fk=fk, status=st, nfev=nf)
+
     def head_angles(self, r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True):
         dp = ctypes.POINTER(ctypes.c_double)
         r_head = np.ascontiguousarray(r_head, dtype=np.float64)
@@ -135,7 +160,7 @@ def host_harness():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libhost_harness.so")
     deps = [src] + [os.path.join(PKG_PARENT, "csrc", f) for f in ("seqik_core.hpp", "seqik_consts.hpp",
-                                                                 "seqik_head.hpp")]
+                                                                 "seqik_head.hpp", "seqik_generic.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call([hipcc, "--offload-host-only", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC",
                                "-shared", "-o", so, src])

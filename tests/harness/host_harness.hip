@@ -65,3 +65,22 @@ extern "C" void harness_head_angles(const double *r_head, const double *l_head, 
     a.angles = angles; a.n_frames = n; a.compute_ant = compute_ant;
     for (int64_t t = 0; t < n; ++t) seqik::head_angles_frame(a, t);
 }
+
+// generic (single-chain) IK: the kernel's per-chain device function, run on the host
+extern "C" int harness_run_generic(const double *pose, int64_t n_frames, const SeqikLegParams *leg, double *angles,
+                                   double *fk, int32_t *status, int32_t *nfev, const double *init)
+{
+    int rc = seqik::validate_leg_generic(*leg);
+    if (rc != SEQIK_OK) return rc;
+    seqik::GenericConst gc;
+    seqik::make_generic_consts(*leg, gc);
+    seqik::LegAffine aff;
+    aff.enabled = 0;
+    seqik::GenericIO io;
+    io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
+    io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
+    io.fk = fk; io.status = status; io.nfev = nfev; io.init = init; io.n_frames = n_frames;
+    if (status || nfev) seqik::run_generic<true>(gc, aff, io);
+    else seqik::run_generic<false>(gc, aff, io);
+    return SEQIK_OK;
+}

@@ -1,0 +1,73 @@
+"""Generic (single 9-link chain) IK row.  The problem is rank-deficient, so the
+reference's angles are not reproducible (they depend on LAPACK round-off); what is checked:
+  * kernel code == C oracle bit for bit (host build here, GPU in the gpu tier);
+  * the claw position equals the reference run's to ~1e-6 and every angle respects its bounds."""
+import numpy as np
+import pytest
+
+from conftest import DOFS, load_golden
+
+
+def _leg(z, leg):
+    return z[f"{leg}_pose"], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"]
+
+
+@pytest.mark.parametrize("leg", ["RF", "LF"])
+def test_generic_core_equals_oracle_and_reaches_the_reference_claw(oracle, host_harness, leg):
+    z = load_golden("generic_rf_100")
+    pose, seg, b, seeds = _leg(z, leg)
+    ref = oracle.generic_leg(pose, seg, b, seeds[18:27])
+    got = host_harness.run_generic(pose, seg, b, seeds)
+    for k in ("angles", "fk", "status", "nfev"):
+        assert np.array_equal(got[k], ref[k]), k
+    # vs the reference's LegInvKinGeneric run here (ikpy shim + real scipy): same claw, other angles
+    assert np.abs(got["fk"][:, 8] - z[f"{leg}_fk"][:, 8]).max() < 1e-6
+    assert np.abs(got["fk"][:, 8] - pose[:, 4]).max() < 1e-6
+    assert np.array_equal(got["fk"][:, 0], pose[:, 0])
+    assert (got["angles"] >= b[:, 0]).all() and (got["angles"] <= b[:, 1]).all()
+
+
+def test_generic_continuation(oracle, host_harness):
+    z = load_golden("generic_rf_100")
+    pose, seg, b, seeds = _leg(z, "RF")
+    full = host_harness.run_generic(pose[:40], seg, b, seeds)
+    a = host_harness.run_generic(pose[:17], seg, b, seeds)
+    c = host_harness.run_generic(pose[17:40], seg, b, seeds, init=a["angles"][-1])
+    assert np.array_equal(np.concatenate([a["angles"], c["angles"]]), full["angles"])
+
+
+def test_generic_seed_validation(host_harness):
+    z = load_golden("generic_rf_100")
+    pose, seg, b, seeds = _leg(z, "RF")
+    bad = seeds.copy()
+    bad[18 + 1] = 1.5  # link 1 is ThC_roll (upper bound 50 deg): the seed is applied positionally
+    with pytest.raises(ValueError):
+        host_harness.run_generic(pose[:2], seg, b, bad)
+
+
+@pytest.mark.gpu
+def test_generic_on_gpu(hiplib, oracle):
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+    from seqikpy_amd.kinematic_chain import KinematicChainGeneric
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinGeneric
+    z = load_golden("generic_rf_100")
+    legs = ["RF", "LF"]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    out = hiplib.solve_generic(pose, params, want_diag=True)
+    for i, leg in enumerate(legs):
+        ref = oracle.generic_leg(*_leg(z, leg)[:3], z[f"{leg}_seeds"][18:27])
+        assert np.array_equal(out["angles"][0, i], ref["angles"])
+        assert np.array_equal(out["fk"][0, i], ref["fk"])
+        assert np.array_equal(out["nfev"][0, i], ref["nfev"])
+        assert np.array_equal(out["status"][0, i], ref["status"])
+    # Python API: keys in the reference's (chain link) order, FK dict, claw reached
+    ik = LegInvKinGeneric({"RF_leg": z["RF_pose"], "LF_leg": z["LF_pose"]}, KinematicChainGeneric(BOUNDS, legs),
+                          INITIAL_ANGLES, log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk()
+    order = ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
+    assert list(ang.keys()) == [f"Angle_{l}_{d}" for l in legs for d in order]
+    assert np.array_equal(np.stack([ang[f"Angle_RF_{d}"] for d in DOFS], 1), out["angles"][0, 0])
+    assert fk["LF_leg"].shape == (100, 9, 3) and np.abs(fk["LF_leg"][:, 8] - z["LF_pose"][:, 4]).max() < 1e-6
+    fk1 = ik.calculate_ik_stage(z["RF_pose"][:, 4], z["RF_pose"][:, 0], INITIAL_ANGLES["RF"]["stage_4"], "RF")
+    assert np.array_equal(fk1, fk["RF_leg"])

@@ -101,12 +101,6 @@ def test_calculate_fk_matches_oracle(oracle, angles):
     assert ik.get_scale_factor(np.array([[0, 0, 0], [0, 0, 1.0], [0, 0, 3.0]]), 6.0) == pytest.approx(2.0)
 
 
-def test_generic_ik_is_declared_but_not_implemented():
-    ik = LegInvKinGeneric({}, KinematicChainGeneric(BOUNDS, ["RF"]), INITIAL_ANGLES, log_level="ERROR")
-    with pytest.raises(NotImplementedError):
-        ik.run_ik_and_fk()
-
-
 def test_synthetic_fk_matches_oracle(oracle):
     from seqikpy_amd import data, synthetic
     body = calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, data.LEGS)
