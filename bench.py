@@ -120,12 +120,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N "
                              "--master-addr 127.0.0.1 bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank % max(n_dev, 1)  # (more ranks than GPUs only happens in the gloo dry run)
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SEQIK_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo": dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     T = args.frames_per_seq
     S = args.frames // T
@@ -183,7 +189,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

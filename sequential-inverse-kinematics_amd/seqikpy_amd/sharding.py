@@ -58,7 +58,10 @@ class GatherPipeline:
         import torch
         self.dist, self.world, self.rank, self.dst = dist, world, rank, dst
         self.work = [None] * n_buffers
-        self.recv = [[torch.empty_like(like) for _ in range(world)] if rank == dst else None
+        # gloo cannot gather device tensors: stage through the host (dry runs / tests only)
+        self.stage_on_host = like.is_cuda and dist.get_backend() != "nccl"
+        proto = like.cpu() if self.stage_on_host else like
+        self.recv = [[torch.empty_like(proto) for _ in range(world)] if rank == dst else None
                      for _ in range(n_buffers)]
 
     def wait_buffer(self, b: int):
@@ -68,6 +71,8 @@ class GatherPipeline:
 
     def submit(self, b: int, tensor):
         self.wait_buffer(b)
+        if self.stage_on_host:
+            tensor = tensor.cpu()  # synchronises with the producing stream
         self.work[b] = self.dist.gather(tensor, gather_list=self.recv[b], dst=self.dst, async_op=True)
 
     def drain(self):
