@@ -15,28 +15,28 @@
 namespace seqik {
 
 // angle_between_segments (:163-178): acos of the normalised dot product, signed by
-// det([rot_axis, v1, v2]) = rot_axis . (v1 x v2)
+// det([rot_axis, v1, v2]) = rot_axis . (v1 x v2).  The reference normalises both vectors component by
+// component (6 divisions, 2 square roots); here cos = (v1 . v2) / sqrt(|v1|^2 |v2|^2) -- one division,
+// one square root, the same value up to ~1 ulp -- because this kernel should be bound by HBM, not by
+// FP64 division throughput.
 SEQIK_HD double signed_angle(const double *v1, const double *v2, int rot_axis)
 {
-    double n1 = sqrt(v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2]);
-    double n2 = sqrt(v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2]);
-    double d = (v1[0] / n1) * (v2[0] / n2) + (v1[1] / n1) * (v2[1] / n2) + (v1[2] / n1) * (v2[2] / n2);
+    double n1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+    double n2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+    double d = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) / sqrt(n1 * n2);
     double det;
     if (rot_axis == 0) det = v1[1] * v2[2] - v1[2] * v2[1];
     else if (rot_axis == 1) det = v1[2] * v2[0] - v1[0] * v2[2];
     else det = v1[0] * v2[1] - v1[1] * v2[0];
-    double mask = (det > 0) ? 1.0 : -1.0;
-    return acos(d) * mask;
+    d = fmin(1.0, fmax(-1.0, d));  // guard the last-ulp overshoot of the fused normalisation
+    double a = acos(d);
+    return (det > 0) ? a : -a;
 }
 
 // derotate_vector (:330-333): scipy Rotation.from_euler("x", -roll).apply(v), i.e. the rotation
-// matrix of the unit quaternion (sin(-roll/2), 0, 0, cos(-roll/2))
-SEQIK_HD void derotate_x(double roll, const double *v, double *out)
+// matrix of the unit quaternion (sin(-roll/2), 0, 0, cos(-roll/2)); m11 / two_xw are computed once per frame
+SEQIK_HD void derotate_x(double m11, double two_xw, const double *v, double *out)
 {
-    double h = -roll * 0.5;
-    double x = sin(h), w = cos(h);
-    double m11 = w * w - x * x;
-    double two_xw = 2.0 * (x * w);
     out[0] = v[0];
     out[1] = m11 * v[1] - two_xw * v[2];
     out[2] = two_xw * v[1] + m11 * v[2];
@@ -77,15 +77,18 @@ SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
     a.angles[n + t] = pitch;
     a.angles[2 * n + t] = yaw;
     if (!a.compute_ant) return;
+    const double hh = -roll * 0.5;
+    const double qx = sin(hh), qw = cos(hh);
+    const double m11 = qw * qw - qx * qx, two_xw = 2.0 * (qx * qw);
     double hor_d[3];
-    derotate_x(roll, hor, hor_d);
+    derotate_x(m11, two_xw, hor, hor_d);
     for (int side = 0; side < 2; ++side) {  // 0 = L, 1 = R (the reference's dict order)
         const double *base = side == 0 ? lb : rb;
         double ant[3] = {base[3] - base[0], base[4] - base[1], base[5] - base[2]};
         double head[3] = {neck[0] - base[0], neck[1] - base[1], neck[2] - base[2]};
         double ant_d[3], head_d[3];
-        derotate_x(roll, ant, ant_d);
-        derotate_x(roll, head, head_d);
+        derotate_x(m11, two_xw, ant, ant_d);
+        derotate_x(m11, two_xw, head, head_d);
         // antenna yaw (:262-291): antenna vs horizontal head vector, both on the transverse plane, about X
         double a1[3] = {0.0, ant_d[1], ant_d[2]};
         double h1[3] = {0.0, hor_d[1], hor_d[2]};
