@@ -170,6 +170,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_siz
     S, L, N = pose.shape[:3]
     if len(legs) != L:
         raise ValueError("one SeqikLegParams per leg expected")
+    _check_finite(pose)
     angles = np.zeros((S, L, N, 7))
     fk = np.full((S, L, N, 9, 3), np.nan) if want_fk else None
     status = np.full((S, L, N), -1, dtype=np.int32) if want_diag else None
@@ -261,6 +262,13 @@ def validate_legs(legs, first_stage=1, last_stage=4):
         _raise(rc)
 
 
+def _check_finite(pose):
+    """scipy refuses non-finite residuals at the start point (``ValueError: Residuals are not finite in
+    the initial point.``); a NaN key point would do exactly that in the reference's frame loop."""
+    if not np.isfinite(pose).all():
+        raise ValueError("Residuals are not finite in the initial point.")
+
+
 def _affine_array(affine, n_legs):
     if affine is None:
         return None
@@ -284,6 +292,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     S, L, N = pose.shape[:3]
     if len(legs) != L:
         raise ValueError("one SeqikLegParams per leg expected")
+    _check_finite(pose)
     if angles is None:
         angles = np.zeros((S, L, N, 7), dtype=np.float64)
     else:

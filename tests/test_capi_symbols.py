@@ -72,6 +72,17 @@ def test_solve_rejects_bad_arguments_before_touching_the_gpu(hiplib):
         hiplib.solve_seq(pose[None, None, :4], [hiplib.leg_params_from_arrays(seg, b, bad)])
 
 
+def test_non_finite_key_points_raise_like_scipy(hiplib):
+    z = load_golden("df3d_100")
+    pose, seg, b, seeds = leg_arrays(z, "RF")
+    bad = pose[None, None, :8].copy()
+    bad[0, 0, 3, 2, 1] = np.nan
+    with pytest.raises(ValueError, match="Residuals are not finite"):
+        hiplib.solve_seq(bad, [hiplib.leg_params_from_arrays(seg, b, seeds)])
+    with pytest.raises(ValueError, match="Residuals are not finite"):
+        hiplib.solve_generic(bad, [hiplib.leg_params_from_arrays(seg, b, seeds)])
+
+
 def test_missing_library_fails_loudly():
     code = ("import sys; sys.path.insert(0, %r); from seqikpy_amd import _lib\n"
             "try:\n    _lib.load()\nexcept _lib.SeqikLibraryError as e:\n    print('LOUD', e)\n" % PKG_PARENT)
