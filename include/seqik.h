@@ -29,6 +29,7 @@
 #ifndef SEQIK_H
 #define SEQIK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -191,6 +192,44 @@ int seqik_head_angles(const double *r_head, const double *l_head, int64_t n_fram
 int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int64_t n_frames, const double *d_neck,
                              int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch,
                              int32_t compute_ant, double *d_angles, void *hip_stream);
+
+/*
+ * Streaming (BASELINE config 5): recordings that do not have to fit or live in HBM are pushed through
+ * the kernels in SLABS of n_seq sequences x n_legs x n_frames from host buffers.  The reference's
+ * counterpart is one AlignPose.align_pose + LegInvKinSeq.run_ik_and_fk call per piece of a recording
+ * (seqikpy/alignment.py:345, seqikpy/leg_inverse_kinematics.py:324).  Upload, the four stage kernels
+ * and download of consecutive slabs overlap on three HIP streams over n_slots device slots.
+ *
+ *   seqik_host_alloc / _free      pinned host memory (hipHostMalloc); slabs in pinned memory are
+ *   seqik_host_register / _unregister   copied asynchronously, pageable ones still work but serialise
+ *   seqik_stream_open    legs / affine / layout as in seqik_solve_seq_device (copied); slab_seq = the largest
+ *                        n_seq a submit may carry; want_fk: also return the stage-4 FK; n_slots: slabs in
+ *                        flight (2-3 hide the copies); carry != 0: consecutive slabs are consecutive pieces
+ *                        IN TIME of the same n_seq recordings -- frame 0 of a slab is warm-started from the
+ *                        last frame of the slab before it (device-resident hand-over), so the result equals
+ *                        one call over the concatenated recording; generic != 0: LegInvKinGeneric chains;
+ *                        opt->device selects the GPU
+ *   seqik_stream_submit  enqueues one slab: pose [n_seq][n_legs][n_frames][5][3] (or `layout`) in, angles
+ *                        [n_seq][n_legs][n_frames][7] (or `layout`) and fk [n_seq][n_legs][n_frames][9][3]
+ *                        out.  Returns as soon as the work is queued; blocks only while all slots are busy.
+ *                        The host buffers must stay valid and untouched until seqik_stream_wait returns
+ *                        (or until n_slots further slabs have been submitted).
+ *   seqik_stream_wait    blocks until every submitted slab's results are in its host buffers
+ *   seqik_stream_reset_carry   the next slab starts new recordings (frame 0 from the seeds again)
+ *   seqik_stream_close   drains and frees everything
+ */
+typedef struct SeqikStream SeqikStream;
+void *seqik_host_alloc(size_t bytes);
+void seqik_host_free(void *p);
+int seqik_host_register(void *p, size_t bytes);
+int seqik_host_unregister(void *p);
+int seqik_stream_open(SeqikStream **out, int32_t n_legs, const SeqikLegParams *legs, const SeqikAffine *affine,
+                      int64_t slab_seq, int64_t n_frames, const SeqikLayout *layout, int32_t want_fk,
+                      int32_t n_slots, int32_t carry, int32_t generic, const SeqikOptions *opt);
+int seqik_stream_submit(SeqikStream *s, const double *pose, int64_t n_seq, double *angles, double *fk);
+int seqik_stream_wait(SeqikStream *s);
+int seqik_stream_reset_carry(SeqikStream *s);
+int seqik_stream_close(SeqikStream *s);
 
 #ifdef __cplusplus
 }

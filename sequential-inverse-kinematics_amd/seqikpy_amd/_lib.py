@@ -16,9 +16,9 @@ from .data import DOFS, SEGMENTS
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
-SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_core.hpp", "seqik_consts.hpp", "seqik_head.hpp",
-           "seqik_generic.hpp"]
-COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip"]
+SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_core.hpp", "seqik_consts.hpp",
+           "seqik_head.hpp", "seqik_generic.hpp"]
+COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 SEQIK_OK = 0
@@ -152,13 +152,35 @@ def load():
         L.seqik_head_angles_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.c_void_p]
+        L.seqik_host_alloc.restype = ctypes.c_void_p
+        L.seqik_host_alloc.argtypes = [ctypes.c_size_t]
+        L.seqik_host_free.restype = None
+        L.seqik_host_free.argtypes = [ctypes.c_void_p]
+        L.seqik_host_register.restype = ctypes.c_int
+        L.seqik_host_register.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.seqik_host_unregister.restype = ctypes.c_int
+        L.seqik_host_unregister.argtypes = [ctypes.c_void_p]
+        L.seqik_stream_open.restype = ctypes.c_int
+        L.seqik_stream_open.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.POINTER(SeqikLegParams),
+                                        ctypes.POINTER(SeqikAffine), ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.POINTER(SeqikLayout), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, ctypes.POINTER(SeqikOptions)]
+        L.seqik_stream_submit.restype = ctypes.c_int
+        L.seqik_stream_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                          ctypes.c_void_p]
+        for name in ("seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [ctypes.c_void_p]
         _lib = L
         return _lib
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_validate_legs",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
-                    "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device"]
+                    "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
+                    "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
+                    "seqik_stream_open", "seqik_stream_submit", "seqik_stream_wait", "seqik_stream_reset_carry",
+                    "seqik_stream_close"]
 
 
 def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_size=0, affine=None, init_angles=None):

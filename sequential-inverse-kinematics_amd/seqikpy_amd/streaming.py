@@ -1,0 +1,184 @@
+"""Slab streaming over host buffers (BASELINE config 5; C ABI ``seqik_stream_*`` in include/seqik.h).
+
+The reference processes a recording with one ``AlignPose.align_pose()`` +
+``LegInvKinSeq.run_ik_and_fk()`` call (``seqikpy/alignment.py:345``,
+``seqikpy/leg_inverse_kinematics.py:324``); everything has to be in memory at once.  Here recordings
+are pushed through the MI355X in *slabs* of ``(n_seq, n_legs, n_frames)`` key points living in pinned
+host memory: upload, the four stage kernels and download of consecutive slabs overlap on three HIP
+streams.  With ``carry=True`` consecutive slabs are consecutive pieces in time of the same
+recordings (frame 0 of a slab is warm-started from the last frame of the slab before, on the
+device), so the result equals one call over the concatenated recording bit for bit.
+
+All work is done by ``libseqik_hip.so``; this module only owns buffers and the handle.
+"""
+import ctypes
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+
+
+class PinnedArray:
+    """A float64 numpy array over pinned (page-locked) host memory from ``seqik_host_alloc``."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        n = int(np.prod(self.shape))
+        self._lib = _lib.load()
+        self._ptr = self._lib.seqik_host_alloc(max(n, 1) * 8)
+        if not self._ptr:
+            _lib._raise(_lib.ERR_HIP)
+        buf = (ctypes.c_double * max(n, 1)).from_address(self._ptr)
+        self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.shape)
+
+    def free(self):
+        if self._ptr:
+            self.array = None
+            self._lib.seqik_host_free(ctypes.c_void_p(self._ptr))
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SeqikStream:
+    """``with SeqikStream(legs, slab_seq, n_frames, ...) as st: st.submit(pose, angles, fk); ...; st.wait()``.
+
+    legs: list of ``SeqikLegParams``; affine: optional list of ``SeqikAffine`` (pose slabs are then RAW
+    key points, ``AlignPose.align_leg`` runs in the kernel prologue); layout: optional ``SeqikLayout`` of
+    the pose / angle slabs (``_lib.planar_layout(n_frames)``), default dense reference-shaped arrays.
+    """
+
+    def __init__(self, legs: List[_lib.SeqikLegParams], slab_seq: int, n_frames: int, affine=None, layout=None,
+                 want_fk: bool = True, n_slots: int = 3, carry: bool = False, generic: bool = False,
+                 device: int = 0, block_size: int = 0):
+        self._lib = _lib.load()
+        self.n_legs = len(legs)
+        self.slab_seq, self.n_frames = int(slab_seq), int(n_frames)
+        self.want_fk, self.layout = bool(want_fk), layout
+        self._handle = ctypes.c_void_p()
+        opt = _lib.SeqikOptions()
+        opt.device = device
+        opt.block_size = block_size
+        rc = self._lib.seqik_stream_open(ctypes.byref(self._handle), self.n_legs,
+                                         (_lib.SeqikLegParams * self.n_legs)(*legs),
+                                         _lib._affine_array(affine, self.n_legs), self.slab_seq, self.n_frames,
+                                         ctypes.byref(layout) if layout is not None else None,
+                                         1 if want_fk else 0, int(n_slots), 1 if carry else 0, 1 if generic else 0,
+                                         ctypes.byref(opt))
+        if rc != _lib.SEQIK_OK:
+            self._handle = ctypes.c_void_p()
+            _lib._raise(rc)
+        self._keep = []  # host arrays of slabs in flight (kept alive until wait())
+
+    # shapes of one slab's host arrays (dense layout)
+    def pose_shape(self, n_seq=None):
+        return (n_seq or self.slab_seq, self.n_legs, self.n_frames, 5, 3)
+
+    def angles_shape(self, n_seq=None):
+        return (n_seq or self.slab_seq, self.n_legs, self.n_frames, 7)
+
+    def fk_shape(self, n_seq=None):
+        return (n_seq or self.slab_seq, self.n_legs, self.n_frames, 9, 3)
+
+    def submit(self, pose: np.ndarray, angles: np.ndarray, fk: Optional[np.ndarray] = None):
+        """Queues one slab.  Arrays must be C-contiguous float64 and stay untouched until ``wait()``."""
+        for name, a in (("pose", pose), ("angles", angles), ("fk", fk)):
+            if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous):
+                raise ValueError(f"{name} must be a C-contiguous float64 array")
+        n_seq = pose.shape[0]
+        per_seq = self.n_legs * self.n_frames
+        if pose.size != n_seq * per_seq * 15 or angles.size != n_seq * per_seq * 7:
+            raise ValueError("pose / angles do not hold n_seq x n_legs x n_frames leg-frames")
+        if self.want_fk and (fk is None or fk.size != n_seq * per_seq * 27):
+            raise ValueError("fk must hold n_seq x n_legs x n_frames x 9 x 3 values")
+        rc = self._lib.seqik_stream_submit(self._handle, ctypes.c_void_p(pose.ctypes.data), n_seq,
+                                           ctypes.c_void_p(angles.ctypes.data),
+                                           ctypes.c_void_p(fk.ctypes.data) if (self.want_fk and fk is not None) else None)
+        if rc != _lib.SEQIK_OK:
+            _lib._raise(rc)
+        self._keep.append((pose, angles, fk))
+
+    def wait(self):
+        rc = self._lib.seqik_stream_wait(self._handle)
+        self._keep.clear()
+        if rc != _lib.SEQIK_OK:
+            _lib._raise(rc)
+
+    def reset_carry(self):
+        self._lib.seqik_stream_reset_carry(self._handle)
+
+    def close(self):
+        if self._handle:
+            self._lib.seqik_stream_close(self._handle)
+            self._handle = ctypes.c_void_p()
+            self._keep.clear()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_streamed(pose: np.ndarray, legs, slab_seq: int, affine=None, want_fk: bool = True, n_slots: int = 3,
+                   device: int = 0):
+    """Convenience: ``pose (S, L, N, 5, 3)`` pushed through a stream in slabs of ``slab_seq`` sequences.
+    Returns ``dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None)`` -- equal to ``_lib.solve_seq`` bit for bit."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    _lib._check_finite(pose)
+    S, L, N = pose.shape[:3]
+    angles = np.zeros((S, L, N, 7))
+    fk = np.full((S, L, N, 9, 3), np.nan) if want_fk else None
+    with SeqikStream(legs, min(slab_seq, max(S, 1)), N, affine=affine, want_fk=want_fk, n_slots=n_slots,
+                     device=device) as st:
+        for s0 in range(0, S, slab_seq):
+            s1 = min(S, s0 + slab_seq)
+            st.submit(pose[s0:s1], angles[s0:s1], fk[s0:s1] if want_fk else None)
+        st.wait()
+    return dict(angles=angles, fk=fk)
+
+
+def solve_streamed_in_time(pose: np.ndarray, legs, slab_frames: int, affine=None, want_fk: bool = True,
+                           n_slots: int = 3, device: int = 0):
+    """``pose (S, L, N, 5, 3)`` pushed through a carried stream in slabs of ``slab_frames`` frames (the S
+    recordings advance in lock step).  Equal to ``_lib.solve_seq(pose, ...)`` bit for bit."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    _lib._check_finite(pose)
+    S, L, N = pose.shape[:3]
+    angles = np.zeros((S, L, N, 7))
+    fk = np.full((S, L, N, 9, 3), np.nan) if want_fk else None
+    T = min(slab_frames, N)
+    n_full = N // T if T else 0
+    if n_full:
+        with SeqikStream(legs, S, T, affine=affine, want_fk=want_fk, n_slots=n_slots, carry=True, device=device) as st:
+            bufs = []
+            for k in range(n_full):
+                sl = slice(k * T, (k + 1) * T)
+                a = np.empty((S, L, T, 7))
+                f = np.empty((S, L, T, 9, 3)) if want_fk else None
+                st.submit(np.ascontiguousarray(pose[:, :, sl]), a, f)
+                bufs.append((sl, a, f))
+            st.wait()
+        for sl, a, f in bufs:
+            angles[:, :, sl] = a
+            if want_fk:
+                fk[:, :, sl] = f
+    t0 = n_full * T
+    if t0 < N:  # a shorter last piece: one direct call, continued from the last streamed frame
+        rest = _lib.solve_seq(pose[:, :, t0:], legs, want_fk=want_fk, affine=affine, device=device,
+                              init_angles=np.ascontiguousarray(angles[:, :, t0 - 1]) if t0 else None)
+        angles[:, :, t0:] = rest["angles"]
+        if want_fk:
+            fk[:, :, t0:] = rest["fk"]
+    return dict(angles=angles, fk=fk)

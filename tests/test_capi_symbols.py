@@ -23,7 +23,10 @@ def test_header_declares_expected_entry_points():
                                            "seqik_validate_legs", "seqik_solve_seq", "seqik_solve_seq_device",
                                            "seqik_head_angles", "seqik_head_angles_device",
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
-                                           "seqik_solve_generic_device"])
+                                           "seqik_solve_generic_device",
+                                           "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
+                                           "seqik_host_unregister", "seqik_stream_open", "seqik_stream_submit",
+                                           "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close"])
 
 
 def test_library_exports_every_declared_symbol(hiplib):

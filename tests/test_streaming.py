@@ -1,0 +1,144 @@
+"""Streaming row (BASELINE config 5): slabs pushed through `seqik_stream_*` give the same bits as one
+`seqik_solve_seq` call -- with a ragged last slab, with the alignment fused (RAW key points), in the
+planar layout from pinned memory, and "in time" (carry) against the unsplit recording."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import leg_arrays, load_golden
+
+from seqikpy_amd import data
+from seqikpy_amd.alignment import AlignPose
+
+
+def _params(lib, z, legs):
+    return [lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+
+
+def _windows(z, legs, key, offs, T):
+    base = np.stack([z[f"{l}_{key}"] for l in legs])  # (L, 1000, 5, 3)
+    return np.stack([base[:, o:o + T] for o in offs])
+
+
+# ---------------------------------------------------------------- CPU tier: argument checks (no GPU needed)
+def test_stream_open_rejects_bad_arguments(hiplib):
+    from seqikpy_amd.streaming import SeqikStream
+    z = load_golden("df3d_100")
+    _, seg, b, seeds = leg_arrays(z, "RF")
+    good = hiplib.leg_params_from_arrays(seg, b, seeds)
+    with pytest.raises(ValueError, match="bad sizes"):
+        SeqikStream([good], slab_seq=4, n_frames=8, n_slots=0)
+    with pytest.raises(ValueError, match="bad sizes"):
+        SeqikStream([good], slab_seq=0, n_frames=8)
+    bad = seeds.copy()
+    bad[1] = 4.0
+    with pytest.raises(ValueError, match="outside of provided bounds"):
+        SeqikStream([hiplib.leg_params_from_arrays(seg, b, bad)], slab_seq=4, n_frames=8)
+    lib = hiplib.load()
+    assert lib.seqik_stream_submit(None, None, 1, None, None) == hiplib.ERR_ARG
+    assert lib.seqik_stream_wait(None) == hiplib.ERR_ARG
+    assert lib.seqik_stream_close(None) == hiplib.SEQIK_OK
+    assert lib.seqik_host_register(None, 8) == hiplib.ERR_ARG
+
+
+# ---------------------------------------------------------------- GPU tier
+@pytest.fixture(scope="module")
+def lib(hiplib):
+    if hiplib.load().seqik_device_count() < 1:
+        pytest.fail("GPU tier needs a GPU: the HIP path must not be skipped silently")
+    return hiplib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_slots", [1, 3])
+def test_slabs_of_sequences_equal_one_call(lib, n_slots):
+    from seqikpy_amd.streaming import solve_streamed
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = _windows(z, legs, "pose", [(37 * i) % 950 for i in range(23)], 48)  # 23 sequences: ragged vs slab 5
+    whole = lib.solve_seq(pose, params, want_fk=True)
+    st = solve_streamed(pose, params, slab_seq=5, n_slots=n_slots)
+    assert np.array_equal(st["angles"], whole["angles"])
+    assert np.array_equal(st["fk"], whole["fk"])
+    no_fk = solve_streamed(pose, params, slab_seq=7, want_fk=False, n_slots=n_slots)
+    assert no_fk["fk"] is None and np.array_equal(no_fk["angles"], whole["angles"])
+
+
+@pytest.mark.gpu
+def test_carried_slabs_in_time_equal_the_unsplit_recording(lib, oracle):
+    """6 legs x 1000 frames in slabs of 96 frames (10 carried slabs + a 40-frame remainder) == one call
+    == the oracle's serial frame loop."""
+    from seqikpy_amd.streaming import solve_streamed_in_time
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    whole = lib.solve_seq(pose, params, want_fk=True)
+    st = solve_streamed_in_time(pose, params, slab_frames=96)
+    assert np.array_equal(st["angles"], whole["angles"])
+    assert np.array_equal(st["fk"], whole["fk"])
+    ref = oracle.seq_leg(*leg_arrays(z, "LM"))
+    assert np.array_equal(st["angles"][0, legs.index("LM")], ref["angles"])
+
+
+@pytest.mark.gpu
+def test_streamed_raw_key_points_with_fused_alignment_planar_pinned(lib):
+    """Config 5 in small: RAW key points in pinned memory, planar layout, SeqikAffine fused, 3 slots."""
+    from seqikpy_amd.streaming import PinnedArray, SeqikStream
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    raw = {f"{l}_leg": z[f"{l}_raw"] for l in legs}
+    al = AlignPose(raw, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    affs = [lib.make_affine(*al.leg_affine(raw[f"{l}_leg"], l)) for l in legs]
+    params = _params(lib, z, legs)
+    T, slab = 32, 4
+    offs = [(53 * i) % 960 for i in range(12)]
+    pose_raw = _windows(z, legs, "raw", offs, T)
+    pose_al = _windows(z, legs, "pose", offs, T)
+    ref = lib.solve_seq(pose_al, params, want_fk=True)
+    L = len(legs)
+    n_slabs = len(offs) // slab
+    bufs = [(PinnedArray((slab, L, 5, T, 3)), PinnedArray((slab, L, 7, T)), PinnedArray((slab, L, T, 9, 3)))
+            for _ in range(n_slabs)]
+    with SeqikStream(params, slab, T, affine=affs, layout=lib.planar_layout(T), want_fk=True, n_slots=3) as st:
+        for k, (p, a, f) in enumerate(bufs):
+            p.array[...] = pose_raw[k * slab:(k + 1) * slab].transpose(0, 1, 3, 2, 4)
+            st.submit(p.array, a.array, f.array)
+        st.wait()
+    for k, (p, a, f) in enumerate(bufs):
+        sl = slice(k * slab, (k + 1) * slab)
+        assert np.array_equal(a.array.transpose(0, 1, 3, 2), ref["angles"][sl])
+        assert np.array_equal(f.array, ref["fk"][sl])
+        p.free(); a.free(); f.free()
+
+
+@pytest.mark.gpu
+def test_stream_slot_reuse_and_reset_carry(lib):
+    """More slabs than slots (slot reuse blocks correctly); reset_carry starts new recordings."""
+    from seqikpy_amd.streaming import SeqikStream
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]  # (1, 6, 100, 5, 3)
+    whole = lib.solve_seq(pose, params, want_fk=False)
+    T = 20
+    outs = []
+    with SeqikStream(params, 1, T, want_fk=False, n_slots=2, carry=True) as st:
+        for rep in range(2):
+            for k in range(5):
+                a = np.empty((1, 6, T, 7))
+                st.submit(np.ascontiguousarray(pose[:, :, k * T:(k + 1) * T]), a)
+                outs.append(a)
+            st.wait()
+            st.reset_carry()
+    for rep in range(2):
+        got = np.concatenate(outs[rep * 5:(rep + 1) * 5], axis=2)
+        assert np.array_equal(got, whole["angles"])
+    with SeqikStream(params, 1, T, want_fk=True, n_slots=2) as st:
+        with pytest.raises(ValueError):
+            st.submit(np.ascontiguousarray(pose[:, :, :T]), np.empty((1, 6, T, 7)))  # fk missing
+        with pytest.raises(ValueError):
+            st.submit(np.ascontiguousarray(np.concatenate([pose[:, :, :T]] * 2)), np.empty((2, 6, T, 7)),
+                      np.empty((2, 6, T, 9, 3)))  # n_seq exceeds the slab size
