@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-python-baseline", action="store_true",
+                    help="skip the Python + scipy process-pool leg of the CPU baseline (about 20 s)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=8192,
                     help="sequences of the batch the CPU baseline solves (8192 x 6 x 64 = 3.1 M leg-frames: 10-20 s on 16 cores)")
     return ap.parse_args()
@@ -85,7 +87,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(pose, legs, body, n_seq_sample):
+def cpu_baseline(pose, legs, body, n_seq_sample, python_pool=True):
     """The C oracle (oracle/seqik_oracle.c) on the host cores: one task per (sequence, leg), the
     shape of the reference's parallel example (examples/example_leg_inv_kinematics_parallel.py:186)."""
     from oracle import c_oracle
@@ -106,10 +108,25 @@ def cpu_baseline(pose, legs, body, n_seq_sample):
     dt = time.perf_counter() - t0
     cores = workers
     units = n_seq_sample * len(legs) * pose.shape[2]
-    return {"value": units / dt, "unit": "leg-frame solves/s", "cores": cores, "kind": "port",
-            "sample": f"{n_seq_sample} of the {pose.shape[0]} sequences x 6 legs x {pose.shape[2]} frames "
-                      f"({units} leg-frames, {dt:.1f} s wall); reference's own published rates for real IKPy: "
-                      "5.6/s serial, 17.2/s on 4 cores (example_leg_inv_kinematics_parallel.py:4-6)"}
+    out = {"value": units / dt, "unit": "leg-frame solves/s", "cores": cores, "kind": "port",
+           "sample": f"{n_seq_sample} of the {pose.shape[0]} sequences x 6 legs x {pose.shape[2]} frames "
+                     f"({units} leg-frames, {dt:.1f} s wall); reference's own published rates for real IKPy: "
+                     "5.6/s serial, 17.2/s on 4 cores (example_leg_inv_kinematics_parallel.py:4-6)"}
+    if python_pool:
+        # The reference's CPU path in its own shape: Python frame loop + real scipy.optimize.least_squares per
+        # (frame, stage) over an IKPy stand-in, multiprocessing.Pool with one task per (sequence, leg)
+        # (examples/example_leg_inv_kinematics_parallel.py:186-187).  Runs in a fresh interpreter.
+        from oracle import scipy_oracle
+        n_py = min(cores, pose.shape[0])
+        _, secs = scipy_oracle.pool_run_subprocess(pose[:n_py], legs, data.BOUNDS_LOCOMOTION, body,
+                                                   data.INITIAL_ANGLES_LOCOMOTION, cores)
+        py_units = n_py * len(legs) * pose.shape[2]
+        out["python_scipy_pool"] = {"value": py_units / secs, "unit": "leg-frame solves/s", "cores": cores,
+                                    "engine": "oracle/scipy_oracle.py: real scipy TRF per (frame, stage), numpy link "
+                                              "matrices instead of IKPy's sympy-built ones (faster than real IKPy)",
+                                    "sample": f"{n_py} sequences x 6 legs x {pose.shape[2]} frames = {py_units} "
+                                              f"leg-frames, {secs:.1f} s in the pool"}
+    return out
 
 
 def main():
@@ -232,7 +249,7 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs)
+            out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist:
