@@ -216,17 +216,32 @@ def main():
     mean_stage_ms = stage_ms.mean(0)
     dom = int(np.argmax(mean_stage_ms)) + 1
     ach = BYTES_STAGE[dom] * units_per_step / (mean_stage_ms[dom - 1] * 1e-3) / 1e9
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("units_per_launch") == units_per_step and tj.get("variant") == args.variant:
             traffic = tj.get(f"stage{dom}_hbm_bytes_per_launch")
+            insts = [tj.get(f"stage{k}_valu_insts_per_launch") for k in (1, 2, 3, 4)]
+            if all(v is not None for v in insts):
+                # What actually bounds the path: VALU issue.  A wave64 VALU instruction occupies its SIMD's 16
+                # lanes for >= 4 cycles (f64 FMA/MUL/ADD: exactly 4; rcp/rsq/sqrt: more), so the step cannot
+                # be shorter than  instructions x 4 / (SIMDs x clock).
+                prop = torch.cuda.get_device_properties(device_index)
+                simds, clock_hz = prop.multi_processor_count * 4, prop.clock_rate * 1e3
+                floor_ms = sum(insts) * 4.0 / (simds * clock_hz) * 1e3
+                valu = {"valu_insts_per_step": sum(insts), "simds": simds, "clock_MHz": prop.clock_rate / 1e3,
+                        "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": elapsed / args.steps * 1e3,
+                        "frac_of_valu_issue_peak": floor_ms / (elapsed / args.steps * 1e3),
+                        "lane_utilisation": [tj.get(f"stage{k}_valu_lane_utilisation") for k in (1, 2, 3, 4)],
+                        "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch from "
+                                  "profiles/traffic_r01.json (rocprofv3 --pmc), timing live"}
     roofline = {"bound": "hbm", "kernel": f"seqik_stage_kernel<{dom}, ...>", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_unit": BYTES_STAGE[dom], "avg_launch_ms": float(mean_stage_ms[dom - 1]),
                 "stage_ms": [float(v) for v in mean_stage_ms],
                 "path_GBps": BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9,
+                "valu": valu,
                 "note": "FP64-VALU/latency-bound solver: ~1e4 f64 instructions per 392 B; HBM fraction << 1% by "
                         "construction (SURVEY 8d)"}
 

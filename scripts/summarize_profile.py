@@ -36,6 +36,9 @@ for st in (1, 2, 3, 4):
     out[f"stage{st}_fetch_bytes_per_launch"] = f
     out[f"stage{st}_write_bytes_per_launch"] = w
     out[f"stage{st}_hbm_bytes_per_launch"] = f + w
+    # wave-level VALU instructions issued per launch, and the share of the 64 lanes that were active in them
+    out[f"stage{st}_valu_insts_per_launch"] = float(sq.loc[st, "SQ_INSTS_VALU"])
+    out[f"stage{st}_valu_lane_utilisation"] = float(sq.loc[st, "SQ_THREAD_CYCLES_VALU"]) / (64.0 * float(sq.loc[st, "SQ_ACTIVE_INST_VALU"]))
 json.dump(out, open(f"{dst}/traffic_{rnd}.json", "w"), indent=1)
 print(pm.round(0).to_string())
 print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("per_launch") and k != "units_per_launch"}, indent=0))

@@ -177,3 +177,43 @@ def good_frames(leg, n):
     if leg == "LF":
         m[LF_DEGENERATE[0]:min(LF_DEGENERATE[1], n)] = False
     return m
+
+
+# DOF index of every link of the four stage chains (-1: base, 7: claw), i.e. which bounds a seed entry must respect
+SEED_LINK_DOF = [-1, 0, 1, 3,  -1, 0, 1, 2, 3, 5,  -1, 0, 1, 2, 3, 4, 5, 6,  -1, 0, 1, 2, 3, 4, 5, 6, 7]
+
+
+def random_leg_case(rng, n_frames=24):
+    """A made-up leg (segment lengths, joint limits, seeds) and nasty key points: reachable + noise, far outside
+    the workspace, (almost) on the origin, repeated frames.  Returns (pose (n, 5, 3), seg, bounds, seeds)."""
+    from seqikpy_amd import synthetic
+    seg = rng.uniform(0.15, 1.8, 4)
+    centre = rng.uniform(-2.0, 2.0, 7)
+    width = rng.choice([0.3, 1.0, 2.5, 6.0], 7) * rng.uniform(0.5, 1.0, 7)
+    lb = np.clip(centre - width / 2, -np.pi, np.pi - 0.05)
+    ub = np.clip(centre + width / 2, lb + 0.05, np.pi)
+    if rng.random() < 0.5:
+        ub[6] = 0.0  # the reference's TiTa_pitch limit; the default seed 0.0 then sits ON the bound
+        lb[6] = min(lb[6], -0.5)
+    bounds = np.stack([lb, ub], 1)
+    seeds = np.zeros(27)
+    for i, dof in enumerate(SEED_LINK_DOF):
+        if dof == -1:
+            seeds[i] = 0.0
+        elif dof == 7:
+            seeds[i] = rng.uniform(-1.0, 1.0)
+        else:
+            u = rng.choice([0.0, 1.0, rng.random()], p=[0.1, 0.1, 0.8])  # sometimes exactly on a bound
+            seeds[i] = lb[dof] if u == 0.0 else (ub[dof] if u == 1.0 else min(ub[dof], lb[dof] + u * (ub[dof] - lb[dof])))
+    theta = lb + rng.random((n_frames, 7)) * (ub - lb)
+    kp = synthetic.leg_forward_kinematics(theta, seg)
+    kp[:, 1:] += 0.02 * rng.standard_normal(kp[:, 1:].shape)
+    kind = rng.integers(0, 6, n_frames)
+    kp[kind == 0, 1:] *= 6.0                       # far outside the workspace
+    kp[kind == 1, 1:] *= 1e-9                      # on top of the origin
+    kp[kind == 2, 4] = 0.0                         # claw exactly at the origin
+    for t in np.where(kind == 3)[0]:
+        if t > 0:
+            kp[t] = kp[t - 1]                      # repeated frame: the warm start is already the answer
+    origin = rng.normal(0.0, 1.0, 3)
+    return kp + origin, seg, bounds, seeds

@@ -101,3 +101,15 @@ def test_continuation_with_init_angles(oracle, host_harness):
         c = run(pose[cut:200], a["angles"][-1])
         assert np.array_equal(np.concatenate([a["angles"], c["angles"]]), full["angles"])
         assert np.array_equal(np.concatenate([a["fk"], c["fk"]]), full["fk"])
+
+
+def test_core_equals_oracle_on_random_legs_and_nasty_targets(oracle, host_harness):
+    """Made-up legs (lengths, limits, seeds on bounds) with unreachable / degenerate / repeated targets."""
+    from conftest import random_leg_case
+    rng = np.random.default_rng(20241022)
+    for _ in range(96):
+        pose, seg, b, seeds = random_leg_case(rng, 32)
+        o = oracle.seq_leg(pose, seg, b, seeds)
+        assert np.isfinite(o["angles"]).all() and np.isfinite(o["fk"]).all()
+        assert (o["angles"] >= b[:, 0]).all() and (o["angles"] <= b[:, 1]).all()
+        _cmp(host_harness.run(pose, seg, b, seeds), o)

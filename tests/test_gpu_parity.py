@@ -258,3 +258,23 @@ def test_full_size_synthetic_properties(lib, oracle, variant):
         seg, b, seeds = oracle.leg_params(leg, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
         ref = oracle.seq_leg(pose[s, li], seg, b, seeds)
         assert np.array_equal(ang[s, li], ref["angles"]) and np.array_equal(fk[s, li], ref["fk"])
+
+
+def test_random_legs_and_nasty_targets_bit_for_bit(lib, oracle):
+    """Made-up legs (segment lengths, joint limits, seeds on bounds) with unreachable, degenerate and repeated
+    targets, 8 different legs per launch: HIP == oracle bit for bit, angles inside their limits, all finite."""
+    from conftest import random_leg_case
+    rng = np.random.default_rng(977)
+    for _ in range(12):
+        cases = [random_leg_case(rng, 40) for _ in range(8)]
+        pose = np.stack([c[0] for c in cases])[None]
+        params = [lib.leg_params_from_arrays(c[1], c[2], c[3]) for c in cases]
+        out = lib.solve_seq(pose, params, want_fk=True, want_diag=True)
+        assert np.isfinite(out["angles"]).all() and np.isfinite(out["fk"]).all()
+        for i, (p, seg, b, seeds) in enumerate(cases):
+            ref = oracle.seq_leg(p, seg, b, seeds)
+            assert np.array_equal(out["angles"][0, i], ref["angles"])
+            assert np.array_equal(out["fk"][0, i], ref["fk"])
+            assert np.array_equal(out["status"][0, i], ref["status"])
+            assert np.array_equal(out["nfev"][0, i], ref["nfev"])
+            assert (out["angles"][0, i] >= b[:, 0]).all() and (out["angles"][0, i] <= b[:, 1]).all()
