@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--frames-per-seq", type=int, default=64)
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--lanes-per-wave", type=int, default=0, help="chains per wavefront (0 = automatic)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,7 +184,7 @@ def main():
             # ONE C-ABI call = the four stage kernels; the library records the given HIP events between them
             _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
                                   d_fks[i % len(streams)].data_ptr(), stream=stream.cuda_stream,
-                                  block_size=args.block, layout=layout,
+                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave,
                                   stage_events=[e.cuda_event for e in events] if events else None)
             if gather:
                 gather.submit(b, buf)
@@ -227,10 +228,10 @@ def main():
                 # What actually bounds the path: VALU issue.  A wave64 VALU instruction occupies its SIMD's 16
                 # lanes for >= 4 cycles (f64 FMA/MUL/ADD: exactly 4; rcp/rsq/sqrt: more), so the step cannot
                 # be shorter than  instructions x 4 / (SIMDs x clock).
-                prop = torch.cuda.get_device_properties(device_index)
-                simds, clock_hz = prop.multi_processor_count * 4, prop.clock_rate * 1e3
+                n_cu, clock_khz, _ = _lib.device_attributes(device_index)
+                simds, clock_hz = n_cu * 4, clock_khz * 1e3
                 floor_ms = sum(insts) * 4.0 / (simds * clock_hz) * 1e3
-                valu = {"valu_insts_per_step": sum(insts), "simds": simds, "clock_MHz": prop.clock_rate / 1e3,
+                valu = {"valu_insts_per_step": sum(insts), "simds": simds, "clock_MHz": clock_khz / 1e3,
                         "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": elapsed / args.steps * 1e3,
                         "frac_of_valu_issue_peak": floor_ms / (elapsed / args.steps * 1e3),
                         "lane_utilisation": [tj.get(f"stage{k}_valu_lane_utilisation") for k in (1, 2, 3, 4)],

@@ -76,7 +76,8 @@ typedef struct SeqikOptions {
     void **stage_events;  /* nullable: 5 hipEvent_t handles, recorded on the launch stream in front of the
                              stage-1..4 kernels ([0]..[3], only for stages that run) and behind the last one
                              ([4]) -- lets a caller time the individual kernels of one call */
-    int32_t reserved[4];
+    int32_t reserved[4];  /* [0]: chains per wavefront, 1..64 (0 = automatic: the chains are spread over all SIMDs of
+                             the GPU before they are stacked into the lanes of a wave); [1..3]: must be 0 */
 } SeqikOptions;
 
 /* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.
@@ -108,6 +109,8 @@ typedef struct SeqikAffine {
 int seqik_abi_version(void);
 int seqik_device_count(void);
 const char *seqik_last_error(void);
+/* Compute units, peak shader clock (kHz) and HBM size of a device (any out pointer may be NULL). */
+int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clock_khz, int64_t *hbm_bytes);
 
 /* Validates `legs` exactly as the reference would fail at frame 0 (bounds order,
  * seeds inside bounds).  Returns SEQIK_OK or the error code; no GPU needed. */

@@ -42,18 +42,52 @@ struct KernelArgs {
     const double *init;           // nullable [n_chains][7]
     double *frames;               // workspace [n_chains][n_frames][12] (stage hand-off), may be null
     int64_t n_chains;             // n_seq * n_legs
+    int64_t n_seq;
     int64_t n_frames;
     int32_t n_legs;
+    int32_t lanes_per_wave;       // W: chains a wavefront carries (1..64), see chain_of_lane()
     // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
 };
 
+// Lane -> chain mapping.  A wavefront carries W <= 64 consecutive chains (chain = seq * n_legs + leg).
+// W < 64 when there are few chains: a pass of a wave costs the UNION of the code paths its lanes take, and
+// one wave per SIMD cannot issue back to back, so n chains finish sooner as n / W thin waves spread over all
+// SIMDs than as n / 64 full waves on a few of them.  launch() fills the 1024 SIMDs of the MI355X with thin
+// waves first and only then fattens them; at benchmark sizes W = 64.  (Grouping the lanes of a wave by leg
+// was measured and dropped: legs differ systematically in cost -- a front leg needs ~20 trust-region passes
+// per stage-1 solve on the benchmark data, a hind leg ~16 -- so leg-pure waves finish at different times and
+// the kernels drain unevenly: 2.26e8 -> 2.09e8 solves/s with two batches in flight.)
+// Returns false for lanes that carry no chain.
+__device__ __forceinline__ bool chain_of_lane(int64_t n_chains, int32_t n_legs, int32_t W, int64_t &c, int &leg)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(g & 63);
+    c = (g >> 6) * W + lane;
+    leg = (int)(c % n_legs);
+    return lane < W && c < n_chains;
+}
+
+// How many chains a wavefront should carry: spread the chains over all SIMDs (256 CUs x 4) before stacking
+// them into the lanes of a wave.
+int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt)
+{
+    if (opt && opt->reserved[0] >= 1 && opt->reserved[0] <= 64) return opt->reserved[0];
+    static int n_simd = 0;
+    if (n_simd == 0) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n_simd = (cus > 0 ? cus : 256) * 4;
+    }
+    int64_t w = (n_chains + n_simd - 1) / n_simd;
+    return (int)(w < 1 ? 1 : (w > 64 ? 64 : w));
+}
+
 // One lane per chain, one launch per stage (the reference's own loop order,
 // leg_inverse_kinematics.py:373-385).  A workgroup is one or more independent wavefronts;
 // the only shared data is the read-only per-leg constant table, staged once into LDS.
-// Chains of a wave are consecutive (sequence, leg) pairs, so a 64-lane wave owns
-// 64 * n_frames * 120 B of contiguous key points.
+// Which chain a lane gets: chain_of_lane().
 template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
 seqik_stage_kernel(KernelArgs a)
@@ -66,9 +100,9 @@ seqik_stage_kernel(KernelArgs a)
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n_chains) return;
-    const int leg = (int)(c % a.n_legs);
+    int64_t c;
+    int leg;
+    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
 
     seqik::ChainIO io;
     io.pose = a.pose + c * a.pose_chain;
@@ -129,8 +163,8 @@ struct GenericKernelArgs {
     int32_t *nfev;
     const GenericLegTable *legs;
     const double *init;
-    int64_t n_chains, n_frames;
-    int32_t n_legs;
+    int64_t n_chains, n_seq, n_frames;
+    int32_t n_legs, lanes_per_wave;
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
 };
@@ -147,9 +181,9 @@ __global__ void __launch_bounds__(kMaxBlock) seqik_generic_kernel(GenericKernelA
         for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n_chains) return;
-    const int leg = (int)(c % a.n_legs);
+    int64_t c;
+    int leg;
+    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
     seqik::GenericIO io;
     io.pose = a.pose + c * a.pose_chain; io.pose_row = a.pose_row; io.pose_frame = a.pose_frame;
     io.angles = a.angles + c * a.ang_chain; io.ang_dof = a.ang_dof; io.ang_frame = a.ang_frame;
@@ -265,7 +299,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (a.n_chains == 0 || n_frames == 0) return SEQIK_OK;
     int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
-    int64_t grid64 = (a.n_chains + block - 1) / block;
+    a.n_seq = n_seq;
+    a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
+    const int64_t n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+    int64_t grid64 = (n_waves * 64 + block - 1) / block;
     if (grid64 > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
     const bool diag = d_status || d_nfev;
@@ -306,6 +343,16 @@ int seqik_device_count(void)
 }
 
 const char *seqik_last_error(void) { return g_err; }
+
+int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clock_khz, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return SEQIK_OK;
+}
 
 // used by the other translation units of the library (seqik_head.hip)
 void seqik_set_error(int code, const char *msg) { (void)fail(code, "%s", msg); }
@@ -379,7 +426,10 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     if (rc != SEQIK_OK) return rc;
     int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
-    const dim3 grid((unsigned)((a.n_chains + block - 1) / block)), blk(block);
+    a.n_seq = n_seq;
+    a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
+    const int64_t n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+    const dim3 grid((unsigned)((n_waves * 64 + block - 1) / block)), blk(block);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (d_status || d_nfev) hipLaunchKernelGGL(seqik_generic_kernel<true>, grid, blk, 0, stream, a);
     else hipLaunchKernelGGL(seqik_generic_kernel<false>, grid, blk, 0, stream, a);

@@ -120,6 +120,8 @@ def load():
         L.seqik_abi_version.restype = ctypes.c_int
         L.seqik_device_count.restype = ctypes.c_int
         L.seqik_last_error.restype = ctypes.c_char_p
+        L.seqik_device_attributes.restype = ctypes.c_int
+        L.seqik_device_attributes.argtypes = [ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64)]
         L.seqik_validate_legs.restype = ctypes.c_int
         L.seqik_validate_legs.argtypes = [ctypes.POINTER(SeqikLegParams), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.seqik_solve_seq.restype = ctypes.c_int
@@ -175,7 +177,8 @@ def load():
         return _lib
 
 
-EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_validate_legs",
+EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes",
+                    "seqik_validate_legs",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
                     "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
@@ -183,7 +186,17 @@ EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error
                     "seqik_stream_close"]
 
 
-def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_size=0, affine=None, init_angles=None):
+def device_attributes(device=0):
+    """(compute units, peak clock in kHz, HBM bytes) of a GPU."""
+    cu, khz, mem = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+    rc = load().seqik_device_attributes(device, ctypes.byref(cu), ctypes.byref(khz), ctypes.byref(mem))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return cu.value, khz.value, mem.value
+
+
+def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_size=0, affine=None, init_angles=None,
+                  lanes_per_wave=0):
     """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
     fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None)."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
@@ -204,6 +217,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_siz
     opt = SeqikOptions()
     opt.device = device
     opt.block_size = block_size
+    opt.reserved[0] = lanes_per_wave
     rc = load().seqik_solve_generic(pose.ctypes.data_as(_dp), S, L, N, (SeqikLegParams * L)(*legs),
                                     angles.ctypes.data_as(_dp), fk.ctypes.data_as(_dp) if fk is not None else None,
                                     status.ctypes.data_as(_ip) if status is not None else None,
@@ -300,13 +314,14 @@ def _affine_array(affine, n_legs):
 
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
-              device=0, block_size=0, affine=None, init_angles=None):
+              device=0, block_size=0, affine=None, init_angles=None, lanes_per_wave=0):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
     (S, L, N, 7) with earlier-stage columns filled when ``first_stage > 1``.
     ``affine``: optional list of L ``SeqikAffine`` -- ``pose`` then holds RAW key points and the
-    alignment is fused into the kernels.  Returns dict(angles, fk or None, status or None, nfev or None).
+    alignment is fused into the kernels.  ``lanes_per_wave``: chains per wavefront (0 = automatic, see
+    ``SeqikOptions.reserved[0]``).  Returns dict(angles, fk or None, status or None, nfev or None).
     """
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
@@ -328,6 +343,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt = SeqikOptions()
     opt.device = device
     opt.block_size = block_size
+    opt.reserved[0] = lanes_per_wave
     if init_angles is not None:
         init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
         if init_angles.shape != (S, L, 7):
@@ -347,7 +363,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
                      first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
-                     stage_events=None):
+                     stage_events=None, lanes_per_wave=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
     ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
@@ -355,6 +371,7 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     arr = (SeqikLegParams * n_legs)(*legs)
     opt = SeqikOptions()
     opt.block_size = block_size
+    opt.reserved[0] = lanes_per_wave
     if stage_events is not None:
         ev = (ctypes.c_void_p * 5)(*[ctypes.c_void_p(int(e)) for e in stage_events])
         opt.stage_events = ctypes.cast(ev, ctypes.POINTER(ctypes.c_void_p))

@@ -278,3 +278,24 @@ def test_random_legs_and_nasty_targets_bit_for_bit(lib, oracle):
             assert np.array_equal(out["status"][0, i], ref["status"])
             assert np.array_equal(out["nfev"][0, i], ref["nfev"])
             assert (out["angles"][0, i] >= b[:, 0]).all() and (out["angles"][0, i] <= b[:, 1]).all()
+
+
+@pytest.mark.parametrize("lanes", [1, 5, 64])
+def test_lanes_per_wave_does_not_change_results(lib, lanes):
+    """The lane -> chain mapping (SeqikOptions.reserved[0]) only decides where a chain runs: 23 sequences x 6
+    legs (ragged against 5 and 64 lanes per wave) give the same bits as the automatic choice."""
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    base = np.stack([z[f"{l}_pose"] for l in legs])
+    pose = np.stack([base[:, o:o + 30] for o in [(41 * i) % 960 for i in range(23)]])
+    auto = lib.solve_seq(pose, params, want_fk=True, want_diag=True)
+    got = lib.solve_seq(pose, params, want_fk=True, want_diag=True, lanes_per_wave=lanes)
+    for k in ("angles", "fk", "status", "nfev"):
+        assert np.array_equal(got[k], auto[k]), k
+    zg = load_golden("generic_rf_100")
+    gp = [lib.leg_params_from_arrays(zg["RF_seg"], zg["RF_bounds"], zg["RF_seeds"])]
+    gpose = np.stack([zg["RF_pose"][o:o + 6] for o in range(0, 70, 10)])[:, None]  # 7 sequences x 1 leg x 6 frames
+    gen_auto = lib.solve_generic(gpose, gp)
+    gen = lib.solve_generic(gpose, gp, lanes_per_wave=lanes)
+    assert np.array_equal(gen["angles"], gen_auto["angles"]) and np.array_equal(gen["fk"], gen_auto["fk"])
