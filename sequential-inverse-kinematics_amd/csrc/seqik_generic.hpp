@@ -125,32 +125,41 @@ SEQIK_HD void svd7(double A[3 + GN][GN], const double *f, double *s, double V[GN
             }
         if (!rotated) break;
     }
-    double sv[GN];
-    int order[GN];
+    // singular values and uf per column, then a stable descending sort of the (sv, uf, V column) triples.
+    // The sort is a fully unrolled bubble sort of adjacent compare-exchanges (swap only if strictly
+    // smaller), which yields the same permutation as the oracle's stable insertion sort; every index is a
+    // compile-time constant, so A and V stay in registers (an index array here forced both into scratch
+    // memory and every rotation of the sweeps above to be written through to it).
+    double sv[GN], ufc[GN];
+#pragma unroll
     for (int j = 0; j < GN; ++j) {
         double acc = 0.0;
+#pragma unroll
         for (int i = 0; i < ROWS; ++i) acc = fma_(A[i][j], A[i][j], acc);
         sv[j] = sqrt(acc);
-        order[j] = j;
-    }
-    for (int i = 1; i < GN; ++i) {  // stable insertion sort, descending
-        int k = order[i];
-        int j = i - 1;
-        while (j >= 0 && sv[order[j]] < sv[k]) { order[j + 1] = order[j]; --j; }
-        order[j + 1] = k;
-    }
-    double Vt[GN][GN];
-    for (int jj = 0; jj < GN; ++jj) {
-        int j = order[jj];
-        s[jj] = sv[j];
         double inv_sv = (sv[j] > 0.0) ? 1.0 / sv[j] : 0.0;
-        double acc = 0.0;
-        for (int k = 0; k < 3; ++k) acc = fma_(A[k][j] * inv_sv, f[k], acc);
-        uf[jj] = acc;
-        for (int i = 0; i < GN; ++i) Vt[i][jj] = V[i][j];
+        double u = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u = fma_(A[k][j] * inv_sv, f[k], u);
+        ufc[j] = u;
     }
-    for (int i = 0; i < GN; ++i)
-        for (int j = 0; j < GN; ++j) V[i][j] = Vt[i][j];
+#pragma unroll
+    for (int pass = 0; pass < GN - 1; ++pass)
+#pragma unroll
+        for (int j = 0; j < GN - 1 - pass; ++j) {
+            const bool sw = sv[j] < sv[j + 1];
+            double a = sv[j], b = sv[j + 1];
+            sv[j] = sw ? b : a; sv[j + 1] = sw ? a : b;
+            a = ufc[j]; b = ufc[j + 1];
+            ufc[j] = sw ? b : a; ufc[j + 1] = sw ? a : b;
+#pragma unroll
+            for (int i = 0; i < GN; ++i) {
+                a = V[i][j]; b = V[i][j + 1];
+                V[i][j] = sw ? b : a; V[i][j + 1] = sw ? a : b;
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < GN; ++j) { s[j] = sv[j]; uf[j] = ufc[j]; }
 }
 
 SEQIK_HD void phi_and_ratio7(double alpha, const double *suf, const double *s, double Delta, double &phi, double &ratio)
@@ -320,12 +329,13 @@ SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const doub
     }
     for (int i = 0; i < GN; ++i) { ag_h[i] = ag_h[i] * ag_stride; ag[i] = ag[i] * ag_stride; }
 
-    const double *bs = ag, *bh = ag_h;
-    double value = ag_value;
-    if (p_value < r_value && p_value < ag_value) { bs = p; bh = p_h; value = p_value; }
-    else if (r_value < p_value && r_value < ag_value) { bs = r; bh = r_h; value = r_value; }
-    for (int i = 0; i < GN; ++i) { step[i] = bs[i]; step_h[i] = bh[i]; }
-    return -value;
+    const bool take_p = p_value < r_value && p_value < ag_value;
+    const bool take_r = !take_p && r_value < p_value && r_value < ag_value;
+    for (int i = 0; i < GN; ++i) {  // value selects, no pointer select: the candidates stay in registers
+        step[i] = take_p ? p[i] : (take_r ? r[i] : ag[i]);
+        step_h[i] = take_p ? p_h[i] : (take_r ? r_h[i] : ag_h[i]);
+    }
+    return -(take_p ? p_value : (take_r ? r_value : ag_value));
 }
 
 struct GenericIO {
