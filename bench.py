@@ -8,8 +8,8 @@ Metric (BASELINE.json): leg-IK solves/s, one solve = one (frame, leg) = 4 stage 
 "synthetic 1M frames x 6 legs, random in-workspace target key points", PER GPU (weak scaling):
 1,000,000 frames are cut into 15,625 independent sequences of 64 frames (frame t of a sequence is
 warm-started from frame t-1, frame 0 from the seeds -- the reference's semantics applied to many
-recordings), 6 legs each = 93,750 chains.  A step is one pass of the 4 stage kernels over that
-batch with inputs resident in HBM; for N > 1 every step also sends the rank's joint angles to rank 0
+recordings), 6 legs each = 93,750 chains.  A step is one pass of the hot path (one launch in which every
+wave takes its chains through stages 1-4; `--staged`: the 4 stage kernels) over that batch with inputs resident in HBM; for N > 1 every step also sends the rank's joint angles to rank 0
 (RCCL gather, overlapped with the next step's kernels).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, live HIP-event timing) and, at
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--lanes-per-wave", type=int, default=0, help="chains per wavefront (0 = automatic)")
+    ap.add_argument("--staged", action="store_true",
+                    help="one launch per stage (SeqikOptions.reserved[1] = 1) instead of the default single launch in "
+                         "which every wave takes its chains through the four stages in turn")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +187,7 @@ def main():
             # ONE C-ABI call = the four stage kernels; the library records the given HIP events between them
             _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
                                   d_fks[i % len(streams)].data_ptr(), stream=stream.cuda_stream,
-                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave,
+                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave, staged=int(args.staged),
                                   stage_events=[e.cuda_event for e in events] if events else None)
             if gather:
                 gather.submit(b, buf)
@@ -215,18 +218,23 @@ def main():
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(args.steps)])
     mean_stage_ms = stage_ms.mean(0)
-    dom = int(np.argmax(mean_stage_ms)) + 1
-    ach = BYTES_STAGE[dom] * units_per_step / (mean_stage_ms[dom - 1] * 1e-3) / 1e9
+    if args.staged:
+        dom = int(np.argmax(mean_stage_ms)) + 1
+        kname, key, bytes_unit, dom_ms = f"seqik_stage_kernel<{dom}, ...>", f"stage{dom}", BYTES_STAGE[dom], float(mean_stage_ms[dom - 1])
+    else:  # one kernel per step: event [0] is recorded in front of it, [1] behind it
+        kname, key, bytes_unit, dom_ms = "seqik_fused_kernel<true>", "fused", BYTES_PATH, float(mean_stage_ms[0])
+    ach = bytes_unit * units_per_step / (dom_ms * 1e-3) / 1e9
     traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01_staged.json" if args.staged else "traffic_r01.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if tj.get("units_per_launch") == units_per_step and tj.get("variant") == args.variant:
-            traffic = tj.get(f"stage{dom}_hbm_bytes_per_launch")
-            insts = [tj.get(f"stage{k}_valu_insts_per_launch") for k in (1, 2, 3, 4)]
+            traffic = tj.get(f"{key}_hbm_bytes_per_launch")
+            names = [f"stage{k}" for k in (1, 2, 3, 4)] if args.staged else ["fused"]
+            insts = [tj.get(f"{n}_valu_insts_per_launch") for n in names]
             if all(v is not None for v in insts):
                 # What actually bounds the path: VALU issue.  A wave64 VALU instruction occupies its SIMD's 16
-                # lanes for >= 4 cycles (f64 FMA/MUL/ADD: exactly 4; rcp/rsq/sqrt: more), so the step cannot
+                # f64 lanes for >= 4 cycles (f64 FMA/MUL/ADD: exactly 4; rcp/rsq seeds: more), so the step cannot
                 # be shorter than  instructions x 4 / (SIMDs x clock).
                 n_cu, clock_khz, _ = _lib.device_attributes(device_index)
                 simds, clock_hz = n_cu * 4, clock_khz * 1e3
@@ -234,17 +242,18 @@ def main():
                 valu = {"valu_insts_per_step": sum(insts), "simds": simds, "clock_MHz": clock_khz / 1e3,
                         "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": elapsed / args.steps * 1e3,
                         "frac_of_valu_issue_peak": floor_ms / (elapsed / args.steps * 1e3),
-                        "lane_utilisation": [tj.get(f"stage{k}_valu_lane_utilisation") for k in (1, 2, 3, 4)],
+                        "lane_utilisation": [tj.get(f"{n}_valu_lane_utilisation") for n in names],
                         "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch from "
-                                  "profiles/traffic_r01.json (rocprofv3 --pmc), timing live"}
-    roofline = {"bound": "hbm", "kernel": f"seqik_stage_kernel<{dom}, ...>", "achieved": ach, "peak": HBM_PEAK_GBS,
+                                  f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc), timing live"}
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_unit": BYTES_STAGE[dom], "avg_launch_ms": float(mean_stage_ms[dom - 1]),
-                "stage_ms": [float(v) for v in mean_stage_ms],
-                "path_GBps": BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9,
+                "bytes_per_unit": bytes_unit, "avg_launch_ms": dom_ms,
                 "valu": valu,
-                "note": "FP64-VALU/latency-bound solver: ~1e4 f64 instructions per 392 B; HBM fraction << 1% by "
-                        "construction (SURVEY 8d)"}
+                "note": "FP64-VALU-issue-bound solver: ~1e4 f64 instructions per 392 B; HBM fraction << 1% by "
+                        "construction (SURVEY 8d); `valu` is the roofline that binds"}
+    if args.staged:
+        roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
+        roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
 
     if rank == 0:
         total_units = units_per_step * world * args.steps
@@ -260,7 +269,7 @@ def main():
                        "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
                        "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
-                       "streams": len(streams),
+                       "streams": len(streams), "launches_per_step": 4 if args.staged else 1,
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU"},
             "roofline": roofline,
         }

@@ -1,14 +1,16 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace stats + PMC passes of the default bench
-# workload.  Usage: bash scripts/gpu_profile.sh TAG   -> gpurun_out/TAG_{stats,fetch,write,sq}/ (+ .log)
+# workload.  Usage: bash scripts/gpu_profile.sh TAG [extra bench.py args, e.g. --staged]
+#   -> gpurun_out/TAG_{stats,fetch,write,sq}/ (+ .log)
 # Summaries for profiles/ are cut from these by scripts/summarize_profile.py TAG rNN.
 set -o pipefail
 TAG=${1:-prof}
+shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1 || exit 1
 # counters in their own runs (no tracing options), one pass each
 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/${TAG}_fetch" -- $BENCH > "$OUT/${TAG}_fetch.log" 2>&1 || exit 1

@@ -16,29 +16,31 @@ open(f"{dst}/{rnd}_bench_under_rocprof.json", "w").write(bench_line)
 
 def pmc(kind):
     d = pd.read_csv(glob.glob(f"{src}/{tag}_{kind}/*/*_counter_collection.csv")[0])
-    d = d[d.Kernel_Name.str.contains("seqik_stage_kernel")].copy()
-    d["stage"] = d.Kernel_Name.str.extract(r"kernel<(\d), ").astype(int)
-    return d.pivot_table(index="stage", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+    d = d[d.Kernel_Name.str.contains("seqik_stage_kernel|seqik_fused_kernel")].copy()
+    st = d.Kernel_Name.str.extract(r"seqik_stage_kernel<(\d), ")[0]
+    d["kernel"] = ("stage" + st).where(st.notna(), "fused")
+    return d.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
 
 fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
 pm = pd.concat([fetch, write, sq], axis=1)
 pm.to_csv(f"{dst}/{rnd}_bench_pmc_per_launch.csv")
 b = json.loads(bench_line)
 units = b["config"]["sequences_per_gpu"] * b["config"]["legs"] * b["config"]["frames_per_sequence"]
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`",
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) on `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`",
        "units_per_launch": units, "variant": b["config"]["variant"],
        "note": "FETCH_SIZE / WRITE_SIZE are in KiB; bytes = value * 1024, mean over the launches of the run. "
                "FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 and under-reports wide (16 B/lane) streaming reads by 2x "
                "(MI355X_MICROARCH.md); these kernels issue 8-byte per-lane loads, for which the counter is uncalibrated, "
-               "so the raw value is reported."}
-for st in (1, 2, 3, 4):
-    f, w = float(fetch.loc[st, "FETCH_SIZE"]) * 1024, float(write.loc[st, "WRITE_SIZE"]) * 1024
-    out[f"stage{st}_fetch_bytes_per_launch"] = f
-    out[f"stage{st}_write_bytes_per_launch"] = w
-    out[f"stage{st}_hbm_bytes_per_launch"] = f + w
+               "so the raw value is reported.  The fused kernel's traffic includes the stage hand-off workspace "
+               "(3 x (96 B written + 96 B read) per leg-frame), which is not part of the 392 algorithmic bytes."}
+for k in pm.index:
+    f, w = float(fetch.loc[k, "FETCH_SIZE"]) * 1024, float(write.loc[k, "WRITE_SIZE"]) * 1024
+    out[f"{k}_fetch_bytes_per_launch"] = f
+    out[f"{k}_write_bytes_per_launch"] = w
+    out[f"{k}_hbm_bytes_per_launch"] = f + w
     # wave-level VALU instructions issued per launch, and the share of the 64 lanes that were active in them
-    out[f"stage{st}_valu_insts_per_launch"] = float(sq.loc[st, "SQ_INSTS_VALU"])
-    out[f"stage{st}_valu_lane_utilisation"] = float(sq.loc[st, "SQ_THREAD_CYCLES_VALU"]) / (64.0 * float(sq.loc[st, "SQ_ACTIVE_INST_VALU"]))
+    out[f"{k}_valu_insts_per_launch"] = float(sq.loc[k, "SQ_INSTS_VALU"])
+    out[f"{k}_valu_lane_utilisation"] = float(sq.loc[k, "SQ_THREAD_CYCLES_VALU"]) / (64.0 * float(sq.loc[k, "SQ_ACTIVE_INST_VALU"]))
 json.dump(out, open(f"{dst}/traffic_{rnd}.json", "w"), indent=1)
 print(pm.round(0).to_string())
-print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("per_launch") and k != "units_per_launch"}, indent=0))
+print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("bytes_per_launch")}, indent=0))

@@ -120,6 +120,46 @@ seqik_stage_kernel(KernelArgs a)
     seqik::run_stage<STAGE, WANT_FK, WANT_DIAG, FROM_ANGLES, HANDOFF>(s_legs[leg], io);
 }
 
+// All four stages in ONE launch: a wave takes its chains through stage 1, then 2, 3, 4 (each stage over all
+// frames, exactly the per-stage kernels' code, so the register budget is the largest stage's, not the sum).
+// The hand-off frames a lane writes are read back by the same lane.  Saves three kernel drains per call:
+// a stage kernel ends with a tail in which ever fewer waves are resident, and the next stage cannot start
+// before the last wave is gone; here every wave simply carries on.
+template <bool WANT_FK>
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_fused_kernel(KernelArgs a)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    int64_t c;
+    int leg;
+    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
+    seqik::ChainIO io;
+    io.pose = a.pose + c * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
+    io.status = nullptr;
+    io.nfev = nullptr;
+    io.init = a.init ? a.init + c * 7 : nullptr;
+    io.frames = a.frames + c * a.n_frames * 12;
+    io.n_frames = a.n_frames;
+    const seqik::LegConst &lc = s_legs[leg];
+    seqik::run_stage<1, false, false, false, true>(lc, io);
+    seqik::run_stage<2, WANT_FK, false, false, true>(lc, io);
+    seqik::run_stage<3, WANT_FK, false, false, true>(lc, io);
+    seqik::run_stage<4, WANT_FK, false, false, false>(lc, io);
+}
+
 // from_angles: first stage of a run that starts after stage 1; handoff: a later stage follows
 template <int STAGE, bool FROM_ANGLES, bool HANDOFF>
 void launch_stage2(const KernelArgs &a, bool fk, bool diag, dim3 grid, dim3 block, hipStream_t stream)
@@ -312,7 +352,16 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     a.frames = nullptr;
     if (last_stage > first_stage)
         HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), sizeof(double) * 12 * a.n_chains * n_frames, stream));
-    for (int stage = first_stage; stage <= last_stage; ++stage) {
+    const bool fused = !(opt && opt->reserved[1] == 1) && first_stage == 1 && last_stage == 4 && !diag;
+    if (fused) {
+        if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
+        if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
+        else hipLaunchKernelGGL((seqik_fused_kernel<false>), grid, blk, 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        if (opt && opt->stage_events)  // one kernel: [0] in front of it, [1..4] behind it
+            for (int k = 1; k <= 4; ++k) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[k]), stream));
+    }
+    for (int stage = first_stage; stage <= last_stage && !fused; ++stage) {
         const bool from_angles = (stage == first_stage) && stage > 1;
         const bool handoff = stage < last_stage;
         if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[stage - 1]), stream));
@@ -324,7 +373,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         }
         HIP_TRY(hipGetLastError());
     }
-    if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[4]), stream));
+    if (opt && opt->stage_events && !fused) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[4]), stream));
     if (a.frames) HIP_TRY(hipFreeAsync(a.frames, stream));
     return SEQIK_OK;
 }

@@ -299,3 +299,20 @@ def test_lanes_per_wave_does_not_change_results(lib, lanes):
     gen_auto = lib.solve_generic(gpose, gp)
     gen = lib.solve_generic(gpose, gp, lanes_per_wave=lanes)
     assert np.array_equal(gen["angles"], gen_auto["angles"]) and np.array_equal(gen["fk"], gen_auto["fk"])
+
+
+def test_single_launch_equals_one_launch_per_stage(lib):
+    """Default = every wave takes its chains through stages 1-4 in one launch; staged=1 = one launch per stage
+    (what a run with diagnostics or a stage subset uses): same bits, with and without FK, any wave shape."""
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    base = np.stack([z[f"{l}_pose"] for l in legs])
+    pose = np.stack([base[:, o:o + 40] for o in [(41 * i) % 950 for i in range(200)]])
+    staged = lib.solve_seq(pose, params, want_fk=True, staged=1)
+    for kw in (dict(), dict(lanes_per_wave=64), dict(lanes_per_wave=3), dict(block_size=256)):
+        one = lib.solve_seq(pose, params, want_fk=True, **kw)
+        assert np.array_equal(one["angles"], staged["angles"]) and np.array_equal(one["fk"], staged["fk"]), kw
+    assert np.array_equal(lib.solve_seq(pose, params, want_fk=False)["angles"], staged["angles"])
+    diag = lib.solve_seq(pose, params, want_fk=True, want_diag=True)  # diagnostics always run staged
+    assert np.array_equal(diag["angles"], staged["angles"])
