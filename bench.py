@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--staged", action="store_true",
                     help="one launch per stage (SeqikOptions.reserved[1] = 1) instead of the default single launch in "
                          "which every wave takes its chains through the four stages in turn")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-python-baseline", action="store_true",

@@ -8,13 +8,14 @@
 // i.e. for every frame four bounded trust-region-reflective least-squares problems with
 // 2 (stages 1-3) or 1 (stage 4) effective unknowns, frame t warm-started from frame t-1.
 //
-// Decomposition (same loop order as the reference, :373-385): ONE KERNEL PER STAGE, and
-// inside a stage kernel ONE LANE PER CHAIN walking its frames serially.  A lane runs a flat
+// Decomposition (same loop order as the reference, :373-385): STAGE BY STAGE, and inside a
+// stage ONE LANE PER CHAIN walking its frames serially (run_stage<STAGE>).  A lane runs a flat
 // state machine whose step ("pass") is one outer TRF iteration, so the 64 lanes of a
 // wavefront never wait for each other at frame boundaries -- only the total work per chain
-// has to balance -- and because all lanes of a launch are in the same stage, the stage
+// has to balance -- and because all lanes of a wave are in the same stage, the stage
 // properties (number of unknowns, rotation axes, rank handling) are compile-time constants.
-// No MFMA: the sub-problems are 5x2 / 4x1.
+// seqik_hip.hip calls run_stage<1..4> back to back from one kernel (default) or from one
+// kernel per stage (diagnostics, stage subsets).  No MFMA: the sub-problems are 5x2 / 4x1.
 //
 // Structure that is exploited (none of it changes the arithmetic, see below):
 //   * links that cannot move the end effector (base, "fixed" links, last link) have

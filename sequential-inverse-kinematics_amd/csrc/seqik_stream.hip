@@ -79,7 +79,7 @@ struct SeqikStream {
     std::vector<SeqikLegParams> legs;
     std::vector<SeqikAffine> affine;
     SeqikOptions opt{};
-    hipStream_t h2d = nullptr, compute[2] = {nullptr, nullptr}, d2h = nullptr;
+    hipStream_t h2d = nullptr, compute[3] = {nullptr, nullptr, nullptr}, d2h = nullptr;
     int n_compute = 1;
     std::vector<Slot> slots;
     double *d_init = nullptr;   // carry: [slab_seq * n_legs][7]
@@ -114,7 +114,10 @@ int open_impl(SeqikStream *s)
 {
     STRY(hipSetDevice(s->device));
     STRY(hipStreamCreateWithFlags(&s->h2d, hipStreamNonBlocking));
-    s->n_compute = s->carry ? 1 : 2;  // carried slabs depend on each other: one in-order stream
+    // carried slabs depend on each other: one in-order stream.  Otherwise two slabs' kernels in flight: a third
+    // was measured slower when FK comes back (1.48e8 -> 1.19e8 leg-frames/s) -- the download is the long pole
+    // there, and three slabs computing side by side all finish late and at once instead of feeding it steadily.
+    s->n_compute = s->carry ? 1 : (s->slots.size() < 2 ? 1 : 2);
     for (int i = 0; i < s->n_compute; ++i) STRY(hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking));
     STRY(hipStreamCreateWithFlags(&s->d2h, hipStreamNonBlocking));
     const size_t lf = (size_t)s->slab_seq * s->n_legs * s->n_frames;

@@ -6,6 +6,9 @@ Same module / class names as the reference for this path:
     from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
 
+plus, beyond the reference: ``batch.run_ik_and_fk_many`` (many recordings in one launch),
+``streaming.SeqikStream`` (slabs from pinned host memory), ``frame_parallel`` (one long recording).
+
 All arithmetic runs in ``csrc/libseqik_hip.so`` (hand-written HIP for gfx950) behind the C ABI
 of ``include/seqik.h``; there is no CPU fallback.
 """

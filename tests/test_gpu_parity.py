@@ -316,3 +316,27 @@ def test_single_launch_equals_one_launch_per_stage(lib):
     assert np.array_equal(lib.solve_seq(pose, params, want_fk=False)["angles"], staged["angles"])
     diag = lib.solve_seq(pose, params, want_fk=True, want_diag=True)  # diagnostics always run staged
     assert np.array_equal(diag["angles"], staged["angles"])
+
+
+def test_many_recordings_of_different_length_in_one_call(lib):
+    """batch.run_ik_and_fk_many: recordings of 100, 57, 100 and 8 frames (bucketed; and padded to a common
+    length) == one LegInvKinSeq.run_ik_and_fk per recording, bit for bit."""
+    from seqikpy_amd import data
+    from seqikpy_amd.batch import run_ik_and_fk_many
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    from seqikpy_amd.utils import calculate_body_size
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    kc = KinematicChainSeq(data.BOUNDS_LOCOMOTION, legs, calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs))
+    cuts = [(0, 100), (300, 357), (500, 600), (900, 908)]
+    recs = [{f"{l}_leg": z[f"{l}_pose"][a:b] for l in legs} | {"Neck": np.zeros((1, 1, 3))} for a, b in cuts]
+    single = [LegInvKinSeq(r, kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR").run_ik_and_fk() for r in recs]
+    for pad in (0, 64):
+        many = run_ik_and_fk_many(recs, kc, data.INITIAL_ANGLES_LOCOMOTION, pad_to_multiple=pad)
+        assert len(many) == len(recs)
+        for (ang, fk), (ang1, fk1) in zip(many, single):
+            assert list(ang.keys()) == list(ang1.keys()) and list(fk.keys()) == list(fk1.keys())
+            assert all(np.array_equal(ang[k], ang1[k]) for k in ang)
+            assert all(np.array_equal(fk[k], fk1[k]) for k in fk)
+    assert run_ik_and_fk_many([], kc) == []
