@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Soak test: many made-up legs (random segment lengths, joint limits, seeds on bounds) with unreachable /
+degenerate / repeated targets, HIP path vs the C oracle, bit for bit.  Prints one JSON line.
+
+    python scripts/soak_parity.py --cases 20000 --frames 48          (needs a GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "sequential-inverse-kinematics_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+from conftest import random_leg_case  # noqa: E402
+from oracle import c_oracle  # noqa: E402  (checker)
+from seqikpy_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=20000)
+    ap.add_argument("--frames", type=int, default=48)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    cases = [random_leg_case(rng, args.frames) for _ in range(args.cases)]
+    c_oracle.lib()
+
+    def ref(c):
+        return c_oracle.seq_leg(*c)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(16) as ex:
+        refs = list(ex.map(ref, cases))
+    t_cpu = time.perf_counter() - t0
+    bad, t_gpu = [], 0.0
+    for g0 in range(0, args.cases, 8):       # 8 different legs per launch (the ABI's maximum)
+        grp = cases[g0:g0 + 8]
+        pose = np.stack([c[0] for c in grp])[None]
+        params = [_lib.leg_params_from_arrays(c[1], c[2], c[3]) for c in grp]
+        t0 = time.perf_counter()
+        out = _lib.solve_seq(pose, params, want_fk=True, want_diag=(g0 // 8) % 2 == 0)   # both launch paths
+        t_gpu += time.perf_counter() - t0
+        for i in range(len(grp)):
+            r = refs[g0 + i]
+            ok = np.array_equal(out["angles"][0, i], r["angles"]) and np.array_equal(out["fk"][0, i], r["fk"])
+            if out["nfev"] is not None:
+                ok = ok and np.array_equal(out["nfev"][0, i], r["nfev"]) and np.array_equal(out["status"][0, i], r["status"])
+            if not ok:
+                bad.append(g0 + i)
+    nf = np.stack([r["nfev"] for r in refs])
+    print(json.dumps({"cases": args.cases, "frames_per_case": args.frames, "leg_frames": args.cases * args.frames,
+                      "mismatching_cases": len(bad), "first_mismatches": bad[:10],
+                      "status_histogram": {int(v): int((np.stack([r["status"] for r in refs]) == v).sum())
+                                           for v in range(0, 5)},
+                      "max_nfev": int(nf.max()), "cpu_oracle_seconds": t_cpu, "gpu_seconds_incl_transfers": t_gpu}))
+
+
+if __name__ == "__main__":
+    main()
