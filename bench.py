@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--lanes-per-wave", type=int, default=0, help="chains per wavefront (0 = automatic)")
+    ap.add_argument("--interleave-legs", type=int, default=0,
+                    help="1 = consecutive chains per wave (legs interleaved) instead of leg-pure, longest-leg-first waves")
     ap.add_argument("--staged", action="store_true",
                     help="one launch per stage (SeqikOptions.reserved[1] = 1) instead of the default single launch in "
                          "which every wave takes its chains through the four stages in turn")
@@ -187,7 +189,7 @@ def main():
             # ONE C-ABI call = the four stage kernels; the library records the given HIP events between them
             _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
                                   d_fks[i % len(streams)].data_ptr(), stream=stream.cuda_stream,
-                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave, staged=int(args.staged),
+                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs,
                                   stage_events=[e.cuda_event for e in events] if events else None)
             if gather:
                 gather.submit(b, buf)

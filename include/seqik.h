@@ -80,7 +80,9 @@ typedef struct SeqikOptions {
                              the GPU before they are stacked into the lanes of a wave);
                              [1]: 0 = a run of all four stages without diagnostics is ONE launch (every wave takes its
                              chains through stages 1, 2, 3, 4 in turn; stage_events[0] is then recorded in front of that
-                             kernel and [1]..[4] behind it), 1 = always one launch per stage;  [2..3]: must be 0 */
+                             kernel and [1]..[4] behind it), 1 = always one launch per stage;
+                             [2]: 0 = all lanes of a wavefront carry the same leg, 1 = consecutive chains (legs
+                             interleaved);  [3]: must be 0.  None of these changes a result bit. */
 } SeqikOptions;
 
 /* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.

@@ -32,6 +32,10 @@ int fail(int code, const char *fmt, const char *detail = "")
         if (e_ != hipSuccess) return fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+struct LegOrder {  // dispatch order of the legs, see chain_of_lane()
+    uint8_t leg[8];
+};
+
 struct KernelArgs {
     const double *pose;
     double *angles;
@@ -46,27 +50,66 @@ struct KernelArgs {
     int64_t n_frames;
     int32_t n_legs;
     int32_t lanes_per_wave;       // W: chains a wavefront carries (1..64), see chain_of_lane()
+    LegOrder leg_order;           // dispatch order of the legs
     // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
 };
 
-// Lane -> chain mapping.  A wavefront carries W <= 64 consecutive chains (chain = seq * n_legs + leg).
-// W < 64 when there are few chains: a pass of a wave costs the UNION of the code paths its lanes take, and
-// one wave per SIMD cannot issue back to back, so n chains finish sooner as n / W thin waves spread over all
-// SIMDs than as n / 64 full waves on a few of them.  launch() fills the 1024 SIMDs of the MI355X with thin
-// waves first and only then fattens them; at benchmark sizes W = 64.  (Grouping the lanes of a wave by leg
-// was measured and dropped: legs differ systematically in cost -- a front leg needs ~20 trust-region passes
-// per stage-1 solve on the benchmark data, a hind leg ~16 -- so leg-pure waves finish at different times and
-// the kernels drain unevenly: 2.26e8 -> 2.09e8 solves/s with two batches in flight.)
-// Returns false for lanes that carry no chain.
-__device__ __forceinline__ bool chain_of_lane(int64_t n_chains, int32_t n_legs, int32_t W, int64_t &c, int &leg)
+// Lane -> chain mapping.  A wavefront carries W <= 64 chains OF THE SAME LEG (W consecutive sequences;
+// chain = seq * n_legs + leg), and the waves of one leg are adjacent in the grid, legs in the order of
+// KernelArgs::leg_order:
+//   * same leg = same joint limits, seeds and segment lengths in all lanes, so the lanes of a wave take the
+//     bound-reflection branches together and their costs are alike (legs differ systematically: on the
+//     benchmark data a front leg needs ~20 trust-region passes per stage-1 solve, a hind leg ~16).  Measured
+//     with the single-launch kernel and three batches in flight: 2.52e8 -> 2.64e8 solves/s.  (With one launch
+//     per stage and two batches in flight it had been a loss, 2.26e8 -> 2.09e8: leg-pure waves finish at
+//     different times and every stage kernel then drains unevenly; SeqikOptions.reserved[2] = 1 selects the
+//     leg-interleaved mapping, W consecutive chains per wave.)
+//   * leg order = longest first: launch() sorts the legs by the total width of their joint limits (wider
+//     limits -> targets further from the warm start -> more passes), so the expensive waves are dispatched
+//     first and the cheap ones fill the end of the launch.  One launch alone: 39.9 -> 34.3 ms; three batches
+//     in flight: 2.64e8 -> 2.66e8.  It is a scheduling heuristic only.
+//   * W < 64 when there are few chains: a pass of a wave costs the UNION of the code paths its lanes take, and
+//     one wave per SIMD cannot issue back to back, so n chains finish sooner as n / W thin waves spread over
+//     all SIMDs than as n / 64 full waves on a few of them.  launch() fills the 1024 SIMDs of the MI355X with
+//     thin waves first and only then fattens them; at benchmark sizes W = 64.
+// W < 0 encodes the leg-interleaved mapping with |W| lanes.  Returns false for lanes that carry no chain.
+__device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int32_t W, const LegOrder &order,
+                                              int64_t &c, int &leg)
 {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = (int)(g & 63);
-    c = (g >> 6) * W + lane;
-    leg = (int)(c % n_legs);
-    return lane < W && c < n_chains;
+    const int64_t wave = g >> 6;
+    if (W < 0) {
+        c = wave * (-W) + lane;
+        leg = (int)(c % n_legs);
+        return lane < -W && c < n_seq * n_legs;
+    }
+    const int64_t n_grp = (n_seq + W - 1) / W;  // waves per leg
+    const int64_t slot = wave / n_grp;          // which leg, in dispatch order
+    if (slot >= n_legs) return false;
+    leg = order.leg[slot];
+    const int64_t seq = (wave - slot * n_grp) * W + lane;
+    c = seq * n_legs + leg;
+    return lane < W && seq < n_seq;
+}
+
+// Dispatch order of the legs: descending total width of the joint limits (stable).
+LegOrder make_leg_order(const SeqikLegParams *legs, int32_t n_legs)
+{
+    LegOrder o;
+    double key[8];
+    for (int l = 0; l < 8; ++l) { o.leg[l] = (uint8_t)l; key[l] = 0.0; }
+    for (int l = 0; l < n_legs; ++l)
+        for (int d = 0; d < 7; ++d) key[l] += legs[l].bounds[d][1] - legs[l].bounds[d][0];
+    for (int i = 1; i < n_legs; ++i) {  // insertion sort, descending, stable
+        const uint8_t v = o.leg[i];
+        int j = i - 1;
+        while (j >= 0 && key[o.leg[j]] < key[v]) { o.leg[j + 1] = o.leg[j]; --j; }
+        o.leg[j + 1] = v;
+    }
+    return o;
 }
 
 // How many chains a wavefront should carry: spread the chains over all SIMDs (256 CUs x 4) before stacking
@@ -102,7 +145,7 @@ seqik_stage_kernel(KernelArgs a)
     __syncthreads();
     int64_t c;
     int leg;
-    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
+    if (!chain_of_lane(a.n_seq, a.n_legs, a.lanes_per_wave, a.leg_order, c, leg)) return;
 
     seqik::ChainIO io;
     io.pose = a.pose + c * a.pose_chain;
@@ -139,7 +182,7 @@ seqik_fused_kernel(KernelArgs a)
     __syncthreads();
     int64_t c;
     int leg;
-    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
+    if (!chain_of_lane(a.n_seq, a.n_legs, a.lanes_per_wave, a.leg_order, c, leg)) return;
     seqik::ChainIO io;
     io.pose = a.pose + c * a.pose_chain;
     io.pose_row = a.pose_row;
@@ -205,6 +248,7 @@ struct GenericKernelArgs {
     const double *init;
     int64_t n_chains, n_seq, n_frames;
     int32_t n_legs, lanes_per_wave;
+    LegOrder leg_order;
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
 };
@@ -223,7 +267,7 @@ __global__ void __launch_bounds__(kMaxBlock) seqik_generic_kernel(GenericKernelA
     __syncthreads();
     int64_t c;
     int leg;
-    if (!chain_of_lane(a.n_chains, a.n_legs, a.lanes_per_wave, c, leg)) return;
+    if (!chain_of_lane(a.n_seq, a.n_legs, a.lanes_per_wave, a.leg_order, c, leg)) return;
     seqik::GenericIO io;
     io.pose = a.pose + c * a.pose_chain; io.pose_row = a.pose_row; io.pose_frame = a.pose_frame;
     io.angles = a.angles + c * a.ang_chain; io.ang_dof = a.ang_dof; io.ang_frame = a.ang_frame;
@@ -314,7 +358,7 @@ int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegPa
     return seqik_validate_legs(legs, n_legs, first_stage, last_stage);
 }
 
-int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
+int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegParams *legs,
            const seqik::LegConst *d_legs, int32_t first_stage, int32_t last_stage, double *d_angles,
            double *d_fk, int32_t *d_status, int32_t *d_nfev, const double *d_init, const SeqikLayout *layout,
            const SeqikOptions *opt, hipStream_t stream)
@@ -340,8 +384,13 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
     a.n_seq = n_seq;
+    a.leg_order = make_leg_order(legs, n_legs);
     a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
-    const int64_t n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+    int64_t n_waves = ((n_seq + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
+    if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
+        n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+        a.lanes_per_wave = -a.lanes_per_wave;
+    }
     int64_t grid64 = (n_waves * 64 + block - 1) / block;
     if (grid64 > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
@@ -433,7 +482,7 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     const seqik::LegConst *d_legs = nullptr;
     rc = device_leg_table(legs, affine, n_legs, &d_legs);
     if (rc != SEQIK_OK) return rc;
-    return launch(d_pose, n_seq, n_legs, n_frames, d_legs, first_stage, last_stage, d_angles, d_fk,
+    return launch(d_pose, n_seq, n_legs, n_frames, legs, d_legs, first_stage, last_stage, d_angles, d_fk,
                   d_status, d_nfev, d_init_angles, layout, opt, stream);
 }
 
@@ -476,8 +525,13 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     int block = (opt && opt->block_size > 0) ? opt->block_size : 64;
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
     a.n_seq = n_seq;
+    a.leg_order = make_leg_order(legs, n_legs);
     a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
-    const int64_t n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+    int64_t n_waves = ((n_seq + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;
+    if (opt && opt->reserved[2] == 1) {
+        n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+        a.lanes_per_wave = -a.lanes_per_wave;
+    }
     const dim3 grid((unsigned)((n_waves * 64 + block - 1) / block)), blk(block);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (d_status || d_nfev) hipLaunchKernelGGL(seqik_generic_kernel<true>, grid, blk, 0, stream, a);

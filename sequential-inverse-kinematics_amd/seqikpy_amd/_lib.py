@@ -314,7 +314,7 @@ def _affine_array(affine, n_legs):
 
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
-              device=0, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0):
+              device=0, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0, interleave_legs=0):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
@@ -345,6 +345,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt.block_size = block_size
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
+    opt.reserved[2] = interleave_legs
     if init_angles is not None:
         init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
         if init_angles.shape != (S, L, 7):
@@ -364,7 +365,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
                      first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
-                     stage_events=None, lanes_per_wave=0, staged=0):
+                     stage_events=None, lanes_per_wave=0, staged=0, interleave_legs=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
     ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
@@ -374,6 +375,7 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     opt.block_size = block_size
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
+    opt.reserved[2] = interleave_legs
     if stage_events is not None:
         ev = (ctypes.c_void_p * 5)(*[ctypes.c_void_p(int(e)) for e in stage_events])
         opt.stage_events = ctypes.cast(ev, ctypes.POINTER(ctypes.c_void_p))
