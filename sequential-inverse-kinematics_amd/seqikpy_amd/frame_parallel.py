@@ -28,30 +28,32 @@ from . import _lib
 
 
 def solve_frame_parallel(pose: np.ndarray, legs: List, chunk: int = 64, halo: int = 16, tol: float = 1e-6,
-                         want_fk: bool = True, affine=None, device: int = 0, stats: Optional[Dict] = None):
-    """``pose`` (S, L, N, 5, 3) -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None).
+                         want_fk: bool = True, affine=None, device: int = 0, stats: Optional[Dict] = None,
+                         lead: int = 0, init_angles: Optional[np.ndarray] = None):
+    """``pose`` (S, L, lead + N, 5, 3) -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None).
 
     Equivalent to ``_lib.solve_seq(pose, legs)`` (stages 1-4) up to ``tol``; see the module docstring.
-    ``stats`` (optional dict) receives ``chunks``, ``repaired``, ``rounds``."""
+    ``stats`` (optional dict) receives ``chunks``, ``repaired``, ``rounds`` and ``start_state0``.
+
+    ``lead`` / ``init_angles`` are for pieces of a longer recording (``frame_sharding.py``): the first ``lead``
+    frames are only a run-in for the first chunk (solved, not returned; the state they reach,
+    ``stats["start_state0"]`` (S, L, 7), is what the caller verifies against the true predecessor), and
+    ``init_angles`` (S, L, 7) warm-starts frame 0 instead of the seeds (continuation from a known state)."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
-    S, L, N = pose.shape[:3]
-    if chunk < 1 or halo < 0:
-        raise ValueError("chunk must be >= 1 and halo >= 0")
+    S, L, n_local = pose.shape[:3]
+    if chunk < 1 or halo < 0 or lead < 0 or lead > n_local:
+        raise ValueError("chunk must be >= 1, halo >= 0 and 0 <= lead <= number of frames")
+    N = n_local - lead
     K = -(-N // chunk) if N else 0
     if K <= 1:
-        out = _lib.solve_seq(pose, legs, want_fk=want_fk, affine=affine, device=device)
+        out = _lib.solve_seq(pose, legs, want_fk=want_fk, affine=affine, device=device, init_angles=init_angles)
         if stats is not None:
-            stats.update(chunks=K, repaired=0, rounds=0)
-        return dict(angles=out["angles"], fk=out["fk"])
+            stats.update(chunks=K, repaired=0, rounds=0,
+                         start_state0=out["angles"][:, :, lead - 1].copy() if lead > 0 else None)
+        return dict(angles=out["angles"][:, :, lead:], fk=out["fk"][:, :, lead:] if want_fk else None)
 
     angles = np.empty((S, L, N, 7))
     fk = np.empty((S, L, N, 9, 3)) if want_fk else None
-
-    def window(k, with_halo):
-        """Frame indices of chunk k (clipped copies of the last frame pad the final chunk)."""
-        lo = k * chunk - (halo if with_halo else 0)
-        idx = np.arange(lo, (k + 1) * chunk)
-        return np.clip(idx, 0, N - 1)
 
     def store(k, res_angles, res_fk, offset):
         a, b = k * chunk, min((k + 1) * chunk, N)
@@ -59,20 +61,24 @@ def solve_frame_parallel(pose: np.ndarray, legs: List, chunk: int = 64, halo: in
         if want_fk:
             fk[:, :, a:b] = res_fk[:, :, offset:offset + (b - a)]
 
+    def local(idx):  # output-frame indices (clipped copies of the last frame pad the final chunk) -> pose frames
+        return lead + np.clip(idx, 0, N - 1)
+
     # ---- 1. speculative pass -----------------------------------------------------------------------
-    first = _lib.solve_seq(pose[:, :, window(0, False)], legs, want_fk=want_fk, affine=affine, device=device)
-    store(0, first["angles"], first["fk"], 0)
+    first = _lib.solve_seq(pose[:, :, np.concatenate([np.arange(lead), local(np.arange(chunk))])], legs,
+                           want_fk=want_fk, affine=affine, device=device, init_angles=init_angles)
+    store(0, first["angles"], first["fk"], lead)
+    start_state0 = first["angles"][:, :, lead - 1].copy() if lead > 0 else None
     h = min(halo, chunk)  # a halo longer than a chunk would reach past the predecessor
-    halo_eff = h
-    win = np.stack([np.clip(np.arange(k * chunk - h, (k + 1) * chunk), 0, N - 1) for k in range(1, K)])  # (K-1, W)
+    win = np.stack([local(np.arange(k * chunk - h, (k + 1) * chunk)) for k in range(1, K)])  # (K-1, W)
     batch = pose[:, :, win]                      # (S, L, K-1, W, 5, 3)
     batch = np.ascontiguousarray(batch.transpose(0, 2, 1, 3, 4, 5)).reshape(S * (K - 1), L, win.shape[1], 5, 3)
     spec = _lib.solve_seq(batch, legs, want_fk=want_fk, affine=affine, device=device)
     spec_ang = spec["angles"].reshape(S, K - 1, L, win.shape[1], 7)
     spec_fk = spec["fk"].reshape(S, K - 1, L, win.shape[1], 9, 3) if want_fk else None
     for k in range(1, K):
-        store(k, spec_ang[:, k - 1], spec_fk[:, k - 1] if want_fk else None, halo_eff)
-    # state reached by the halo run just before each chunk (local frame h - 1 = global k * chunk - 1)
+        store(k, spec_ang[:, k - 1], spec_fk[:, k - 1] if want_fk else None, h)
+    # state reached by the halo run just before each chunk (window frame h - 1 = output frame k * chunk - 1)
     start_state = spec_ang[:, :, :, h - 1] if h > 0 else None    # (S, K-1, L, 7)
 
     # ---- 2./3. verify, repair, cascade ----------------------------------------------------------------
@@ -92,7 +98,7 @@ def solve_frame_parallel(pose: np.ndarray, legs: List, chunk: int = 64, halo: in
         # a dirty chunk can be repaired once its predecessor is final
         ready = dirty & ~np.concatenate([np.zeros((S, 1), bool), dirty[:, :-1]], axis=1)
         s_idx, k_idx = np.nonzero(ready)
-        frames = np.stack([np.clip(np.arange(k * chunk, (k + 1) * chunk), 0, N - 1) for k in k_idx])   # (R, chunk)
+        frames = np.stack([local(np.arange(k * chunk, (k + 1) * chunk)) for k in k_idx])               # (R, chunk)
         rp = np.stack([pose[s][:, f] for s, f in zip(s_idx, frames)])                                   # (R, L, chunk, 5, 3)
         init = np.stack([angles[s, :, k * chunk - 1] for s, k in zip(s_idx, k_idx)])                    # (R, L, 7)
         res = _lib.solve_seq(rp, legs, want_fk=want_fk, affine=affine, device=device, init_angles=init)
@@ -108,5 +114,5 @@ def solve_frame_parallel(pose: np.ndarray, legs: List, chunk: int = 64, halo: in
                 if h == 0 or np.abs(start_state[s, k] - angles[s, :, (k + 1) * chunk - 1]).max() > tol:
                     dirty[s, k + 1] = True
     if stats is not None:
-        stats.update(chunks=int(S * K), repaired=int(repaired), rounds=int(rounds))
+        stats.update(chunks=int(S * K), repaired=int(repaired), rounds=int(rounds), start_state0=start_state0)
     return dict(angles=angles, fk=fk)

@@ -98,3 +98,63 @@ def test_gather_pipeline_double_buffering(tmp_path):
     mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     seen = np.load(tmp_path / "seen.npy")
     assert np.array_equal(seen, np.array([[100.0 * s, 100.0 * s + 1] for s in range(5)]))
+
+
+def _frame_shard_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from oracle import c_oracle
+    from seqikpy_amd import _lib, frame_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = ["RF", "LM", "RH"]
+
+    def solve(pose, legs_params, want_fk=True, affine=None, device=0, init_angles=None, **_):
+        S, L, N = pose.shape[:3]
+        ang, fk = np.zeros((S, L, N, 7)), np.zeros((S, L, N, 9, 3))
+        for s in range(S):
+            for li, leg in enumerate(legs):
+                r = c_oracle.seq_leg(pose[s, li], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"],
+                                     init=None if init_angles is None else init_angles[s, li])
+                ang[s, li], fk[s, li] = r["angles"], r["fk"]
+        return dict(angles=ang, fk=fk)
+
+    _lib.solve_seq = solve      # the oracle stands in for the library: this test is about the orchestration
+    pose = np.stack([z[f"{l}_pose"][:610] for l in legs])[None]
+    res = {}
+    for name, tol in (("spec", 1e-6), ("exact", 0.0)):
+        st = {}
+        out = frame_sharding.solve_frame_sharded(pose, legs, chunk=50, halo=8, tol=tol, stats=st)
+        res[name + "_angles"], res[name + "_fk"] = out["angles"], out["fk"]
+        res[name + "_rounds"], res[name + "_slab"] = st["boundary_rounds"], np.array(st["slab"])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    if rank == 0:
+        serial = solve(pose, legs)
+        np.savez(os.path.join(out_dir, "serial.npz"), angles=serial["angles"], fk=serial["fk"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_recording_sharded_by_frame_over_ranks(tmp_path, world):
+    """610 frames x 3 legs cut into slabs of whole 50-frame chunks over 2 / 3 ranks: speculative run-in +
+    boundary verification (== serial to ~tol), and with tol = 0 every boundary is repaired from the true state
+    (== serial bit for bit, after world - 1 rounds); every rank ends up with the whole result."""
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_frame_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    serial = np.load(tmp_path / "serial.npz")
+    slabs = []
+    for r in range(world):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        assert z["spec_angles"].shape == serial["angles"].shape
+        assert np.abs(z["spec_angles"] - serial["angles"]).max() < 2e-5
+        assert np.abs(z["spec_fk"] - serial["fk"]).max() < 2e-5
+        assert np.array_equal(z["exact_angles"], serial["angles"]) and np.array_equal(z["exact_fk"], serial["fk"])
+        assert int(z["exact_rounds"]) == world - 1
+        slabs.append(tuple(z["spec_slab"]))
+    assert slabs[0][0] == 0 and slabs[-1][1] == 610 and all(slabs[i][1] == slabs[i + 1][0] for i in range(world - 1))
