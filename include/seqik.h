@@ -239,6 +239,29 @@ int seqik_stream_wait(SeqikStream *s);
 int seqik_stream_reset_carry(SeqikStream *s);
 int seqik_stream_close(SeqikStream *s);
 
+/*
+ * Alignment statistics: the whole-recording reductions behind AlignPose.align_leg (seqikpy/alignment.py:83-87,
+ * 392-434), i.e. the constants of SeqikAffine.  Per leg seven per-frame series -- coxa x, y, z (get_fixed_pos) and
+ * the lengths of coxa, femur, tibia, tarsus (get_mean_length) -- are extracted from the RAW key points on the GPU
+ * and sorted; _finish returns the requested order statistics, to which the caller applies numpy's own quantile
+ * interpolation / mean / scale formulas (seqikpy_amd/alignment.py does), so the constants are bit-identical to the
+ * reference's.  Host cost avoided: ~5 s per million frames x 6 legs.
+ *   _open     room for capacity_frames frames per leg on device opt->device
+ *   _add      appends n_seq x n_frames frames of every leg: pose [n_seq][n_legs][n_frames][5][3] or `layout`
+ *             (pose strides only), host memory (pose_on_device = 0, blocking) or device memory (enqueued on
+ *             hip_stream); slabs may come in any order
+ *   _finish   sorts; out [n_legs][7][n_ranks] = value at the 0-based ranks `ranks[i]` of each ascending series
+ *             (series order: coxa x, y, z, then the four segment lengths); blocking
+ *   _reset    forget the frames added so far;  _close  free everything
+ */
+typedef struct SeqikAlignStats SeqikAlignStats;
+int seqik_align_stats_open(SeqikAlignStats **out, int32_t n_legs, int64_t capacity_frames, const SeqikOptions *opt);
+int seqik_align_stats_add(SeqikAlignStats *s, const double *pose, int32_t pose_on_device, int64_t n_seq,
+                          int64_t n_frames, const SeqikLayout *layout, void *hip_stream);
+int seqik_align_stats_finish(SeqikAlignStats *s, const int64_t *ranks, int32_t n_ranks, double *out, void *hip_stream);
+int seqik_align_stats_reset(SeqikAlignStats *s);
+int seqik_align_stats_close(SeqikAlignStats *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--no-fk", action="store_true")
     ap.add_argument("--pageable", action="store_true", help="use ordinary numpy buffers instead of pinned ones")
     ap.add_argument("--check", action="store_true", help="compare one slab with a direct solve on aligned data")
+    ap.add_argument("--gpu-stats", action="store_true",
+                    help="also time pass 1: AlignPose's whole-recording statistics from the RAW slabs on the GPU")
     args = ap.parse_args()
 
     legs = data.LEGS
@@ -78,6 +80,25 @@ def main():
     outs = [(alloc((S, L, 7, T)), alloc((S, L, T, 9, 3)) if want_fk else None) for _ in range(args.slots)]
     t_gen = time.perf_counter() - t_gen
 
+    # ---- pass 1: the alignment constants from the RAW slabs (AlignPose's quantile reductions) on the GPU --------
+    stats = None
+    if args.gpu_stats:
+        n_tot = n_slabs * S * T
+        qs = (0.45, 0.55)
+        ranks = [r for q in qs for r in (int(np.floor((n_tot - 1) * q)), min(int(np.floor((n_tot - 1) * q)) + 1, n_tot - 1))]
+        with _lib.AlignStats(L, n_tot) as ast:
+            ast.add(slabs[0].array, n_seq=S, n_frames=T, layout=layout)     # warm-up (allocations, first launch)
+            ast.reset()
+            t0 = time.perf_counter()
+            for k in range(n_slabs):
+                ast.add(slabs[k % args.unique].array, n_seq=S, n_frames=T, layout=layout)
+            order = ast.finish(ranks)
+            dt_stats = time.perf_counter() - t0
+        stats = {"seconds": dt_stats, "frames_per_leg": n_tot, "leg_frames_per_s": n_tot * L / dt_stats,
+                 "what": "7 series per leg extracted from the RAW slabs, radix-sorted, 4 order statistics each "
+                         "(np.quantile 0.45 / 0.55 neighbours) -> fixed_coxa, mean segment lengths, scale",
+                 "median_coxa_x_RF": float(order[0, 0, 0])}
+
     with SeqikStream(params, S, T, affine=affs, layout=layout, want_fk=want_fk, n_slots=args.slots) as st:
         for k in range(min(3, n_slabs)):  # warm-up: allocator pools, first-launch costs
             a, f = outs[k % args.slots]
@@ -115,7 +136,8 @@ def main():
            "frames_per_sequence": T, "slots": args.slots, "unique_slabs": args.unique, "pinned": not args.pageable,
            "fused_alignment": True, "outputs": "7 angles" + (" + 9x3 FK" if want_fk else ""),
            "pcie_GBps_total": units * bytes_per / dt / 1e9, "h2d_GBps": units * 120 / dt / 1e9,
-           "d2h_GBps": units * (bytes_per - 120) / dt / 1e9, "datagen_seconds": t_gen, "check": check}
+           "d2h_GBps": units * (bytes_per - 120) / dt / 1e9, "datagen_seconds": t_gen, "check": check,
+           "alignment_statistics_pass": stats}
     print(json.dumps(out))
     for p in slabs:
         p.free()

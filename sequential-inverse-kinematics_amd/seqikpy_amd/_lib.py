@@ -16,9 +16,9 @@ from .data import DOFS, SEGMENTS
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
-SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_core.hpp", "seqik_consts.hpp",
-           "seqik_head.hpp", "seqik_generic.hpp"]
-COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip"]
+SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_core.hpp",
+           "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp"]
+COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 SEQIK_OK = 0
@@ -173,6 +173,18 @@ def load():
         for name in ("seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.seqik_align_stats_open.restype = ctypes.c_int
+        L.seqik_align_stats_open.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.POINTER(SeqikOptions)]
+        L.seqik_align_stats_add.restype = ctypes.c_int
+        L.seqik_align_stats_add.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.POINTER(SeqikLayout), ctypes.c_void_p]
+        L.seqik_align_stats_finish.restype = ctypes.c_int
+        L.seqik_align_stats_finish.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, _dp,
+                                               ctypes.c_void_p]
+        for name in ("seqik_align_stats_reset", "seqik_align_stats_close"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [ctypes.c_void_p]
         _lib = L
         return _lib
 
@@ -183,7 +195,69 @@ EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
                     "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
                     "seqik_stream_open", "seqik_stream_submit", "seqik_stream_wait", "seqik_stream_reset_carry",
-                    "seqik_stream_close"]
+                    "seqik_stream_close", "seqik_align_stats_open", "seqik_align_stats_add",
+                    "seqik_align_stats_finish", "seqik_align_stats_reset", "seqik_align_stats_close"]
+
+
+class AlignStats:
+    """``seqik_align_stats_*``: order statistics of the seven per-leg series AlignPose reduces (coxa x, y, z and
+    the four segment lengths), computed on the GPU.  ``add`` takes host arrays ``(S, L, N, 5, 3)`` (or a raw
+    device pointer with ``on_device=True``); ``finish(ranks)`` returns ``(L, 7, len(ranks))``."""
+
+    def __init__(self, n_legs, capacity_frames, device=0):
+        self.n_legs = int(n_legs)
+        self._h = ctypes.c_void_p()
+        opt = SeqikOptions()
+        opt.device = device
+        rc = load().seqik_align_stats_open(ctypes.byref(self._h), self.n_legs, int(capacity_frames), ctypes.byref(opt))
+        if rc != SEQIK_OK:
+            self._h = ctypes.c_void_p()
+            _raise(rc)
+
+    def add(self, pose, n_seq=None, n_frames=None, layout=None, on_device=False, stream=0):
+        if on_device:
+            ptr = ctypes.c_void_p(int(pose))
+        else:
+            pose = np.ascontiguousarray(pose, dtype=np.float64)
+            if layout is None:
+                if pose.ndim != 5 or pose.shape[1] != self.n_legs or pose.shape[3:] != (5, 3):
+                    raise ValueError(f"pose must have shape (S, {self.n_legs}, N, 5, 3), got {pose.shape}")
+                n_seq, n_frames = pose.shape[0], pose.shape[2]
+            ptr = ctypes.c_void_p(pose.ctypes.data)
+        rc = load().seqik_align_stats_add(self._h, ptr, 1 if on_device else 0, int(n_seq), int(n_frames),
+                                          ctypes.byref(layout) if layout is not None else None,
+                                          ctypes.c_void_p(stream or None))
+        if rc != SEQIK_OK:
+            _raise(rc)
+
+    def finish(self, ranks, stream=0):
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+        out = np.zeros((self.n_legs, 7, len(ranks)))
+        rc = load().seqik_align_stats_finish(self._h, ranks.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), len(ranks),
+                                             out.ctypes.data_as(_dp), ctypes.c_void_p(stream or None))
+        if rc != SEQIK_OK:
+            _raise(rc)
+        return out
+
+    def reset(self):
+        load().seqik_align_stats_reset(self._h)
+
+    def close(self):
+        if self._h:
+            load().seqik_align_stats_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_attributes(device=0):

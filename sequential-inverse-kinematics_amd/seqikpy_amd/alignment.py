@@ -112,9 +112,53 @@ class AlignPose:
         self.logger.info("Scale factor for %s leg: %s", leg_name, scale)
         return fixed_coxa, float(scale), np.asarray(self.body_template[f"{leg_name}_Coxa"], dtype=np.float64)
 
-    def leg_affines(self) -> Dict[str, Tuple[np.ndarray, float, np.ndarray]]:
-        """Affine constants of every ``*_leg`` entry, keyed by leg name (for the fused GPU path)."""
-        return {seg[:2]: self.leg_affine(arr, seg[:2]) for seg, arr in self.pose_data_dict.items() if "leg" in seg}
+    def leg_affines(self, on_gpu: bool = False, device: int = 0) -> Dict[str, Tuple[np.ndarray, float, np.ndarray]]:
+        """Affine constants of every ``*_leg`` entry, keyed by leg name (for the fused GPU path).
+
+        ``on_gpu=True`` computes the whole-recording reductions (seven quantile pairs per leg) on the MI355X
+        (``seqik_align_stats_*``): the GPU returns the exact order statistics, numpy's own interpolation / mean /
+        scale formulas are applied here, so the constants equal the host path's bit for bit -- at a fraction of
+        its cost for long recordings (host: ~5 s per million frames and six legs)."""
+        segs = [(seg, arr) for seg, arr in self.pose_data_dict.items() if "leg" in seg]
+        if not on_gpu:
+            return {seg[:2]: self.leg_affine(arr, seg[:2]) for seg, arr in segs}
+        from . import _lib
+        n = {np.asarray(arr).shape[0] for _, arr in segs}
+        if len(n) != 1:
+            raise ValueError("on_gpu=True needs the same number of frames for every leg")
+        n = n.pop()
+        pose = np.stack([np.asarray(arr, dtype=np.float64)[:, :5, :] for _, arr in segs])[None]   # (1, L, N, 5, 3)
+        qs = (0.5 - 0.05, 0.5 + 0.05)
+        ranks, gammas = [], []
+        for q in qs:  # numpy's "linear" quantile: virtual index (n - 1) q, neighbours floor / floor + 1
+            vi = (n - 1) * q
+            lo = int(np.floor(vi))
+            ranks += [lo, min(lo + 1, n - 1)]
+            gammas.append(vi - lo)
+        with _lib.AlignStats(len(segs), n, device=device) as st:
+            st.add(pose)
+            order = st.finish(ranks)                                                                  # (L, 7, 4)
+
+        def mean_quantile(v4):
+            vals = []
+            for j, g in enumerate(gammas):  # numpy.lib._function_base_impl._lerp
+                a, b = v4[2 * j], v4[2 * j + 1]
+                diff = b - a
+                r = a + diff * g
+                if g >= 0.5:
+                    r = b - diff * (1 - g)
+                vals.append(r)
+            return 0.5 * (vals[0] + vals[1])
+
+        out = {}
+        for li, (seg, _) in enumerate(segs):
+            leg = seg[:2]
+            fixed = np.array([mean_quantile(order[li, a]) for a in range(3)])
+            mean_length = {name: mean_quantile(order[li, 3 + i]) for i, name in enumerate(["coxa", "femur", "tibia", "tarsus"])}
+            scale = self.find_scale_leg(leg, mean_length)
+            self.logger.info("Scale factor for %s leg: %s", leg, scale)
+            out[leg] = (fixed, float(scale), np.asarray(self.body_template[f"{leg}_Coxa"], dtype=np.float64))
+        return out
 
     # -- host application (reference-identical) ------------------------------------------
     def align_leg(self, leg_array: np.ndarray, leg_name: str) -> np.ndarray:

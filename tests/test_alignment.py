@@ -114,3 +114,77 @@ def test_converters(tmp_path):
     al = AlignPose.from_file_path(tmp_path, file_name="pose3d.*", convert_func=convert_from_anipose_to_dict,
                                   legs_list=["RF", "LF"], log_level="ERROR")
     assert al.pose_data_dict["Thorax"].shape == (11, 3, 3)
+
+
+class _FakeAlignStats:
+    """numpy stand-in for _lib.AlignStats (CPU tier: checks the finishing formulas, not the GPU sort)."""
+
+    def __init__(self, n_legs, capacity, device=0):
+        self.pose = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        pass
+
+    def add(self, pose, **_):
+        self.pose.append(pose)
+
+    def finish(self, ranks):
+        pose = np.concatenate([p.transpose(1, 0, 2, 3, 4).reshape(p.shape[1], -1, 5, 3) for p in self.pose], axis=1)
+        out = np.zeros((pose.shape[0], 7, len(ranks)))
+        for li in range(pose.shape[0]):
+            series = [pose[li, :, 0, a] for a in range(3)]
+            lengths = np.linalg.norm(np.diff(pose[li], axis=1), axis=2)
+            series += [lengths[:, i] for i in range(4)]
+            for j, v in enumerate(series):
+                out[li, j] = np.sort(v)[np.asarray(ranks)]
+        return out
+
+
+def test_gpu_statistics_path_finishing_formulas_equal_numpy(df3d, monkeypatch):
+    """leg_affines(on_gpu=True) applies numpy's quantile interpolation to exact order statistics: with a numpy
+    sort standing in for the GPU the constants equal the host path bit for bit (several lengths: the
+    interpolation weight changes with N)."""
+    from seqikpy_amd import _lib
+    monkeypatch.setattr(_lib, "AlignStats", _FakeAlignStats)
+    z, legs, raw = df3d
+    for n in (1000, 999, 37, 12):
+        cut = {k: v[:n] for k, v in raw.items()}
+        al = AlignPose(cut, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+        host, dev = al.leg_affines(), al.leg_affines(on_gpu=True)
+        for leg in legs:
+            assert np.array_equal(host[leg][0], dev[leg][0]) and host[leg][1] == dev[leg][1], (n, leg)
+
+
+@pytest.mark.gpu
+def test_alignment_statistics_on_gpu(df3d, hiplib):
+    """seqik_align_stats_*: the GPU's order statistics give bit-identical affine constants; slabs added in two
+    pieces and a device-resident planar slab give the same answer."""
+    import torch
+    z, legs, raw = df3d
+    al = AlignPose(raw, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    host, dev = al.leg_affines(), al.leg_affines(on_gpu=True)
+    for leg in legs:
+        assert np.array_equal(host[leg][0], dev[leg][0]) and host[leg][1] == dev[leg][1], leg
+    pose = np.stack([raw[f"{l}_leg"] for l in legs])[None]          # (1, 6, 1000, 5, 3)
+    ranks = [0, 449, 450, 549, 550, 999]
+    with hiplib.AlignStats(6, 1000) as st:
+        st.add(pose)
+        whole = st.finish(ranks)
+        st.reset()
+        st.add(np.ascontiguousarray(pose[:, :, 600:]))
+        st.add(np.ascontiguousarray(pose[:, :, :600]))
+        assert np.array_equal(st.finish(ranks), whole)
+        st.reset()
+        # 10 "sequences" of 100 frames in the planar device layout of the streaming path
+        seqs = np.ascontiguousarray(pose[0].reshape(6, 10, 100, 5, 3).transpose(1, 0, 3, 2, 4))   # (10, 6, 5, 100, 3)
+        d = torch.from_numpy(seqs).cuda()
+        st.add(d.data_ptr(), n_seq=10, n_frames=100, layout=hiplib.planar_layout(100), on_device=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(st.finish(ranks), whole)
+    srt = np.sort(raw["RM_leg"][:, 0, 1])
+    assert np.array_equal(whole[legs.index("RM"), 1], srt[ranks])
+    lengths = np.sort(np.linalg.norm(np.diff(raw["LH_leg"], axis=1), axis=2)[:, 2])
+    assert np.array_equal(whole[legs.index("LH"), 5], lengths[ranks])
