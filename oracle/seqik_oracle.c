@@ -69,6 +69,7 @@
  * sub-problem (see the ACTIVE SET note in oracle_least_squares). */
 #define NULL_ACTIVE_ONLY 0 /* zero columns removed: scipy's own full-rank logic on the active set */
 #define NULL_EXACT_ZERO 1  /* zero columns kept as exactly-zero singular values (m < n: never full rank) */
+#define NULL_WOODBURY 2    /* active columns, m < n: the trust-region step from 3x3 solves instead of an SVD */
 
 /* ------------------------------------------------------------------ */
 /* sin / cos: fdlibm algorithm (Sun Microsystems, public algorithm):   */
@@ -486,6 +487,98 @@ static void solve_lsq_trust_region(int n, int m, const double *uf, const double 
     *alpha_io = alpha;
 }
 
+/* ------------------------------------------------------------------ */
+/* Trust-region step without an SVD (generic chain: n = 7 unknowns, m = 3 residuals).
+ *
+ * scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] ((3 + n) x n).  All it
+ * needs from it is  p(alpha) = -(A^T A + alpha I)^-1 J_h^T f,  ||p||  and  phi'(alpha) = -p^T (A^T A + alpha I)^-1 p / ||p||.
+ * With B = diag(diag_h + alpha) and A^T A = diag(diag_h) + J_h^T J_h the push-through identity gives
+ *     (B + J_h^T J_h)^-1 r = W r - W J_h^T (I_3 + J_h W J_h^T)^-1 J_h W r,     W = B^-1,
+ * i.e. one symmetric 3 x 3 inverse per alpha (by cofactors: no pivoting, valid for indefinite matrices too,
+ * which the last, possibly negative alpha of scipy's m < n root search can produce).  Same root search, same
+ * bracket updates, same final rescaling of p to the trust radius (_lsq/common.py:solve_lsq_trust_region,
+ * m < n branch); alpha_upper = ||s * uf|| / Delta = ||J_h^T f|| / Delta.  The 10 x 7 one-sided Jacobi SVD this
+ * replaces was > 95 % of the generic kernel's instructions. */
+static void sym3_inverse(const double m[6] /* 00 01 02 11 12 22 */, double inv[6])
+{
+    double c00 = FMA(m[3], m[5], -(m[4] * m[4]));
+    double c01 = FMA(m[2], m[4], -(m[1] * m[5]));
+    double c02 = FMA(m[1], m[4], -(m[2] * m[3]));
+    double c11 = FMA(m[0], m[5], -(m[2] * m[2]));
+    double c12 = FMA(m[1], m[2], -(m[0] * m[4]));
+    double c22 = FMA(m[0], m[3], -(m[1] * m[1]));
+    double det = FMA(m[2], c02, FMA(m[1], c01, m[0] * c00));
+    double r = 1.0 / det;
+    inv[0] = c00 * r; inv[1] = c01 * r; inv[2] = c02 * r; inv[3] = c11 * r; inv[4] = c12 * r; inv[5] = c22 * r;
+}
+
+/* q = (B + J_h^T J_h)^-1 r  given W = 1 / (diag_h + alpha) and Minv = (I + J_h W J_h^T)^-1 */
+static void woodbury_solve(int n, double Jh[NRES][MAXN], const double *W, const double Minv[6], const double *r, double *q)
+{
+    double wr[MAXN], t[3], y[3];
+    for (int c = 0; c < n; ++c) wr[c] = W[c] * r[c];
+    for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+        for (int c = 0; c < n; ++c) acc = FMA(Jh[k][c], wr[c], acc);
+        t[k] = acc;
+    }
+    y[0] = FMA(Minv[2], t[2], FMA(Minv[1], t[1], Minv[0] * t[0]));
+    y[1] = FMA(Minv[4], t[2], FMA(Minv[3], t[1], Minv[1] * t[0]));
+    y[2] = FMA(Minv[5], t[2], FMA(Minv[4], t[1], Minv[2] * t[0]));
+    for (int c = 0; c < n; ++c) {
+        double jy = FMA(Jh[2][c], y[2], FMA(Jh[1][c], y[1], Jh[0][c] * y[0]));
+        q[c] = FMA(-W[c], jy, wr[c]);
+    }
+}
+
+/* p(alpha) (un-negated: pp = (B + J_h^T J_h)^-1 J_h^T f), phi and the Newton ratio phi / phi' */
+static void woodbury_phi(int n, double Jh[NRES][MAXN], const double *diag_h, const double *rhs /* J_h^T f */,
+                         double alpha, double Delta, double *pp, double *phi, double *ratio)
+{
+    double W[MAXN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6], q[MAXN];
+    for (int c = 0; c < n; ++c) W[c] = 1.0 / (diag_h[c] + alpha);
+    for (int c = 0; c < n; ++c) {
+        double w0 = W[c] * Jh[0][c], w1 = W[c] * Jh[1][c], w2 = W[c] * Jh[2][c];
+        M[0] = FMA(w0, Jh[0][c], M[0]); M[1] = FMA(w0, Jh[1][c], M[1]); M[2] = FMA(w0, Jh[2][c], M[2]);
+        M[3] = FMA(w1, Jh[1][c], M[3]); M[4] = FMA(w1, Jh[2][c], M[4]); M[5] = FMA(w2, Jh[2][c], M[5]);
+    }
+    sym3_inverse(M, Minv);
+    woodbury_solve(n, Jh, W, Minv, rhs, pp);
+    if (phi) {
+        double p_norm = vnorm(pp, n);
+        woodbury_solve(n, Jh, W, Minv, pp, q);
+        double acc = vdot(pp, q, n);
+        *phi = p_norm - Delta;
+        *ratio = -(*phi * p_norm) / acc;
+    }
+}
+
+static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h, const double *f, double Delta,
+                              double *alpha_io, double *p)
+{
+    double rhs[MAXN], pp[MAXN];
+    for (int c = 0; c < n; ++c) rhs[c] = FMA(Jh[2][c], f[2], FMA(Jh[1][c], f[1], Jh[0][c] * f[0]));
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = vnorm(rhs, n) * inv_Delta;
+    double alpha_lower = 0.0;
+    double alpha = *alpha_io;
+    if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double phi, ratio;
+        woodbury_phi(n, Jh, diag_h, rhs, alpha, Delta, pp, &phi, &ratio);
+        if (phi < 0) alpha_upper = alpha;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio * inv_Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    woodbury_phi(n, Jh, diag_h, rhs, alpha, Delta, pp, NULL, NULL);
+    double scale = Delta / vnorm(pp, n);
+    for (int c = 0; c < n; ++c) p[c] = -(pp[c] * scale);
+    *alpha_io = alpha;
+}
+
 /* _lsq/common.py:step_size_to_bound */
 static double step_size_to_bound(const double *x, const double *s, const double *lb, const double *ub,
                                  int n, int *hits)
@@ -764,11 +857,19 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
             for (int r = 0; r < na; ++r) A[NRES + r][c] = (r == c) ? sqrt(diag_h[i]) : 0.0;
         }
         double s[MAXN], U[MAXROWS][MAXN], V[MAXN][MAXN], uf[MAXN];
-        jacobi_svd(NRES + na, na, A, s, U, V);
-        for (int c = 0; c < na; ++c) {  /* uf = U.T.dot(f_augmented) */
-            double acc = 0.0;
-            for (int k = 0; k < NRES; ++k) acc = FMA(U[k][c], f[k], acc);
-            uf[c] = acc;
+        double Jh_act[NRES][MAXN], diag_act[MAXN];
+        if (null_mode == NULL_WOODBURY) {
+            for (int c = 0; c < na; ++c) {
+                for (int k = 0; k < NRES; ++k) Jh_act[k][c] = Jh[k][act[c]];
+                diag_act[c] = diag_h[act[c]];
+            }
+        } else {
+            jacobi_svd(NRES + na, na, A, s, U, V);
+            for (int c = 0; c < na; ++c) {  /* uf = U.T.dot(f_augmented) */
+                double acc = 0.0;
+                for (int k = 0; k < NRES; ++k) acc = FMA(U[k][c], f[k], acc);
+                uf[c] = acc;
+            }
         }
         double theta = fmax(0.995, 1 - g_norm);
 
@@ -776,7 +877,8 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
         while (actual_reduction <= 0 && nfev < max_nfev) {
             double p_h[MAXN], p[MAXN], step[MAXN], step_h[MAXN];
             double p_act[MAXN];
-            solve_lsq_trust_region(na, NRES, uf, s, V, Delta, &alpha, p_act, null_mode == NULL_EXACT_ZERO);
+            if (null_mode == NULL_WOODBURY) solve_tr_woodbury(na, Jh_act, diag_act, f, Delta, &alpha, p_act);
+            else solve_lsq_trust_region(na, NRES, uf, s, V, Delta, &alpha, p_act, null_mode == NULL_EXACT_ZERO);
             for (int i = 0; i < n; ++i) p_h[i] = 0.0;
             for (int c = 0; c < na; ++c) p_h[act[c]] = p_act[c];
             for (int i = 0; i < n; ++i) p[i] = d[i] * p_h[i];
@@ -1002,6 +1104,11 @@ int oracle_seq_leg(const double *pose, int64_t N, const double *seg, const doubl
  * 581-594): single 9-link chain following the claw (pose row 4), seed =
  * initial_angles["stage_4"]; angles out [N][7] in this build's DOF order.
  */
+/* The generic chain (7 unknowns, 3 residuals) uses the SVD-free trust-region step (solve_tr_woodbury); the
+ * SVD-based variant (NULL_ACTIVE_ONLY) gives the same iteration counts and claw positions and stays selectable. */
+static int g_generic_mode = NULL_WOODBURY;
+void oracle_set_generic_mode(int mode) { g_generic_mode = mode; }
+
 int oracle_generic_leg(const double *pose, int64_t N, const double *seg, const double *bounds,
                        const double *seed9, double *angles, double *fk, int32_t *status, int32_t *nfev,
                        int64_t *err_frame)
@@ -1017,7 +1124,7 @@ int oracle_generic_leg(const double *pose, int64_t N, const double *seg, const d
         const double *kp = pose + t * 15;
         double target[3] = {kp[12] - kp[0], kp[13] - kp[1], kp[14] - kp[2]};
         int st = 0, nf = 0;
-        int rc = oracle_least_squares(&ch, target, prev, sol, &st, &nf, NULL_ACTIVE_ONLY);
+        int rc = oracle_least_squares(&ch, target, prev, sol, &st, &nf, g_generic_mode);
         if (rc != SEQIK_OK) { if (err_frame) *err_frame = t; return rc; }
         for (int i = 1; i < 8; ++i) angles[t * NDOF + LINK_DOF[i]] = sol[i];
         if (status) status[t] = st;

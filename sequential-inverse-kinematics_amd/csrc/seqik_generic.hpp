@@ -86,103 +86,91 @@ SEQIK_HD double diag_form7(const double *a, const double *diag, const double *b)
     return acc;
 }
 
-// oracle jacobi_svd for a (3 + 7) x 7 matrix: singular values (descending), the first three rows of U
-// folded into uf = U^T f, and V (columns = right singular vectors)
-SEQIK_HD void svd7(double A[3 + GN][GN], const double *f, double *s, double V[GN][GN], double *uf)
+// ---------------------------------------------------------------------------
+// Trust-region step without an SVD (mirrors oracle solve_tr_woodbury operation for operation).
+//
+// scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] (10 x 7).  All it needs from
+// it is p(alpha) = -(A^T A + alpha I)^-1 J_h^T f, ||p|| and phi'(alpha) = -p^T (A^T A + alpha I)^-1 p / ||p||.  With
+// B = diag(diag_h + alpha), W = B^-1 and A^T A = diag(diag_h) + J_h^T J_h the push-through identity gives
+//     (B + J_h^T J_h)^-1 r = W r - W J_h^T (I_3 + J_h W J_h^T)^-1 J_h W r,
+// one symmetric 3 x 3 inverse per alpha (by cofactors: no pivoting, fine for the indefinite matrices the last,
+// possibly negative alpha of scipy's m < n root search can produce).  Root search, bracket updates and the final
+// rescaling of p to the trust radius are scipy's (_lsq/common.py:solve_lsq_trust_region, m < n branch);
+// alpha_upper = ||s * uf|| / Delta = ||J_h^T f|| / Delta.  The one-sided Jacobi SVD this replaces (21 rotations x
+// ~8 sweeps per pass, 119 matrix entries live) was > 95 % of this kernel's instructions and the reason it needed
+// 489 registers.
+// ---------------------------------------------------------------------------
+SEQIK_HD void sym3_inverse(const double *m /* 00 01 02 11 12 22 */, double *inv)
 {
-    const double TOL = 8.881784197001252e-16;
-    constexpr int ROWS = 3 + GN;
-    for (int i = 0; i < GN; ++i)
-        for (int j = 0; j < GN; ++j) V[i][j] = (i == j) ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < GN - 1; ++p)
-            for (int q = p + 1; q < GN; ++q) {
-                double alpha = 0.0, beta = 0.0, gamma = 0.0;
-                for (int i = 0; i < ROWS; ++i) {
-                    alpha = fma_(A[i][p], A[i][p], alpha);
-                    beta = fma_(A[i][q], A[i][q], beta);
-                    gamma = fma_(A[i][p], A[i][q], gamma);
-                }
-                if (gamma == 0.0) continue;
-                if (fabs(gamma) <= TOL * sqrt(alpha * beta)) continue;
-                rotated = true;
-                double zeta = (beta - alpha) / (2.0 * gamma);
-                double t = 1.0 / (fabs(zeta) + sqrt(fma_(zeta, zeta, 1.0)));
-                if (zeta < 0.0) t = -t;
-                double c = 1.0 / sqrt(fma_(t, t, 1.0));
-                double sn = c * t;
-                for (int i = 0; i < ROWS; ++i) {
-                    double ap = A[i][p], aq = A[i][q];
-                    A[i][p] = fma_(c, ap, -(sn * aq));
-                    A[i][q] = fma_(sn, ap, c * aq);
-                }
-                for (int i = 0; i < GN; ++i) {
-                    double vp = V[i][p], vq = V[i][q];
-                    V[i][p] = fma_(c, vp, -(sn * vq));
-                    V[i][q] = fma_(sn, vp, c * vq);
-                }
-            }
-        if (!rotated) break;
-    }
-    // singular values and uf per column, then a stable descending sort of the (sv, uf, V column) triples.
-    // The sort is a fully unrolled bubble sort of adjacent compare-exchanges (swap only if strictly
-    // smaller), which yields the same permutation as the oracle's stable insertion sort; every index is a
-    // compile-time constant, so A and V stay in registers (an index array here forced both into scratch
-    // memory and every rotation of the sweeps above to be written through to it).
-    double sv[GN], ufc[GN];
+    double c00 = fma_(m[3], m[5], -(m[4] * m[4]));
+    double c01 = fma_(m[2], m[4], -(m[1] * m[5]));
+    double c02 = fma_(m[1], m[4], -(m[2] * m[3]));
+    double c11 = fma_(m[0], m[5], -(m[2] * m[2]));
+    double c12 = fma_(m[1], m[2], -(m[0] * m[4]));
+    double c22 = fma_(m[0], m[3], -(m[1] * m[1]));
+    double det = fma_(m[2], c02, fma_(m[1], c01, m[0] * c00));
+    double r = 1.0 / det;
+    inv[0] = c00 * r; inv[1] = c01 * r; inv[2] = c02 * r; inv[3] = c11 * r; inv[4] = c12 * r; inv[5] = c22 * r;
+}
+
+// q = (B + J_h^T J_h)^-1 r  given W = 1 / (diag_h + alpha) and Minv = (I + J_h W J_h^T)^-1
+SEQIK_HD void woodbury_solve(const double Jh[3][GN], const double *W, const double *Minv, const double *r, double *q)
+{
+    double wr[GN], t[3], y[3];
 #pragma unroll
-    for (int j = 0; j < GN; ++j) {
+    for (int c = 0; c < GN; ++c) wr[c] = W[c] * r[c];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc = fma_(A[i][j], A[i][j], acc);
-        sv[j] = sqrt(acc);
-        double inv_sv = (sv[j] > 0.0) ? 1.0 / sv[j] : 0.0;
-        double u = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u = fma_(A[k][j] * inv_sv, f[k], u);
-        ufc[j] = u;
+        for (int c = 0; c < GN; ++c) acc = fma_(Jh[k][c], wr[c], acc);
+        t[k] = acc;
     }
+    y[0] = fma_(Minv[2], t[2], fma_(Minv[1], t[1], Minv[0] * t[0]));
+    y[1] = fma_(Minv[4], t[2], fma_(Minv[3], t[1], Minv[1] * t[0]));
+    y[2] = fma_(Minv[5], t[2], fma_(Minv[4], t[1], Minv[2] * t[0]));
 #pragma unroll
-    for (int pass = 0; pass < GN - 1; ++pass)
-#pragma unroll
-        for (int j = 0; j < GN - 1 - pass; ++j) {
-            const bool sw = sv[j] < sv[j + 1];
-            double a = sv[j], b = sv[j + 1];
-            sv[j] = sw ? b : a; sv[j + 1] = sw ? a : b;
-            a = ufc[j]; b = ufc[j + 1];
-            ufc[j] = sw ? b : a; ufc[j + 1] = sw ? a : b;
-#pragma unroll
-            for (int i = 0; i < GN; ++i) {
-                a = V[i][j]; b = V[i][j + 1];
-                V[i][j] = sw ? b : a; V[i][j + 1] = sw ? a : b;
-            }
-        }
-#pragma unroll
-    for (int j = 0; j < GN; ++j) { s[j] = sv[j]; uf[j] = ufc[j]; }
+    for (int c = 0; c < GN; ++c) {
+        double jy = fma_(Jh[2][c], y[2], fma_(Jh[1][c], y[1], Jh[0][c] * y[0]));
+        q[c] = fma_(-W[c], jy, wr[c]);
+    }
 }
 
-SEQIK_HD void phi_and_ratio7(double alpha, const double *suf, const double *s, double Delta, double &phi, double &ratio)
+// pp = (B + J_h^T J_h)^-1 J_h^T f (the un-negated step), and -- when WANT_PHI -- phi and the Newton ratio phi / phi'
+template <bool WANT_PHI>
+SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const double *rhs, double alpha, double Delta,
+                           double *pp, double &phi, double &ratio)
 {
-    double tmp[GN];
-    double acc = 0.0;
-    for (int i = 0; i < GN; ++i) {
-        double r = 1.0 / fma_(s[i], s[i], alpha);
-        tmp[i] = suf[i] * r;
-        acc = fma_(tmp[i] * tmp[i], r, acc);
+    double W[GN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6];
+#pragma unroll
+    for (int c = 0; c < GN; ++c) W[c] = 1.0 / (diag_h[c] + alpha);
+#pragma unroll
+    for (int c = 0; c < GN; ++c) {
+        double w0 = W[c] * Jh[0][c], w1 = W[c] * Jh[1][c], w2 = W[c] * Jh[2][c];
+        M[0] = fma_(w0, Jh[0][c], M[0]); M[1] = fma_(w0, Jh[1][c], M[1]); M[2] = fma_(w0, Jh[2][c], M[2]);
+        M[3] = fma_(w1, Jh[1][c], M[3]); M[4] = fma_(w1, Jh[2][c], M[4]); M[5] = fma_(w2, Jh[2][c], M[5]);
     }
-    double p_norm = vnorm7(tmp);
-    phi = p_norm - Delta;
-    ratio = -(phi * p_norm) / acc;
+    sym3_inverse(M, Minv);
+    woodbury_solve(Jh, W, Minv, rhs, pp);
+    if constexpr (WANT_PHI) {
+        double q[GN];
+        double p_norm = vnorm7(pp);
+        woodbury_solve(Jh, W, Minv, pp, q);
+        double acc = vdot7(pp, q);
+        phi = p_norm - Delta;
+        ratio = -(phi * p_norm) / acc;
+    }
 }
 
-// solve_lsq_trust_region with m = 3 < n = 7: never full rank
-SEQIK_HD void solve_lsq7(const double *uf, const double *s, const double V[GN][GN], double Delta, double &alpha_io, double *p)
+// solve_lsq_trust_region with m = 3 < n = 7 (never full rank), SVD-free
+SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, const double *f, double Delta,
+                                double &alpha_io, double *p)
 {
-    double suf[GN], tmp[GN];
-    for (int i = 0; i < GN; ++i) suf[i] = s[i] * uf[i];
+    double rhs[GN], pp[GN];
+#pragma unroll
+    for (int c = 0; c < GN; ++c) rhs[c] = fma_(Jh[2][c], f[2], fma_(Jh[1][c], f[1], Jh[0][c] * f[0]));
     const double inv_Delta = 1.0 / Delta;
-    double alpha_upper = vnorm7(suf) * inv_Delta;
+    double alpha_upper = vnorm7(rhs) * inv_Delta;
     double alpha_lower = 0.0;
     double alpha = alpha_io;
     if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
@@ -190,20 +178,17 @@ SEQIK_HD void solve_lsq7(const double *uf, const double *s, const double V[GN][G
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         double phi, ratio;
-        phi_and_ratio7(alpha, suf, s, Delta, phi, ratio);
+        woodbury_phi<true>(Jh, diag_h, rhs, alpha, Delta, pp, phi, ratio);
         if (phi < 0) alpha_upper = alpha;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
-    for (int i = 0; i < GN; ++i) tmp[i] = suf[i] / fma_(s[i], s[i], alpha);
-    for (int i = 0; i < GN; ++i) {
-        double acc = 0.0;
-        for (int k = 0; k < GN; ++k) acc = fma_(V[i][k], tmp[k], acc);
-        p[i] = -acc;
-    }
-    double scale = Delta / vnorm7(p);
-    for (int i = 0; i < GN; ++i) p[i] = p[i] * scale;
+    double unused_phi, unused_ratio;
+    woodbury_phi<false>(Jh, diag_h, rhs, alpha, Delta, pp, unused_phi, unused_ratio);
+    double scale = Delta / vnorm7(pp);
+#pragma unroll
+    for (int c = 0; c < GN; ++c) p[c] = -(pp[c] * scale);
     alpha_io = alpha;
 }
 
@@ -430,22 +415,17 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 finished = true;
             } else {
                 double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
-                double A[3 + GN][GN];
                 for (int j = 0; j < GN; ++j) {
                     d[j] = sqrt(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
                 }
                 for (int k = 0; k < 3; ++k)
-                    for (int j = 0; j < GN; ++j) { Jh[k][j] = J[k][j] * d[j]; A[k][j] = Jh[k][j]; }
-                for (int r = 0; r < GN; ++r)
-                    for (int j = 0; j < GN; ++j) A[3 + r][j] = (r == j) ? sqrt(diag_h[j]) : 0.0;
-                double s[GN], V[GN][GN], uf[GN];
-                svd7(A, f, s, V, uf);
+                    for (int j = 0; j < GN; ++j) Jh[k][j] = J[k][j] * d[j];
                 double theta = fmax(0.995, 1 - g_norm);
 
                 double p_h[GN], p[GN], step[GN], step_h[GN];
-                solve_lsq7(uf, s, V, Delta, alpha, p_h);
+                solve_tr_woodbury(Jh, diag_h, f, Delta, alpha, p_h);
                 for (int j = 0; j < GN; ++j) p[j] = d[j] * p_h[j];
                 double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h);
                 double x_new[GN], sn_n[GN], cs_n[GN], f_new[3];
