@@ -69,6 +69,7 @@
  * sub-problem (see the ACTIVE SET note in oracle_least_squares). */
 #define NULL_ACTIVE_ONLY 0 /* zero columns removed: scipy's own full-rank logic on the active set */
 #define NULL_EXACT_ZERO 1  /* zero columns kept as exactly-zero singular values (m < n: never full rank) */
+static int g_closed_form_2x2 = 1;     /* 2 unknowns: closed-form trust-region step (solve_tr_2x2); 0 = one-sided Jacobi SVD (test hook) */
 #define NULL_WOODBURY 2    /* active columns, m < n: the trust-region step from 3x3 solves instead of an SVD */
 
 /* ------------------------------------------------------------------ */
@@ -579,6 +580,77 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
     *alpha_io = alpha;
 }
 
+/* ------------------------------------------------------------------ */
+/* Trust-region step of a 2-unknown problem in closed form (sequential stages 1-3).
+ * A^T A = J_h^T J_h + diag(diag_h) is 2 x 2: (A^T A + alpha I)^-1 by cofactors, the extreme singular values of A
+ * for scipy's rank test from the eigenvalues of A^T A (lambda_max = tr/2 + sqrt(((a-c)/2)^2 + b^2),
+ * lambda_min = det / lambda_max).  Same root search as solve_lsq_trust_region. */
+static void tr2_apply(double a, double b, double c, double alpha, const double *r, double *q, double *inv_det_out)
+{
+    double aa = a + alpha, cc = c + alpha;
+    double det = FMA(aa, cc, -(b * b));
+    double inv = 1.0 / det;
+    q[0] = FMA(cc, r[0], -(b * r[1])) * inv;
+    q[1] = FMA(aa, r[1], -(b * r[0])) * inv;
+    if (inv_det_out) *inv_det_out = inv;
+}
+
+static void tr2_phi(double a, double b, double c, double alpha, const double *r, double Delta, double *pp,
+                    double *phi, double *ratio)
+{
+    double q[2];
+    tr2_apply(a, b, c, alpha, r, pp, NULL);
+    double p_norm = sqrt(FMA(pp[1], pp[1], pp[0] * pp[0]));
+    tr2_apply(a, b, c, alpha, pp, q, NULL);
+    double acc = FMA(pp[1], q[1], pp[0] * q[0]);
+    *phi = p_norm - Delta;
+    *ratio = -(*phi * p_norm) / acc;
+}
+
+static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const double *f, double Delta,
+                         double *alpha_io, double *p, int force_deficient)
+{
+    double a = diag_h[0], b = 0.0, c = diag_h[1], r[2], pp[2];
+    for (int k = 0; k < NRES; ++k) { a = FMA(Jh[k][0], Jh[k][0], a); b = FMA(Jh[k][0], Jh[k][1], b); c = FMA(Jh[k][1], Jh[k][1], c); }
+    r[0] = FMA(Jh[2][0], f[2], FMA(Jh[1][0], f[1], Jh[0][0] * f[0]));
+    r[1] = FMA(Jh[2][1], f[2], FMA(Jh[1][1], f[1], Jh[0][1] * f[0]));
+    int full_rank = 0;
+    if (!force_deficient) {
+        double h = 0.5 * (a - c);
+        double lmax = FMA(0.5, a + c, sqrt(FMA(h, h, b * b)));
+        double lmin = FMA(a, c, -(b * b)) / lmax;
+        full_rank = lmin > 4.437342591868191e-31 * lmax;  /* (3 eps)^2: s_min > eps * m * s_max */
+    }
+    if (full_rank) {
+        tr2_apply(a, b, c, 0.0, r, pp, NULL);
+        if (sqrt(FMA(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; *alpha_io = 0.0; return; }
+    }
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = sqrt(FMA(r[1], r[1], r[0] * r[0])) * inv_Delta;
+    double alpha_lower = 0.0;
+    if (full_rank) {
+        double phi, ratio;
+        tr2_phi(a, b, c, 0.0, r, Delta, pp, &phi, &ratio);
+        alpha_lower = -ratio;
+    }
+    double alpha = *alpha_io;
+    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double phi, ratio;
+        tr2_phi(a, b, c, alpha, r, Delta, pp, &phi, &ratio);
+        if (phi < 0) alpha_upper = alpha;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio * inv_Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    tr2_apply(a, b, c, alpha, r, pp, NULL);
+    double scale = Delta / sqrt(FMA(pp[1], pp[1], pp[0] * pp[0]));
+    p[0] = -(pp[0] * scale); p[1] = -(pp[1] * scale);
+    *alpha_io = alpha;
+}
+
 /* _lsq/common.py:step_size_to_bound */
 static double step_size_to_bound(const double *x, const double *s, const double *lb, const double *ub,
                                  int n, int *hits)
@@ -858,7 +930,8 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
         }
         double s[MAXN], U[MAXROWS][MAXN], V[MAXN][MAXN], uf[MAXN];
         double Jh_act[NRES][MAXN], diag_act[MAXN];
-        if (null_mode == NULL_WOODBURY) {
+        int cf2 = g_closed_form_2x2 && na == 2 && null_mode != NULL_WOODBURY;
+        if (null_mode == NULL_WOODBURY || cf2) {
             for (int c = 0; c < na; ++c) {
                 for (int k = 0; k < NRES; ++k) Jh_act[k][c] = Jh[k][act[c]];
                 diag_act[c] = diag_h[act[c]];
@@ -877,7 +950,8 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
         while (actual_reduction <= 0 && nfev < max_nfev) {
             double p_h[MAXN], p[MAXN], step[MAXN], step_h[MAXN];
             double p_act[MAXN];
-            if (null_mode == NULL_WOODBURY) solve_tr_woodbury(na, Jh_act, diag_act, f, Delta, &alpha, p_act);
+            if (cf2) solve_tr_2x2(Jh_act, diag_act, f, Delta, &alpha, p_act, null_mode == NULL_EXACT_ZERO);
+            else if (null_mode == NULL_WOODBURY) solve_tr_woodbury(na, Jh_act, diag_act, f, Delta, &alpha, p_act);
             else solve_lsq_trust_region(na, NRES, uf, s, V, Delta, &alpha, p_act, null_mode == NULL_EXACT_ZERO);
             for (int i = 0; i < n; ++i) p_h[i] = 0.0;
             for (int c = 0; c < na; ++c) p_h[act[c]] = p_act[c];
@@ -1027,6 +1101,7 @@ static void build_generic_chain(oracle_chain *ch, const double *seg, const doubl
 }
 
 static int g_null_mode_override = -1; /* test hook: force one mode for every stage */
+void oracle_set_closed_form(int on) { g_closed_form_2x2 = on; }
 void oracle_set_null_mode(int mode) { g_null_mode_override = mode; }
 static int seq_null_mode(int stage)
 {

