@@ -338,6 +338,38 @@ static void approx_jacobian(const oracle_chain *ch, const double *x, const doubl
     }
 }
 
+/* TEST HOOK (off): geometric (analytic) Jacobian of the end-effector position: column i = a_i x (p_ee - o_i) for a
+ * revolute link whose axis a_i passes through o_i (both in the base frame), 0 for links without a rotation.
+ * Measured and REJECTED as a replacement of the finite differences: on every well-posed frame of the fixtures the
+ * angles and evaluation counts are the same to three digits, but the round-off of the 2-point differences is what
+ * lets the solver leave the kinematic singularity of the anipose LF episode -- with the exact Jacobian it stays
+ * stuck until frame 304 (reference: 287, finite differences: 286-288), 2 rad off on 16 more frames. */
+static int g_analytic_jac = 0;
+void oracle_set_analytic_jacobian(int on) { g_analytic_jac = on; }
+static void analytic_jacobian(const oracle_chain *ch, const double *x, double J[NRES][MAXN])
+{
+    int n = ch->n;
+    double frame[16], link[16], before[MAXN][16];
+    mat4_identity(frame);
+    for (int i = 0; i < n; ++i) {
+        mat4_mul(frame, ch->base[i], before[i]);
+        link_frame_matrix(ch, i, x[i], link);
+        mat4_mul(frame, link, frame);
+    }
+    double pe[3] = {frame[3], frame[7], frame[11]};
+    for (int i = 0; i < n; ++i) {
+        if (ch->is_origin[i] || !ch->has_rot[i]) { for (int k = 0; k < NRES; ++k) J[k][i] = 0.0; continue; }
+        const double *b = before[i];
+        const double *ax = ch->axis[i];
+        double aw[3], d[3];
+        for (int r = 0; r < 3; ++r) aw[r] = FMA(b[4 * r + 2], ax[2], FMA(b[4 * r + 1], ax[1], b[4 * r] * ax[0]));
+        d[0] = pe[0] - b[3]; d[1] = pe[1] - b[7]; d[2] = pe[2] - b[11];
+        J[0][i] = FMA(aw[1], d[2], -(aw[2] * d[1]));
+        J[1][i] = FMA(aw[2], d[0], -(aw[0] * d[2]));
+        J[2][i] = FMA(aw[0], d[1], -(aw[1] * d[0]));
+    }
+}
+
 /* _lsq/common.py:CL_scaling_vector */
 static void cl_scaling_vector(const double *x, const double *g, const double *lb, const double *ub,
                               int n, double *v, double *dv)
@@ -862,7 +894,7 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
     memcpy(x0, x, n * sizeof(double));
 
     residual(ch, x, target, f);
-    approx_jacobian(ch, x, f, target, J);
+    if (g_analytic_jac) analytic_jacobian(ch, x, J); else approx_jacobian(ch, x, f, target, J);
 
     int nfev = 1;
     int max_nfev = 100 * n;
@@ -992,7 +1024,7 @@ int oracle_least_squares(oracle_chain *ch, const double *target, const double *x
             memcpy(x, x_new, n * sizeof(double));
             memcpy(f, f_new, sizeof(f));
             cost = cost_new;
-            approx_jacobian(ch, x, f, target, J);
+            if (g_analytic_jac) analytic_jacobian(ch, x, J); else approx_jacobian(ch, x, f, target, J);
             for (int i = 0; i < n; ++i) {
                 double acc = 0.0;
                 for (int k = 0; k < NRES; ++k) acc = FMA(J[k][i], f[k], acc);
