@@ -13,9 +13,13 @@ namespace {
 constexpr int kMaxLegs = 8;   // LegConst table staged in LDS (a fly has 6 legs)
 constexpr int kMaxBlock = 256;
 
-// Register budget: waves per SIMD the stage kernels are compiled for (512 / N VGPRs per lane).
+// Register budget: waves per SIMD the stage kernels are compiled for (512 / N registers per lane).  With the
+// closed-form trust-region step the single-launch kernel needs 180 VGPRs; capping it at 168 (three waves per
+// SIMD) costs 12 spilled registers and still wins: 3.10e8 -> 3.47e8 solves/s (four waves = 128 registers spill
+// 120 and lose: 3.0-3.2e8).  The third wave fills the issue slots the two others leave while they wait on
+// dependent f64 chains and quarter-rate reciprocal / square-root seeds.
 #ifndef SEQIK_WAVES_PER_EU
-#define SEQIK_WAVES_PER_EU 2
+#define SEQIK_WAVES_PER_EU 3
 #endif
 
 thread_local char g_err[512] = "";
