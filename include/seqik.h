@@ -76,8 +76,8 @@ typedef struct SeqikOptions {
     void **stage_events;  /* nullable: 5 hipEvent_t handles, recorded on the launch stream in front of the
                              stage-1..4 kernels ([0]..[3], only for stages that run) and behind the last one
                              ([4]) -- lets a caller time the individual kernels of one call (see reserved[1]) */
-    int32_t reserved[4];  /* [0]: chains per wavefront, 1..64 (0 = automatic: the chains are spread over all SIMDs of
-                             the GPU before they are stacked into the lanes of a wave);
+    int32_t reserved[4];  /* [0]: chains per wavefront, 1..64 (0 = automatic: one to four while there are fewer than
+                             1024 chains, 64 from there on);
                              [1]: 0 = a run of all four stages without diagnostics is ONE launch (every wave takes its
                              chains through stages 1, 2, 3, 4 in turn; stage_events[0] is then recorded in front of that
                              kernel and [1]..[4] behind it), 1 = always one launch per stage;

@@ -74,10 +74,9 @@ struct KernelArgs {
 //     limits -> targets further from the warm start -> more passes), so the expensive waves are dispatched
 //     first and the cheap ones fill the end of the launch.  One launch alone: 39.9 -> 34.3 ms; three batches
 //     in flight: 2.64e8 -> 2.66e8.  It is a scheduling heuristic only.
-//   * W < 64 when there are few chains: a pass of a wave costs the UNION of the code paths its lanes take, and
-//     one wave per SIMD cannot issue back to back, so n chains finish sooner as n / W thin waves spread over
-//     all SIMDs than as n / 64 full waves on a few of them.  launch() fills the 1024 SIMDs of the MI355X with
-//     thin waves first and only then fattens them; at benchmark sizes W = 64.
+//   * W < 64 only when there are few chains (pick_lanes_per_wave below): a pass of a wave costs the UNION of the
+//     code paths its lanes take, so a handful of chains run best as one-lane waves; at a thousand chains and
+//     more W = 64.
 // W < 0 encodes the leg-interleaved mapping with |W| lanes.  Returns false for lanes that carry no chain.
 __device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int32_t W, const LegOrder &order,
                                               int64_t &c, int &leg)
@@ -116,19 +115,20 @@ LegOrder make_leg_order(const SeqikLegParams *legs, int32_t n_legs)
     return o;
 }
 
-// How many chains a wavefront should carry: spread the chains over all SIMDs (256 CUs x 4) before stacking
-// them into the lanes of a wave.
+// How many chains a wavefront should carry.  Measured (smooth synthetic data, 64 frames, single launch):
+//     6 chains (one recording)      W = 1: 117 ms   W = 64 (one wave of 6 lanes): 137 ms
+//     1 200 chains                  W = 1: 21.9   W = 3: 14.0   W = 64: 14.8 ms
+//     6 000 chains                  W = 1: 30.4   W = 6: 26.9   W = 12: 19.4   W = 64: 15.9 ms
+//     24 000 chains                 W = 3: 48.7   W = 24: 17.2  W = 64: 18.9 ms
+// A pass of a wave costs the union of the code paths its lanes take, so a handful of chains run best one per
+// wave; but every wave -- however thin -- occupies its SIMD's issue slots for the whole pass, and a thousand thin
+// waves on all CUs run slower than the same chains in a hundred full waves on a few CUs (consistent with a
+// power-limited clock), so from about a thousand chains on full waves win.
 int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt)
 {
     if (opt && opt->reserved[0] >= 1 && opt->reserved[0] <= 64) return opt->reserved[0];
-    static int n_simd = 0;
-    if (n_simd == 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n_simd = (cus > 0 ? cus : 256) * 4;
-    }
-    int64_t w = (n_chains + n_simd - 1) / n_simd;
-    return (int)(w < 1 ? 1 : (w > 64 ? 64 : w));
+    if (n_chains >= 1024) return 64;
+    return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);  // <= 256 thin waves of 1-4 lanes
 }
 
 // One lane per chain, one launch per stage (the reference's own loop order,
@@ -258,8 +258,12 @@ struct GenericKernelArgs {
 };
 
 // Generic (single 9-link chain, 7 unknowns) IK: one lane per chain, one launch.
+#ifndef SEQIK_GENERIC_WAVES_PER_EU
+#define SEQIK_GENERIC_WAVES_PER_EU 1
+#endif
 template <bool WANT_DIAG>
-__global__ void __launch_bounds__(kMaxBlock) seqik_generic_kernel(GenericKernelArgs a)
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_GENERIC_WAVES_PER_EU, SEQIK_GENERIC_WAVES_PER_EU)))
+seqik_generic_kernel(GenericKernelArgs a)
 {
     __shared__ GenericLegTable s_legs[kMaxLegs];
     {
