@@ -111,3 +111,36 @@ def test_synthetic_fk_matches_oracle(oracle):
         q = np.concatenate([[0.0], theta[0, 0, t], [0.0]])
         pos = oracle.stage_fk(4, seg, b, theta[0, 0, t], q) + data.TEMPLATE_NMF_LOCOMOTION["RM_Coxa"]
         assert np.abs(pos[[0, 4, 6, 7, 8]] - pose[0, 0, t]).max() < 1e-12
+
+
+def test_many_recordings_bucketing_and_padding(monkeypatch):
+    """batch.run_ik_and_fk_many: recordings are bucketed by length (optionally rounded up to a multiple, padded by
+    repeating the last frame), one library call per bucket, results cut back and returned in input order."""
+    from seqikpy_amd import _lib, batch, data
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    calls = []
+
+    def fake_solve(pose, legs, want_fk=True, device=0, affine=None):
+        calls.append(pose.shape)
+        S, L, N = pose.shape[:3]
+        ang = np.broadcast_to(pose[..., 1, 0][..., None], (S, L, N, 7)).copy()   # echoes a key-point coordinate
+        return dict(angles=ang, fk=np.zeros((S, L, N, 9, 3)))
+
+    monkeypatch.setattr(_lib, "solve_seq", fake_solve)
+    kc = KinematicChainSeq(data.BOUNDS, ["RF", "LF"])
+    rng = np.random.default_rng(0)
+    recs = [{"RF_leg": rng.normal(size=(n, 5, 3)), "LF_leg": rng.normal(size=(n, 5, 3)), "Neck": np.zeros((1, 1, 3))}
+            for n in (10, 7, 10, 0, 3)]
+    out = batch.run_ik_and_fk_many(recs, kc)
+    assert sorted(calls) == [(1, 2, 3, 5, 3), (1, 2, 7, 5, 3), (2, 2, 10, 5, 3)]
+    for rec, (ang, fk) in zip(recs, out):
+        n = rec["RF_leg"].shape[0]
+        assert list(ang) == [f"Angle_{leg}_{d}" for leg in ("RF", "LF") for d in DOFS] and list(fk) == ["RF_leg", "LF_leg"]
+        assert ang["Angle_LF_FTi_pitch"].shape == (n,) and fk["RF_leg"].shape == (n, 9, 3)
+        assert np.array_equal(ang["Angle_RF_ThC_yaw"], rec["RF_leg"][:, 1, 0])
+    calls.clear()
+    out8 = batch.run_ik_and_fk_many(recs, kc, pad_to_multiple=8)
+    assert sorted(calls) == [(2, 2, 8, 5, 3), (2, 2, 16, 5, 3)]
+    assert all(np.array_equal(a[0]["Angle_LF_ThC_yaw"], b[0]["Angle_LF_ThC_yaw"]) for a, b in zip(out, out8))
+    with pytest.raises(ValueError):
+        batch.run_ik_and_fk_many([{"RF_leg": np.zeros((4, 5, 3)), "LF_leg": np.zeros((5, 5, 3))}], kc)
