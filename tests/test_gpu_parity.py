@@ -341,3 +341,29 @@ def test_many_recordings_of_different_length_in_one_call(lib):
             assert all(np.array_equal(ang[k], ang1[k]) for k in ang)
             assert all(np.array_equal(fk[k], fk1[k]) for k in fk)
     assert run_ik_and_fk_many([], kc) == []
+
+
+def test_concurrent_calls_from_several_host_threads(lib):
+    """The ABI is thread-safe for distinct buffers (per-thread constant-table cache and error string): four
+    threads solving different legs / recordings at once get the same bits as one after the other; repeated
+    stream open / close does not leak device state."""
+    from concurrent.futures import ThreadPoolExecutor
+    from seqikpy_amd.streaming import solve_streamed
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    jobs = []
+    for i in range(8):
+        sub = [legs[i % 6], legs[(i + 2) % 6]]
+        pose = np.stack([z[f"{l}_pose"][40 * i:40 * i + 120] for l in sub])[None]
+        jobs.append((pose, _params(lib, z, sub)))
+    serial = [lib.solve_seq(p, prm, want_fk=True) for p, prm in jobs]
+    with ThreadPoolExecutor(4) as ex:
+        par = list(ex.map(lambda j: lib.solve_seq(j[0], j[1], want_fk=True), jobs))
+    for a, b in zip(serial, par):
+        assert np.array_equal(a["angles"], b["angles"]) and np.array_equal(a["fk"], b["fk"])
+    with ThreadPoolExecutor(3) as ex:
+        st = list(ex.map(lambda j: solve_streamed(np.concatenate([j[0]] * 5), j[1], slab_seq=2), jobs[:6]))
+    for a, b in zip(serial, st):
+        assert all(np.array_equal(b["angles"][k], a["angles"][0]) for k in range(5))
+    for _ in range(20):
+        solve_streamed(jobs[0][0], jobs[0][1], slab_seq=1, n_slots=2)
