@@ -144,3 +144,19 @@ def test_many_recordings_bucketing_and_padding(monkeypatch):
     assert all(np.array_equal(a[0]["Angle_LF_ThC_yaw"], b[0]["Angle_LF_ThC_yaw"]) for a, b in zip(out, out8))
     with pytest.raises(ValueError):
         batch.run_ik_and_fk_many([{"RF_leg": np.zeros((4, 5, 3)), "LF_leg": np.zeros((5, 5, 3))}], kc)
+
+
+def test_host_objects_are_picklable_like_the_reference_parallel_example_needs():
+    """examples/example_leg_inv_kinematics_parallel.py ships (pose_data, leg) to worker processes and builds the
+    chain / IK objects there; users also pickle the objects themselves.  Nothing here may hold a library handle."""
+    import pickle
+    z = load_golden("df3d_100")
+    kc = KinematicChainSeq(BOUNDS, ["RF", "LF"])
+    ik = LegInvKinSeq({"RF_leg": z["RF_pose"], "LF_leg": z["LF_pose"]}, kc, INITIAL_ANGLES, log_level="ERROR")
+    kc2 = pickle.loads(pickle.dumps(kc))
+    ik2 = pickle.loads(pickle.dumps(ik))
+    assert kc2.body_size == kc.body_size and kc2.bounds_dof == kc.bounds_dof
+    assert np.array_equal(ik2.aligned_pos["LF_leg"], ik.aligned_pos["LF_leg"]) and ik2.joint_angles_dict == {}
+    gen = pickle.loads(pickle.dumps(LegInvKinGeneric({"RF_leg": z["RF_pose"]}, KinematicChainGeneric(BOUNDS, ["RF"]),
+                                                     INITIAL_ANGLES, log_level="ERROR")))
+    assert gen.kinematic_chain_class.create_leg_chain("RF").links[-1].name == "RF_Claw"
