@@ -34,7 +34,7 @@ def frame_slab(n_frames: int, world: int, rank: int, chunk: int):
     return min(k0 * chunk, n_frames), min(k1 * chunk, n_frames)
 
 
-def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 64, halo: int = 16, tol: float = 1e-6,
+def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 32, halo: int = 16, tol: float = 1e-6,
                         want_fk: bool = True, affine=None, device: int = 0, group=None,
                         stats: Optional[Dict] = None):
     """``pose`` (S, L, N, 5, 3) -- the same array on every rank, of which a rank only touches its slab and the
