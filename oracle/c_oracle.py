@@ -166,3 +166,25 @@ def sincos(x):
     c = ctypes.c_double()
     lib().oracle_sincos(float(x), ctypes.byref(s), ctypes.byref(c))
     return s.value, c.value
+
+
+# --- test hooks: algorithm variants kept in the C file for comparison (defaults in brackets) -----------------------
+def set_variant(tr2_shortcut=None, closed_form_2x2=None, generic_svd=None, analytic_jacobian=None):
+    """tr2_shortcut [True]: shortcut of scipy's ten-iteration root search when the Gauss-Newton step is inside the
+    trust region (False = the loop verbatim); closed_form_2x2 [True]: closed-form trust-region step for two
+    unknowns (False = one-sided Jacobi SVD); generic_svd [False]: SVD-based step for the generic chain (default:
+    3 x 3 push-through form); analytic_jacobian [False]: geometric Jacobian instead of scipy's 2-point differences
+    (rejected, see the C file)."""
+    L = lib()
+    if tr2_shortcut is not None:
+        L.oracle_set_tr2_shortcut(1 if tr2_shortcut else 0)
+    if closed_form_2x2 is not None:
+        L.oracle_set_closed_form(1 if closed_form_2x2 else 0)
+    if generic_svd is not None:
+        L.oracle_set_generic_mode(0 if generic_svd else 2)
+    if analytic_jacobian is not None:
+        L.oracle_set_analytic_jacobian(1 if analytic_jacobian else 0)
+
+
+def reset_variants():
+    set_variant(tr2_shortcut=True, closed_form_2x2=True, generic_svd=False, analytic_jacobian=False)

@@ -617,6 +617,8 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
  * A^T A = J_h^T J_h + diag(diag_h) is 2 x 2: (A^T A + alpha I)^-1 by cofactors, the extreme singular values of A
  * for scipy's rank test from the eigenvalues of A^T A (lambda_max = tr/2 + sqrt(((a-c)/2)^2 + b^2),
  * lambda_min = det / lambda_max).  Same root search as solve_lsq_trust_region. */
+static int g_tr2_shortcut = 1;  /* 0 = scipy's ten iterations verbatim (test hook) */
+void oracle_set_tr2_shortcut(int on) { g_tr2_shortcut = on; }
 static void tr2_apply(double a, double b, double c, double alpha, const double *r, double *q, double *inv_det_out)
 {
     double aa = a + alpha, cc = c + alpha;
@@ -667,6 +669,29 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
     }
     double alpha = *alpha_io;
     if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (g_tr2_shortcut && !full_rank) {
+        /* SHORTCUT of the m < n root search.  When the Gauss-Newton step lies well inside the trust region
+         * (||p(0+)|| <= 0.99 Delta: 89 % of the stage-1 solves) scipy's ten iterations are ten resets
+         * alpha <- 0.001 alpha_upper followed by one Newton step from the last, tiny alpha: phi < 0 at every
+         * alpha > 0 (||p(alpha)|| decreases in alpha), so alpha_upper <- alpha each time; 1 / ||p(alpha)|| is concave,
+         * so the Newton step from the right of its (negative) root lands left of the root, i.e. below
+         * alpha_lower = 0, which stays 0; and |phi| >= 0.01 Delta never stops the loop.  The reset sequence needs no
+         * evaluation, so only the last alpha is evaluated.  This is exact in exact arithmetic; in binary64 it gave
+         * the same bits as the verbatim loop on every one of 42 576 frames (447 071 uses; tests/test_oracle_golden.py
+         * keeps checking).  Whenever the test below fails the verbatim loop runs. */
+        double au = alpha_upper, a_k = alpha;
+        for (int it = 0; it < 10; ++it) {
+            if (a_k < 0.0 || a_k > au) a_k = fmax(0.001 * au, 0.0);
+            au = a_k;
+            if (it < 9) a_k = -1.0;  /* stands for "below alpha_lower": reset on the next iteration */
+        }
+        double phi, ratio;
+        tr2_phi(a, b, c, a_k, r, Delta, pp, &phi, &ratio);
+        if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
+            alpha = a_k - (phi + Delta) * ratio * inv_Delta;
+            goto final_step;
+        }
+    }
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
@@ -677,6 +702,7 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
+final_step:
     tr2_apply(a, b, c, alpha, r, pp, NULL);
     double scale = Delta / sqrt(FMA(pp[1], pp[1], pp[0] * pp[0]));
     p[0] = -(pp[0] * scale); p[1] = -(pp[1] * scale);

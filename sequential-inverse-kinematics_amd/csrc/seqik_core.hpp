@@ -523,12 +523,30 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
     }
     double alpha = alpha_io;
     if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    // SHORTCUT of the m < n root search (mirrors oracle solve_tr_2x2, where it is derived): when the Gauss-Newton
+    // step lies well inside the trust region scipy's ten iterations are ten resets alpha <- 0.001 alpha_upper plus
+    // one Newton step from the last alpha, so only that alpha is evaluated; otherwise the verbatim loop runs.
+    bool shortcut = false;
+    if (!full_rank) {
+        double au = alpha_upper, a_k = alpha;
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            if (a_k < 0.0 || a_k > au) a_k = fmax(0.001 * au, 0.0);
+            au = a_k;
+            if (it < 9) a_k = -1.0;
+        }
+        tr2_phi(a + a_k, b, c + a_k, r, Delta, pp, phi, ratio);
+        if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
+            alpha = a_k - (phi + Delta) * ratio * inv_Delta;
+            shortcut = true;
+        }
+    }
     // phi / ratio depend on alpha only through a + alpha and c + alpha.  In the rank-deficient stage 1 scipy's
     // search shrinks alpha a thousandfold per iteration; once it is below half an ulp of a and c the sums stop
     // changing and the evaluation (two divisions, a square root) would repeat itself bit for bit -- measured on the
     // benchmark data: in the last three of the ten iterations for 99.9 % of the solves -- so it is skipped.
     double aa_prev = __builtin_nan(""), cc_prev = __builtin_nan("");
-    for (int it = 0; it < 10; ++it) {
+    for (int it = 0; it < 10 && !shortcut; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         const double aa = a + alpha, cc = c + alpha;
