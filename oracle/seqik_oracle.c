@@ -25,10 +25,23 @@
  *        ::approx_derivative/_adjust_scheme_to_bounds/_dense_difference).
  *
  * It is deliberately GENERIC and un-optimised: chains are lists of n links
- * with full 4x4 homogeneous matrices multiplied left to right, the Jacobian has
- * all n columns, the trust-region sub-problem uses an SVD of the full
- * (3+n) x n augmented matrix.  The HIP kernel exploits the structure
- * (2 / 2 / 2 / 1 effective unknowns); this file does not.
+ * with full 4x4 homogeneous matrices multiplied left to right and the Jacobian has
+ * all n columns.  The HIP kernel exploits the structure (2 / 2 / 2 / 1 effective
+ * unknowns); this file does not.
+ *
+ * WHERE THE RESTATEMENT CHOOSES AN EQUIVALENT FORM (each kept switchable, see the
+ * oracle_set_* hooks and tests/test_oracle_golden.py::test_algorithm_variants_kept_as_hooks):
+ *   - inert (exactly-zero) Jacobian columns are removed from the trust-region
+ *     sub-problem (ACTIVE SET note in oracle_least_squares);
+ *   - the sub-problem itself -- scipy: SVD of the (3+n) x n augmented matrix --
+ *     is solved in closed form for two unknowns (solve_tr_2x2) and through 3 x 3
+ *     solves for the generic chain (solve_tr_woodbury); a one-sided Jacobi SVD
+ *     (jacobi_svd) remains for one unknown and as the test-hook variant;
+ *   - scipy's ten-iteration root search is short-cut when the Gauss-Newton step
+ *     lies inside the trust region (bit-identical to the verbatim loop on every
+ *     input tried, see solve_tr_2x2).
+ * None of them moves the distances to the reference's shipped outputs in the third
+ * significant digit.
  *
  * PARITY PINNING: tests/test_oracle_golden.py checks this file against
  *   (1) the shipped outputs of the reference pipeline
