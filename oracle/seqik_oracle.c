@@ -82,6 +82,7 @@
  * sub-problem (see the ACTIVE SET note in oracle_least_squares). */
 #define NULL_ACTIVE_ONLY 0 /* zero columns removed: scipy's own full-rank logic on the active set */
 #define NULL_EXACT_ZERO 1  /* zero columns kept as exactly-zero singular values (m < n: never full rank) */
+static int g_tr2_shortcut = 1;        /* 0 = scipy's ten-iteration root search verbatim (test hook) */
 static int g_closed_form_2x2 = 1;     /* 2 unknowns: closed-form trust-region step (solve_tr_2x2); 0 = one-sided Jacobi SVD (test hook) */
 #define NULL_WOODBURY 2    /* active columns, m < n: the trust-region step from 3x3 solves instead of an SVD */
 
@@ -609,6 +610,20 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
     double alpha_lower = 0.0;
     double alpha = *alpha_io;
     if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (g_tr2_shortcut) {  /* same shortcut as in solve_tr_2x2 (m < n: never full rank) */
+        double au = alpha_upper, a_k = alpha;
+        for (int it = 0; it < 10; ++it) {
+            if (a_k < 0.0 || a_k > au) a_k = fmax(0.001 * au, 0.0);
+            au = a_k;
+            if (it < 9) a_k = -1.0;
+        }
+        double phi, ratio;
+        woodbury_phi(n, Jh, diag_h, rhs, a_k, Delta, pp, &phi, &ratio);
+        if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
+            alpha = a_k - (phi + Delta) * ratio * inv_Delta;
+            goto final_step;
+        }
+    }
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
@@ -619,6 +634,7 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
+final_step:
     woodbury_phi(n, Jh, diag_h, rhs, alpha, Delta, pp, NULL, NULL);
     double scale = Delta / vnorm(pp, n);
     for (int c = 0; c < n; ++c) p[c] = -(pp[c] * scale);
@@ -630,7 +646,6 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
  * A^T A = J_h^T J_h + diag(diag_h) is 2 x 2: (A^T A + alpha I)^-1 by cofactors, the extreme singular values of A
  * for scipy's rank test from the eigenvalues of A^T A (lambda_max = tr/2 + sqrt(((a-c)/2)^2 + b^2),
  * lambda_min = det / lambda_max).  Same root search as solve_lsq_trust_region. */
-static int g_tr2_shortcut = 1;  /* 0 = scipy's ten iterations verbatim (test hook) */
 void oracle_set_tr2_shortcut(int on) { g_tr2_shortcut = on; }
 static void tr2_apply(double a, double b, double c, double alpha, const double *r, double *q, double *inv_det_out)
 {

@@ -174,7 +174,25 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
     double alpha_lower = 0.0;
     double alpha = alpha_io;
     if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-    for (int it = 0; it < 10; ++it) {
+    // shortcut of the m < n root search (see seqik_core.hpp solve_tr_2x2 / oracle solve_tr_2x2): Gauss-Newton step
+    // inside the trust region = ten resets alpha <- 0.001 alpha_upper + one Newton step from the last alpha
+    bool shortcut = false;
+    {
+        double au = alpha_upper, a_k = alpha;
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            if (a_k < 0.0 || a_k > au) a_k = fmax(0.001 * au, 0.0);
+            au = a_k;
+            if (it < 9) a_k = -1.0;
+        }
+        double phi, ratio;
+        woodbury_phi<true>(Jh, diag_h, rhs, a_k, Delta, pp, phi, ratio);
+        if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
+            alpha = a_k - (phi + Delta) * ratio * inv_Delta;
+            shortcut = true;
+        }
+    }
+    for (int it = 0; it < 10 && !shortcut; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         double phi, ratio;
