@@ -142,3 +142,31 @@ def test_stream_slot_reuse_and_reset_carry(lib):
         with pytest.raises(ValueError):
             st.submit(np.ascontiguousarray(np.concatenate([pose[:, :, :T]] * 2)), np.empty((2, 6, T, 7)),
                       np.empty((2, 6, T, 9, 3)))  # n_seq exceeds the slab size
+
+
+@pytest.mark.gpu
+def test_generic_chains_through_the_stream(lib):
+    """generic=True: LegInvKinGeneric chains streamed in slabs (and carried in time) == seqik_solve_generic."""
+    from seqikpy_amd.streaming import SeqikStream
+    zg = load_golden("generic_rf_100")
+    legs = ["RF", "LF"]
+    params = [lib.leg_params_from_arrays(zg[f"{l}_seg"], zg[f"{l}_bounds"], zg[f"{l}_seeds"]) for l in legs]
+    pose = np.stack([zg[f"{l}_pose"][:60] for l in legs])[None]                  # (1, 2, 60, 5, 3)
+    whole = lib.solve_generic(pose, params)
+    outs = []
+    with SeqikStream(params, 1, 20, want_fk=True, n_slots=2, carry=True, generic=True) as st:
+        for k in range(3):
+            a, f = np.empty((1, 2, 20, 7)), np.empty((1, 2, 20, 9, 3))
+            st.submit(np.ascontiguousarray(pose[:, :, 20 * k:20 * (k + 1)]), a, f)
+            outs.append((a, f))
+        st.wait()
+    assert np.array_equal(np.concatenate([o[0] for o in outs], axis=2), whole["angles"])
+    assert np.array_equal(np.concatenate([o[1] for o in outs], axis=2), whole["fk"])
+    seqs = np.concatenate([pose[:, :, :30], pose[:, :, 30:]])                     # 2 independent sequences of 30
+    ref = lib.solve_generic(seqs, params)
+    with SeqikStream(params, 1, 30, want_fk=False, generic=True) as st:
+        a0, a1 = np.empty((1, 2, 30, 7)), np.empty((1, 2, 30, 7))
+        st.submit(np.ascontiguousarray(seqs[:1]), a0)
+        st.submit(np.ascontiguousarray(seqs[1:]), a1)
+        st.wait()
+    assert np.array_equal(a0, ref["angles"][:1]) and np.array_equal(a1, ref["angles"][1:])
