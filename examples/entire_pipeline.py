@@ -8,7 +8,6 @@ converted segment dictionary (converted_dict.pkl) under --path.
 """
 import argparse
 import os
-import pickle
 import sys
 import time
 from pathlib import Path

@@ -1,5 +1,5 @@
 """Dev script: smoke + timing of the stage kernels on replicated df3d data (device-resident buffers)."""
-import os, sys, time, ctypes
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
 import numpy as np

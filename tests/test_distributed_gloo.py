@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from conftest import PKG_PARENT, ROOT, leg_arrays, load_golden
+from conftest import PKG_PARENT, ROOT
 
 
 def _worker(rank, world, port, out_dir):

@@ -3,7 +3,7 @@ orchestration with the oracle standing in for the library, the GPU tier runs the
 import numpy as np
 import pytest
 
-from conftest import LF_DEGENERATE, leg_arrays, load_golden
+from conftest import LF_DEGENERATE, load_golden
 
 from seqikpy_amd import _lib, frame_parallel
 

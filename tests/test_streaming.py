@@ -1,8 +1,6 @@
 """Streaming row (BASELINE config 5): slabs pushed through `seqik_stream_*` give the same bits as one
 `seqik_solve_seq` call -- with a ragged last slab, with the alignment fused (RAW key points), in the
 planar layout from pinned memory, and "in time" (carry) against the unsplit recording."""
-import ctypes
-
 import numpy as np
 import pytest
 
