@@ -961,13 +961,17 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             cl_scaling(x[0], g[0], lb[0], ub[0], v[0], dv[0]);
             if constexpr (NA == 2) cl_scaling(x[1], g[1], lb[1], ub[1], v[1], dv[1]);
             else { v[1] = 1.0; dv[1] = 0.0; }
+            // d = sqrt(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
+            double d[2];
+            d[0] = sqrt(v[0]);
+            d[1] = (NA == 2) ? sqrt(v[1]) : 1.0;
             if (first_pass) {
                 // Delta_0 = || x0 / sqrt(v) || over ALL links (inert entries: v = 1)
                 double acc = sc.x_pre_sq;
                 // (x is still the start point x0 here: no step has been taken yet)
-                double t0 = x[0] / sqrt(v[0]);
+                double t0 = x[0] / d[0];
                 acc = fma_(t0, t0, acc);
-                if constexpr (NA == 2) { double t1 = x[1] / sqrt(v[1]); acc = fma_(t1, t1, acc); }
+                if constexpr (NA == 2) { double t1 = x[1] / d[1]; acc = fma_(t1, t1, acc); }
                 acc = fma_(sc.x_suf, sc.x_suf, acc);
                 Delta = sqrt(acc);
                 if (Delta == 0) Delta = 1.0;
@@ -981,10 +985,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 finished = true;
             } else {
                 // ---- trust-region sub-problem -------------------------------------------
-                double d[2], diag_h[2], g_h[2], Jh[3][2];
+                double diag_h[2], g_h[2], Jh[3][2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    d[j] = sqrt(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
                 }
