@@ -761,24 +761,30 @@ SEQIK_HD void frame_after_active(const StageProblem<STAGE> &P, double sa, double
 }
 
 // End-effector residual for given sin/cos pairs of the active joints.
+// pe (nullable): the end-effector position itself, f = pe - target
 template <int STAGE>
-SEQIK_HD void residual_sc(const StageProblem<STAGE> &P, double sa, double ca, double sb, double cb, double *f)
+SEQIK_HD void residual_sc(const StageProblem<STAGE> &P, double sa, double ca, double sb, double cb, double *f,
+                          double *pe = nullptr)
 {
     Frame after;
     frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) f[i] = (after.r[3 * i + 2] * P.tz_last + after.t[i]) - P.target[i];
+    for (int i = 0; i < 3; ++i) {
+        const double e = after.r[3 * i + 2] * P.tz_last + after.t[i];
+        if (pe) pe[i] = e;
+        f[i] = e - P.target[i];
+    }
 }
 
 // End-effector residual at (xa, xb); also returns the sin/cos pairs.
 template <int STAGE>
 SEQIK_HD void eval_residual(const StageProblem<STAGE> &P, double xa, double xb, double *f,
-                            double &sa, double &ca, double &sb, double &cb)
+                            double &sa, double &ca, double &sb, double &cb, double *pe = nullptr)
 {
     sincos_cw(xa, sa, ca);
     if constexpr (StageTraits<STAGE>::NA == 2) sincos_cw(xb, sb, cb);
     else { sb = 0.0; cb = 1.0; }
-    residual_sc<STAGE>(P, sa, ca, sb, cb, f);
+    residual_sc<STAGE>(P, sa, ca, sb, cb, f, pe);
 }
 
 // 2-point finite-difference Jacobian of the active columns: J[k][j].  Column a perturbs
@@ -909,6 +915,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     bool first_pass = true, new_solve = true;
     double coxa_end[3] = {0.0, 0.0, 0.0};  // stage 4 + FK only
     int64_t t = 0;
+    double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
+    bool have_pe = false;
 
     while (t < io.n_frames) {
         if (new_solve) {
@@ -938,9 +946,26 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 P.target[1] = kp[1] - org[1];
                 P.target[2] = kp[2] - org[2];
             }
-            x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
-            if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
-            eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
+            if constexpr (STAGE == 1) {
+                // Stage 1 has no frame-dependent prefix: the chain position at the warm start x is the one the last
+                // accepted trial of the previous frame computed.  Unless make_strictly_feasible moves x (it sat
+                // within 1e-10 of a bound) the start residual is pe - new target -- the same operations on the same
+                // values as a fresh evaluation -- and the two sin/cos + the chain product are skipped.
+                const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+                const double xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                if (have_pe && xs0 == x[0] && xs1 == x[1]) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) f[i] = pe[i] - P.target[i];
+                } else {
+                    x[0] = xs0; x[1] = xs1;
+                    eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb, pe);
+                    have_pe = true;
+                }
+            } else {
+                x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+                if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
+            }
             cost = 0.5 * dot3(f, f);
             nfev = 1;
             alpha = 0.0;
@@ -1017,10 +1042,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
                                                                      theta, step, step_h);
                 }
-                double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n;
+                double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n, pe_n[3] = {0.0, 0.0, 0.0};
                 x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
                 if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);
-                eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n);
+                eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
                 nfev += 1;
                 double step_h_norm = norm2v<NA>(step_h);
                 double cost_new = 0.5 * dot3(f_new, f_new);
@@ -1053,6 +1078,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     f[0] = f_new[0]; f[1] = f_new[1]; f[2] = f_new[2];
                     cost = cost_new;
                     sa = sa_n; ca = ca_n; sb = sb_n; cb = cb_n;
+                    if constexpr (STAGE == 1) { pe[0] = pe_n[0]; pe[1] = pe_n[1]; pe[2] = pe_n[2]; }
                 }
                 if (!WANT_DIAG && (status != STATUS_NONE || nfev == max_nfev)) finished = true;
             }
