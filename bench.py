@@ -22,6 +22,12 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
+# share a queue run one after the other.  Three solver streams fit -- until RCCL adds its own: measured on one MI355X,
+# 4.13e8 -> 3.0e8 solves/s as soon as a process group exists (same as GPU_MAX_HW_QUEUES=2 without one); with 8
+# queues both cases run at 4.13e8.  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (os.path.join(ROOT, "sequential-inverse-kinematics_amd"), ROOT):
     if p not in sys.path:
@@ -137,6 +143,11 @@ def cpu_baseline(pose, legs, body, n_seq_sample, python_pool=True):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when its communicator
+    # is created, so everything up to the final print goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,12 +159,20 @@ def main():
     device_index = local_rank % max(n_dev, 1)  # (more ranks than GPUs only happens in the gloo dry run)
     torch.cuda.set_device(device_index)
     dist = None
-    if world > 1:
+    # SEQIK_BENCH_FORCE_DIST=1: run the process-group + gather path with a single rank too (rehearsal of the RCCL
+    # code path on a one-GPU box; the gather is then a device-to-device copy)
+    use_dist = world > 1 or os.environ.get("SEQIK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SEQIK_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo": dry runs
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+            # the solver keeps every CU busy for the whole step: give RCCL's stream priority so that the gather's
+            # few workgroups are dispatched as soon as a slot frees up instead of behind the queued solver waves
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index),
+                                    pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -169,10 +188,13 @@ def main():
     d_fk = torch.zeros((S, L, T, 9, 3), dtype=torch.float64, device="cuda")
     main_stream = torch.cuda.current_stream()
     streams = [main_stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
-    n_buf = max(2, len(streams))
+    # angle buffers: one per batch in flight + two spare, so that a gather that is still draining (it only gets
+    # CU slots as solver waves retire) does not hold back the launch that wants to reuse its buffer
+    n_buf = len(streams) + (2 if use_dist else 0)
+    n_buf = max(2, n_buf)
     d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(n_buf)]
     d_fks = [d_fk] + [torch.zeros_like(d_fk) for _ in range(len(streams) - 1)]
-    gather = sharding.GatherPipeline(dist, world, rank, d_ang[0], n_buffers=n_buf) if world > 1 else None
+    gather = sharding.GatherPipeline(dist, world, rank, d_ang[0], n_buffers=n_buf) if use_dist else None
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
@@ -216,6 +238,20 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # Outside the timed region: every buffer the overlapped launches wrote must hold, bit for bit, what one launch
+    # made alone writes (all steps solve the same batch) -- a measurement of launches that disturbed each other
+    # would be worthless.
+    chk_ang, chk_fk = torch.zeros_like(d_ang[0]), torch.zeros_like(d_fk)
+    _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, chk_ang.data_ptr(), chk_fk.data_ptr(),
+                          stream=main_stream.cuda_stream, block_size=args.block, layout=layout,
+                          lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs)
+    torch.cuda.synchronize()
+    used = range(min(n_buf, args.steps + args.warmup))
+    if not all(torch.equal(d_ang[b], chk_ang) for b in used) or \
+            not all(torch.equal(f, chk_fk) for f in d_fks[:min(len(d_fks), args.steps + args.warmup)]):
+        raise SystemExit("bench: overlapped launches did not reproduce a launch made alone -- result invalid")
+    del chk_ang, chk_fk
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(args.steps)])
@@ -274,11 +310,16 @@ def main():
                        "streams": len(streams), "launches_per_step": 4 if args.staged else 1,
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU"},
             "roofline": roofline,
+            "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
+                        "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -116,6 +116,10 @@ int seqik_device_count(void);
 const char *seqik_last_error(void);
 /* Compute units, peak shader clock (kHz) and HBM size of a device (any out pointer may be NULL). */
 int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clock_khz, int64_t *hbm_bytes);
+/* The library keeps one stage hand-off workspace (96 B per leg-frame of the largest call so far) per HIP stream it
+ * has launched on.  This drains the devices and frees them all (they are re-created on demand).  No reference
+ * counterpart: the reference allocates per frame in Python. */
+int seqik_release_workspaces(void);
 
 /* Validates `legs` exactly as the reference would fail at frame 0 (bounds order,
  * seeds inside bounds).  Returns SEQIK_OK or the error code; no GPU needed. */

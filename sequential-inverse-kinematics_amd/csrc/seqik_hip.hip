@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
 #include <vector>
 
 #include "seqik_core.hpp"
@@ -355,6 +357,63 @@ int device_generic_table(const SeqikLegParams *legs, const SeqikAffine *affine, 
     return SEQIK_OK;
 }
 
+// Stage hand-off workspace (12 doubles per leg-frame), one buffer per (device, stream): launches on one stream are
+// ordered, so they can share a buffer; launches on different streams never do.  (Stream-ordered hipMallocAsync /
+// hipFreeAsync per call was the first implementation: with several streams in flight the pool handed a block that a
+// still-running kernel of another stream was using to the next launch.)  Grown on demand, kept until
+// seqik_release_workspaces() or process exit; at most kMaxWorkspaces streams are remembered (least recently used
+// evicted after draining its stream).
+struct Workspace {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    double *d = nullptr;
+    size_t bytes = 0;
+    uint64_t last_use = 0;
+};
+constexpr int kMaxWorkspaces = 16;
+std::mutex g_ws_mutex;
+std::vector<Workspace> g_ws;
+uint64_t g_ws_clock = 0;
+
+int workspace_for(hipStream_t stream, size_t bytes, double **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    Workspace *w = nullptr;
+    for (auto &e : g_ws)
+        if (e.device == dev && e.stream == stream) w = &e;
+    if (!w) {
+        if ((int)g_ws.size() >= kMaxWorkspaces) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g_ws.size(); ++i)
+                if (g_ws[i].last_use < g_ws[lru].last_use) lru = i;
+            if (g_ws[lru].device == dev) {  // (a buffer of another device is left to seqik_release_workspaces)
+                HIP_TRY(hipDeviceSynchronize());
+                if (g_ws[lru].d) HIP_TRY(hipFree(g_ws[lru].d));
+            }
+            g_ws.erase(g_ws.begin() + lru);
+        }
+        g_ws.push_back(Workspace());
+        w = &g_ws.back();
+        w->device = dev;
+        w->stream = stream;
+    }
+    if (w->bytes < bytes) {
+        if (w->d) {
+            HIP_TRY(hipStreamSynchronize(stream));  // an earlier launch on this stream may still use the old buffer
+            HIP_TRY(hipFree(w->d));
+            w->d = nullptr;
+            w->bytes = 0;
+        }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&w->d), bytes));
+        w->bytes = bytes;
+    }
+    w->last_use = ++g_ws_clock;
+    *out = w->d;
+    return SEQIK_OK;
+}
+
 int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegParams *legs,
                int32_t first_stage, int32_t last_stage, const void *pose, const void *angles)
 {
@@ -407,8 +466,12 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (!fk) a.fk = nullptr;
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
-    if (last_stage > first_stage)
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), sizeof(double) * 12 * a.n_chains * n_frames, stream));
+    static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
+    if (last_stage > first_stage) {
+        const size_t ws_bytes = sizeof(double) * 12 * a.n_chains * n_frames;
+        if (pool_workspace) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), ws_bytes, stream));
+        else if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
+    }
     const bool fused = !(opt && opt->reserved[1] == 1) && first_stage == 1 && last_stage == 4 && !diag;
     if (fused) {
         if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
@@ -431,7 +494,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         HIP_TRY(hipGetLastError());
     }
     if (opt && opt->stage_events && !fused) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[4]), stream));
-    if (a.frames) HIP_TRY(hipFreeAsync(a.frames, stream));
+    if (a.frames && pool_workspace) HIP_TRY(hipFreeAsync(a.frames, stream));
     return SEQIK_OK;
 }
 
@@ -449,6 +512,23 @@ int seqik_device_count(void)
 }
 
 const char *seqik_last_error(void) { return g_err; }
+
+int seqik_release_workspaces(void)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    int prev = -1;
+    HIP_TRY(hipGetDevice(&prev));
+    for (auto &w : g_ws) {
+        if (!w.d) continue;
+        HIP_TRY(hipSetDevice(w.device));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(w.d));
+        w.d = nullptr;
+    }
+    g_ws.clear();
+    HIP_TRY(hipSetDevice(prev));
+    return SEQIK_OK;
+}
 
 int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clock_khz, int64_t *hbm_bytes)
 {

@@ -14,6 +14,14 @@ of ``include/seqik.h``; there is no CPU fallback.
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# Streams of a process share GPU_MAX_HW_QUEUES hardware queues (HIP default: 4) and streams on one queue serialise;
+# the streaming pipeline (upload, 2 x compute, download) next to the caller's own streams or RCCL needs more
+# (measured: three solver streams + an RCCL communicator 3.0e8 solves/s with 4 queues, 4.1e8 with 8).  Only
+# effective when this package is imported before the HIP runtime starts; an explicit setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import data, utils  # noqa: F401
 from .kinematic_chain import KinematicChainGeneric, KinematicChainSeq  # noqa: F401
 from .leg_inverse_kinematics import LegInvKinGeneric, LegInvKinSeq  # noqa: F401

@@ -120,6 +120,8 @@ def load():
         L.seqik_abi_version.restype = ctypes.c_int
         L.seqik_device_count.restype = ctypes.c_int
         L.seqik_last_error.restype = ctypes.c_char_p
+        L.seqik_release_workspaces.restype = ctypes.c_int
+        L.seqik_release_workspaces.argtypes = []
         L.seqik_device_attributes.restype = ctypes.c_int
         L.seqik_device_attributes.argtypes = [ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64)]
         L.seqik_validate_legs.restype = ctypes.c_int
@@ -189,7 +191,7 @@ def load():
         return _lib
 
 
-EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes",
+EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
                     "seqik_validate_legs",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
@@ -258,6 +260,13 @@ class AlignStats:
             self.close()
         except Exception:
             pass
+
+
+def release_workspaces():
+    """Frees the per-stream stage hand-off workspaces the library keeps between calls (drains the device)."""
+    rc = load().seqik_release_workspaces()
+    if rc != SEQIK_OK:
+        _raise(rc)
 
 
 def device_attributes(device=0):

@@ -20,7 +20,7 @@ def declared_functions():
 
 def test_header_declares_expected_entry_points():
     assert declared_functions() == sorted(["seqik_abi_version", "seqik_device_count", "seqik_last_error",
-                                           "seqik_device_attributes",
+                                           "seqik_device_attributes", "seqik_release_workspaces",
                                            "seqik_validate_legs", "seqik_solve_seq", "seqik_solve_seq_device",
                                            "seqik_head_angles", "seqik_head_angles_device",
                                            "seqik_validate_legs_generic", "seqik_solve_generic",

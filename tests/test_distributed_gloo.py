@@ -158,3 +158,51 @@ def test_one_recording_sharded_by_frame_over_ranks(tmp_path, world):
         assert int(z["exact_rounds"]) == world - 1
         slabs.append(tuple(z["spec_slab"]))
     assert slabs[0][0] == 0 and slabs[-1][1] == 610 and all(slabs[i][1] == slabs[i + 1][0] for i in range(world - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_gather_pipeline_on_rccl_single_rank(hiplib):
+    """The bench's per-step gather pipeline under a real "nccl" (= RCCL) process group, as far as one GPU allows:
+    one rank (so no peer to receive from: the root's own block is the submitted buffer), high-priority
+    communicator stream, solver launches on three streams, buffers handed round -- every gathered block is the
+    solver's output of that step.  (This test found the stream-ordered workspace pool handing one launch's
+    hand-off frames to another stream's launch; see `Workspace` in csrc/seqik_hip.hip.)"""
+    import torch
+    import torch.distributed as dist
+    from conftest import load_golden
+    from seqikpy_amd import sharding
+    if hiplib.load().seqik_device_count() < 1:
+        pytest.fail("GPU tier needs a GPU")
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    T = 25
+    pose = np.stack([np.stack([z[f"{l}_pose"][k * T:(k + 1) * T] for l in legs]) for k in range(4)])  # (4, 6, T, 5, 3)
+    want = hiplib.solve_seq(pose, params, want_fk=False)["angles"]
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0), pg_options=opts)
+    try:
+        d_pose = [torch.from_numpy(np.ascontiguousarray(pose[k:k + 1])).cuda() for k in range(4)]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(2)]
+        d_ang = [torch.zeros((1, 6, T, 7), dtype=torch.float64, device="cuda") for _ in range(3)]
+        pipe = sharding.GatherPipeline(dist, 1, 0, d_ang[0], n_buffers=3)
+        got = {}
+        for i in range(8):
+            b, k = i % 3, i % 4
+            with torch.cuda.stream(streams[b]):
+                pipe.wait_buffer(b)
+                if i >= 3:
+                    got[i - 3] = pipe.recv[b][0].cpu().numpy().copy()  # ordered after the gather on this stream
+                hiplib.solve_seq_device(d_pose[k].data_ptr(), 1, 6, T, params, d_ang[b].data_ptr(), 0,
+                                        stream=streams[b].cuda_stream)
+                pipe.submit(b, d_ang[b])
+        pipe.drain()
+        torch.cuda.synchronize()
+        for i in range(5, 8):
+            got[i] = pipe.recv[i % 3][0].cpu().numpy().copy()
+        for i in range(8):
+            assert np.array_equal(got[i], want[i % 4:i % 4 + 1]), i
+    finally:
+        dist.destroy_process_group()

@@ -367,3 +367,34 @@ def test_concurrent_calls_from_several_host_threads(lib):
         assert all(np.array_equal(b["angles"][k], a["angles"][0]) for k in range(5))
     for _ in range(20):
         solve_streamed(jobs[0][0], jobs[0][1], slab_seq=1, n_slots=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("want_fk", [False, True])
+def test_launches_in_flight_on_several_streams_equal_serial(lib, want_fk):
+    """The device entry point on three HIP streams back to back, no host synchronisation in between (the
+    benchmark's launch pattern), different key points per launch: every launch returns the bits of the same call
+    made alone.  (Each stream has its own stage hand-off workspace inside the library.)"""
+    import torch
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    T, n_launch = 40, 18
+    poses = [np.stack([z[f"{l}_pose"][(53 * i) % 950:(53 * i) % 950 + T] for l in legs])[None] for i in range(n_launch)]
+    alone = [lib.solve_seq(p, params, want_fk=want_fk) for p in poses]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    d_pose = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in poses]
+    d_ang = [torch.zeros((1, 6, T, 7), dtype=torch.float64, device="cuda") for _ in range(n_launch)]
+    d_fk = [torch.zeros((1, 6, T, 9, 3), dtype=torch.float64, device="cuda") for _ in range(n_launch)]
+    torch.cuda.synchronize()
+    for i in range(n_launch):
+        lib.solve_seq_device(d_pose[i].data_ptr(), 1, 6, T, params, d_ang[i].data_ptr(),
+                             d_fk[i].data_ptr() if want_fk else 0, stream=streams[i % 3].cuda_stream)
+    torch.cuda.synchronize()
+    bad = [i for i in range(n_launch) if not np.array_equal(d_ang[i].cpu().numpy(), alone[i]["angles"])]
+    assert not bad, bad
+    if want_fk:
+        assert all(np.array_equal(d_fk[i].cpu().numpy(), alone[i]["fk"]) for i in range(n_launch))
+    lib.release_workspaces()
+    again = lib.solve_seq(poses[0], params, want_fk=want_fk)  # workspaces come back on demand
+    assert np.array_equal(again["angles"], alone[0]["angles"])
