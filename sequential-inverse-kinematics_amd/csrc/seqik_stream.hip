@@ -114,10 +114,11 @@ int open_impl(SeqikStream *s)
 {
     STRY(hipSetDevice(s->device));
     STRY(hipStreamCreateWithFlags(&s->h2d, hipStreamNonBlocking));
-    // carried slabs depend on each other: one in-order stream.  Otherwise two slabs' kernels in flight: a third
-    // was measured slower when FK comes back (1.48e8 -> 1.19e8 leg-frames/s) -- the download is the long pole
-    // there, and three slabs computing side by side all finish late and at once instead of feeding it steadily.
-    s->n_compute = s->carry ? 1 : (s->slots.size() < 2 ? 1 : 2);
+    // carried slabs depend on each other: one in-order stream.  Otherwise one compute stream per slot, up to three
+    // (10 M frames x 6 legs with FK: 1 stream 0.47 s, 2 0.40 s, 3 0.38 s; without FK 2 0.26 s, 3 0.24 s).  That is
+    // five streams with the copies: they only overlap on separate hardware queues, i.e. with GPU_MAX_HW_QUEUES >= 8
+    // (HIP's default of 4 made the third compute stream a loss: 1.48e8 -> 1.19e8 leg-frames/s).
+    s->n_compute = s->carry ? 1 : (int)(s->slots.size() < 3 ? s->slots.size() : 3);
     for (int i = 0; i < s->n_compute; ++i) STRY(hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking));
     STRY(hipStreamCreateWithFlags(&s->d2h, hipStreamNonBlocking));
     const size_t lf = (size_t)s->slab_seq * s->n_legs * s->n_frames;
