@@ -82,6 +82,17 @@
  * sub-problem (see the ACTIVE SET note in oracle_least_squares). */
 #define NULL_ACTIVE_ONLY 0 /* zero columns removed: scipy's own full-rank logic on the active set */
 #define NULL_EXACT_ZERO 1  /* zero columns kept as exactly-zero singular values (m < n: never full rank) */
+/* Branch statistics of the trust-region step (what share of the solves takes which path: used to reason about
+ * divergence in the lane-per-chain kernels).  Off by default; not thread-safe.
+ * [kind][0] calls, [1] Gauss-Newton step inside the region, [2] shortcut, [3] root loop entered, [4] sum of its
+ * iterations, [5] select_step calls, [6] of which reflective, [8 + k] loops that ran k iterations;
+ * kind 0 = stage 1 (rank deficient), 1 = stages 2-3. */
+static int g_stats_on = 0;
+static long long g_stats[2][24];
+void oracle_stats_reset(int on) { g_stats_on = on; memset(g_stats, 0, sizeof g_stats); }
+void oracle_stats_get(long long *out) { memcpy(out, g_stats, sizeof g_stats); }
+static int g_stats_kind = 0;
+#define STAT(i) do { if (g_stats_on) g_stats[g_stats_kind][i] += 1; } while (0)
 static int g_tr2_shortcut = 1;        /* 0 = scipy's ten-iteration root search verbatim (test hook) */
 static int g_closed_form_2x2 = 1;     /* 2 unknowns: closed-form trust-region step (solve_tr_2x2); 0 = one-sided Jacobi SVD (test hook) */
 #define NULL_WOODBURY 2    /* active columns, m < n: the trust-region step from 3x3 solves instead of an SVD */
@@ -677,6 +688,8 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
     r[0] = FMA(Jh[2][0], f[2], FMA(Jh[1][0], f[1], Jh[0][0] * f[0]));
     r[1] = FMA(Jh[2][1], f[2], FMA(Jh[1][1], f[1], Jh[0][1] * f[0]));
     int full_rank = 0;
+    g_stats_kind = force_deficient ? 0 : 1;
+    STAT(0);
     if (!force_deficient) {
         double h = 0.5 * (a - c);
         double lmax = FMA(0.5, a + c, sqrt(FMA(h, h, b * b)));
@@ -685,7 +698,7 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
     }
     if (full_rank) {
         tr2_apply(a, b, c, 0.0, r, pp, NULL);
-        if (sqrt(FMA(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; *alpha_io = 0.0; return; }
+        if (sqrt(FMA(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { STAT(1); p[0] = -pp[0]; p[1] = -pp[1]; *alpha_io = 0.0; return; }
     }
     const double inv_Delta = 1.0 / Delta;
     double alpha_upper = sqrt(FMA(r[1], r[1], r[0] * r[0])) * inv_Delta;
@@ -717,18 +730,25 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
         tr2_phi(a, b, c, a_k, r, Delta, pp, &phi, &ratio);
         if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
             alpha = a_k - (phi + Delta) * ratio * inv_Delta;
+            STAT(2);
             goto final_step;
         }
     }
-    for (int it = 0; it < 10; ++it) {
-        if (alpha < alpha_lower || alpha > alpha_upper)
-            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
-        double phi, ratio;
-        tr2_phi(a, b, c, alpha, r, Delta, pp, &phi, &ratio);
-        if (phi < 0) alpha_upper = alpha;
-        alpha_lower = fmax(alpha_lower, alpha - ratio);
-        alpha -= (phi + Delta) * ratio * inv_Delta;
-        if (fabs(phi) < 0.01 * Delta) break;
+    STAT(3);
+    {
+        int n_it = 0;
+        for (int it = 0; it < 10; ++it) {
+            if (alpha < alpha_lower || alpha > alpha_upper)
+                alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+            double phi, ratio;
+            tr2_phi(a, b, c, alpha, r, Delta, pp, &phi, &ratio);
+            n_it += 1;
+            if (phi < 0) alpha_upper = alpha;
+            alpha_lower = fmax(alpha_lower, alpha - ratio);
+            alpha -= (phi + Delta) * ratio * inv_Delta;
+            if (fabs(phi) < 0.01 * Delta) break;
+        }
+        if (g_stats_on) { g_stats[g_stats_kind][4] += n_it; g_stats[g_stats_kind][8 + n_it] += 1; }
     }
 final_step:
     tr2_apply(a, b, c, alpha, r, pp, NULL);
@@ -853,6 +873,8 @@ static double select_step(const double *x, double Jh[NRES][MAXN], const double *
 {
     double xp[MAXN];
     for (int i = 0; i < n; ++i) xp[i] = x[i] + p[i];
+    STAT(5);
+    if (!in_bounds(xp, lb, ub, n)) STAT(6);
     if (in_bounds(xp, lb, ub, n)) {
         double p_value = evaluate_quadratic(Jh, g_h, p_h, diag_h, n);
         memcpy(step, p, n * sizeof(double));
