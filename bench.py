@@ -283,6 +283,18 @@ def main():
                         "lane_utilisation": [tj.get(f"{n}_valu_lane_utilisation") for n in names],
                         "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch from "
                                   f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc), timing live"}
+                mix = {c: [tj.get(f"{n}_f64_{c}_insts_per_launch") for n in names] for c in ("add", "mul", "fma", "trans")}
+                utils_ = valu["lane_utilisation"]
+                if all(v is not None for vs in mix.values() for v in vs) and all(u is not None for u in utils_):
+                    # FP64 operations actually performed: wave-level instruction counts by class x 64 lanes x the
+                    # share of active lanes (FMA = 2 flops), against the 78.6 TFLOP/s FP64 vector peak
+                    flops = sum((mix["add"][i] + mix["mul"][i] + mix["trans"][i] + 2.0 * mix["fma"][i]) * 64.0 * utils_[i]
+                                for i in range(len(names)))
+                    tfl = flops / (elapsed / args.steps) / 1e12
+                    peak = simds * 16 * 2 * clock_hz / 1e12
+                    valu["fp64"] = {"f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
+                                    "thread_level_TFLOPs": tfl, "vector_peak_TFLOPs": peak, "frac": tfl / peak,
+                                    "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
     roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_unit": bytes_unit, "avg_launch_ms": dom_ms,

@@ -22,11 +22,12 @@ def pmc(kind):
     return d.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
 
 fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
-pm = pd.concat([fetch, write, sq], axis=1)
+f64 = pmc("f64") if glob.glob(f"{src}/{tag}_f64/*/*_counter_collection.csv") else None
+pm = pd.concat([fetch, write, sq] + ([f64] if f64 is not None else []), axis=1)
 pm.to_csv(f"{dst}/{rnd}_bench_pmc_per_launch.csv")
 b = json.loads(bench_line)
 units = b["config"]["sequences_per_gpu"] * b["config"]["legs"] * b["config"]["frames_per_sequence"]
-out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) on `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline`",
+out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) on `python3 bench.py --no-cpu-baseline`",
        "units_per_launch": units, "variant": b["config"]["variant"],
        "note": "FETCH_SIZE / WRITE_SIZE are in KiB; bytes = value * 1024, mean over the launches of the run. "
                "FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 and under-reports wide (16 B/lane) streaming reads by 2x "
@@ -41,6 +42,9 @@ for k in pm.index:
     # wave-level VALU instructions issued per launch, and the share of the 64 lanes that were active in them
     out[f"{k}_valu_insts_per_launch"] = float(sq.loc[k, "SQ_INSTS_VALU"])
     out[f"{k}_valu_lane_utilisation"] = float(sq.loc[k, "SQ_THREAD_CYCLES_VALU"]) / (64.0 * float(sq.loc[k, "SQ_ACTIVE_INST_VALU"]))
+    if f64 is not None:  # wave-level FP64 instructions by class (FMA counts two flops)
+        for c in ("ADD", "MUL", "FMA", "TRANS"):
+            out[f"{k}_f64_{c.lower()}_insts_per_launch"] = float(f64.loc[k, f"SQ_INSTS_VALU_{c}_F64"])
 json.dump(out, open(f"{dst}/traffic_{rnd}.json", "w"), indent=1)
 print(pm.round(0).to_string())
 print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("bytes_per_launch")}, indent=0))
