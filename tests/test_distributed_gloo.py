@@ -93,11 +93,14 @@ def _pipeline_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_gather_pipeline_double_buffering(tmp_path):
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_pipeline_double_buffering(tmp_path, world):
+    """Rank 0 posts one receive per peer and step (grouped point-to-point), the peers one send each; buffers
+    alternate; what rank 0 sees for step s is every rank's block of step s."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     seen = np.load(tmp_path / "seen.npy")
-    assert np.array_equal(seen, np.array([[100.0 * s, 100.0 * s + 1] for s in range(5)]))
+    assert np.array_equal(seen, np.array([[100.0 * s + r for r in range(world)] for s in range(5)]))
 
 
 def _frame_shard_worker(rank, world, port, out_dir):
