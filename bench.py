@@ -36,7 +36,7 @@ for p in (os.path.join(ROOT, "sequential-inverse-kinematics_amd"), ROOT):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (loads the HIP runtime that libseqik_hip.so binds to)
 
-from seqikpy_amd import _lib, data, sharding, synthetic, utils  # noqa: E402
+from seqikpy_amd import _lib, data, peer_gather, sharding, synthetic, utils  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # Algorithmic HBM bytes per leg-frame (DESIGN.md "Kernels"):
@@ -194,7 +194,10 @@ def main():
     n_buf = max(2, n_buf)
     d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(n_buf)]
     d_fks = [d_fk] + [torch.zeros_like(d_fk) for _ in range(len(streams) - 1)]
-    gather = sharding.GatherPipeline(dist, world, rank, d_ang[0], n_buffers=n_buf) if use_dist else None
+    # final joint-angle gather: peer writes over xGMI when every rank can map rank 0's buffers and each link
+    # carries a block well within a step (336 MB / 14.5 ms = 23 GB/s), grouped RCCL point-to-point otherwise
+    gather, gather_how = (peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=25.0)
+                          if use_dist else (None, None))
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
@@ -320,7 +323,8 @@ def main():
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
                        "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
                        "streams": len(streams), "launches_per_step": 4 if args.staged else 1,
-                       "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU"},
+                       "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
+                       **({"gather": gather_how} if gather_how else {})},
             "roofline": roofline,
             "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
                         "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
@@ -333,6 +337,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if dist:
+        if hasattr(gather, "close"):
+            gather.close()
         dist.barrier()
         dist.destroy_process_group()
 

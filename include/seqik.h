@@ -206,6 +206,29 @@ int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int
                              int32_t compute_ant, double *d_angles, void *hip_stream);
 
 /*
+ * Peer gather ("RCCL over xGMI only for the final joint-angle gather").  One process per GPU; the rank
+ * that collects the joint angles allocates its receive buffers with seqik_peer_alloc and publishes their handles
+ * (SEQIK_PEER_HANDLE_BYTES opaque bytes, sent through any channel, e.g. torch.distributed); every other rank
+ * maps its slot with seqik_peer_open and pushes its angle block into it with seqik_peer_copy after each solve:
+ * a copy-engine transfer over the direct xGMI link, ordered on the given HIP stream, no compute unit busy on
+ * either GPU.  Completion / reuse of a slot is signalled by the caller (seqikpy_amd/peer_gather.py: an 8-byte
+ * all-reduce enqueued behind the copy).  The reference has no counterpart (its parallel example returns pickled
+ * dictionaries from a multiprocessing.Pool, examples/example_leg_inv_kinematics_parallel.py:186-187).
+ *
+ *   seqik_peer_alloc / _free     device memory that can be exported (one allocation per call)
+ *   seqik_peer_export            handle of such an allocation
+ *   seqik_peer_open / _close     map / unmap another process's allocation on the current device
+ *   seqik_peer_copy              asynchronous device-to-device copy (either side may be a mapped pointer)
+ */
+#define SEQIK_PEER_HANDLE_BYTES 64
+int seqik_peer_alloc(void **d_ptr, size_t bytes);
+int seqik_peer_free(void *d_ptr);
+int seqik_peer_export(const void *d_ptr, unsigned char *handle);
+int seqik_peer_open(const unsigned char *handle, void **d_ptr);
+int seqik_peer_close(void *d_ptr);
+int seqik_peer_copy(void *d_dst, const void *d_src, size_t bytes, void *hip_stream);
+
+/*
  * Streaming (BASELINE config 5): recordings that do not have to fit or live in HBM are pushed through
  * the kernels in SLABS of n_seq sequences x n_legs x n_frames from host buffers.  The reference's
  * counterpart is one AlignPose.align_pose + LegInvKinSeq.run_ik_and_fk call per piece of a recording

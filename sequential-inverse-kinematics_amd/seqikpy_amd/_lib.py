@@ -16,9 +16,9 @@ from .data import DOFS, SEGMENTS
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
-SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_core.hpp",
+SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip", "seqik_core.hpp",
            "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp"]
-COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip"]
+COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
 SEQIK_OK = 0
@@ -122,6 +122,13 @@ def load():
         L.seqik_last_error.restype = ctypes.c_char_p
         L.seqik_release_workspaces.restype = ctypes.c_int
         L.seqik_release_workspaces.argtypes = []
+        _vpp = ctypes.POINTER(ctypes.c_void_p)
+        for name, args in (("seqik_peer_alloc", [_vpp, ctypes.c_size_t]), ("seqik_peer_free", [ctypes.c_void_p]),
+                           ("seqik_peer_export", [ctypes.c_void_p, ctypes.c_char_p]),
+                           ("seqik_peer_open", [ctypes.c_char_p, _vpp]), ("seqik_peer_close", [ctypes.c_void_p]),
+                           ("seqik_peer_copy", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p])):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = args
         L.seqik_device_attributes.restype = ctypes.c_int
         L.seqik_device_attributes.argtypes = [ctypes.c_int32, _ip, _ip, ctypes.POINTER(ctypes.c_int64)]
         L.seqik_validate_legs.restype = ctypes.c_int
@@ -193,6 +200,8 @@ def load():
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
                     "seqik_validate_legs",
+                    "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
+                    "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
                     "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
@@ -260,6 +269,64 @@ class AlignStats:
             self.close()
         except Exception:
             pass
+
+
+PEER_HANDLE_BYTES = 64
+
+
+class PeerBuffer:
+    """Device memory that other processes can map (``seqik_peer_alloc`` / ``_export``) or the mapping of another
+    process's buffer (``PeerBuffer.open(handle, nbytes)``).  ``tensor(shape)`` views it as a float64 torch tensor."""
+
+    def __init__(self, nbytes, _mapped_ptr=None):
+        self.nbytes = int(nbytes)
+        self.mapped = _mapped_ptr is not None
+        if self.mapped:
+            self.ptr = _mapped_ptr
+        else:
+            p = ctypes.c_void_p()
+            rc = load().seqik_peer_alloc(ctypes.byref(p), self.nbytes)
+            if rc != SEQIK_OK:
+                _raise(rc)
+            self.ptr = p.value
+
+    @classmethod
+    def open(cls, handle: bytes, nbytes):
+        assert len(handle) == PEER_HANDLE_BYTES
+        p = ctypes.c_void_p()
+        rc = load().seqik_peer_open(handle, ctypes.byref(p))
+        if rc != SEQIK_OK:
+            _raise(rc)
+        return cls(nbytes, _mapped_ptr=p.value)
+
+    def handle(self) -> bytes:
+        buf = ctypes.create_string_buffer(PEER_HANDLE_BYTES)
+        rc = load().seqik_peer_export(self.ptr, buf)
+        if rc != SEQIK_OK:
+            _raise(rc)
+        return buf.raw
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes // 8,), "typestr": "<f8", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self, shape):
+        import torch
+        return torch.as_tensor(self, device="cuda").view(shape)
+
+    def close(self):
+        if self.ptr:
+            rc = load().seqik_peer_close(self.ptr) if self.mapped else load().seqik_peer_free(self.ptr)
+            self.ptr = None
+            if rc != SEQIK_OK:
+                _raise(rc)
+
+
+def peer_copy(dst_ptr, src_ptr, nbytes, stream=0):
+    """``seqik_peer_copy``: asynchronous device-to-device copy on ``stream`` (raw pointers)."""
+    rc = load().seqik_peer_copy(dst_ptr, src_ptr, nbytes, ctypes.c_void_p(stream))
+    if rc != SEQIK_OK:
+        _raise(rc)
 
 
 def release_workspaces():

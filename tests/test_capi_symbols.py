@@ -21,7 +21,8 @@ def declared_functions():
 def test_header_declares_expected_entry_points():
     assert declared_functions() == sorted(["seqik_abi_version", "seqik_device_count", "seqik_last_error",
                                            "seqik_device_attributes", "seqik_release_workspaces",
-                                           "seqik_validate_legs", "seqik_solve_seq", "seqik_solve_seq_device",
+                                           "seqik_validate_legs", "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export",
+                                           "seqik_peer_open", "seqik_peer_close", "seqik_peer_copy", "seqik_solve_seq", "seqik_solve_seq_device",
                                            "seqik_head_angles", "seqik_head_angles_device",
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
                                            "seqik_solve_generic_device",

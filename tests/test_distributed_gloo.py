@@ -165,7 +165,8 @@ def test_one_recording_sharded_by_frame_over_ranks(tmp_path, world):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-def test_gather_pipeline_on_rccl_single_rank(hiplib):
+@pytest.mark.parametrize("kind", ["rccl point-to-point", "peer writes"])
+def test_gather_pipeline_on_rccl_single_rank(hiplib, kind):
     """The bench's per-step gather pipeline under a real "nccl" (= RCCL) process group, as far as one GPU allows:
     one rank (so no peer to receive from: the root's own block is the submitted buffer), high-priority
     communicator stream, solver launches on three streams, buffers handed round -- every gathered block is the
@@ -174,7 +175,7 @@ def test_gather_pipeline_on_rccl_single_rank(hiplib):
     import torch
     import torch.distributed as dist
     from conftest import load_golden
-    from seqikpy_amd import sharding
+    from seqikpy_amd import peer_gather, sharding
     if hiplib.load().seqik_device_count() < 1:
         pytest.fail("GPU tier needs a GPU")
     z = load_golden("df3d_100")
@@ -184,13 +185,18 @@ def test_gather_pipeline_on_rccl_single_rank(hiplib):
     pose = np.stack([np.stack([z[f"{l}_pose"][k * T:(k + 1) * T] for l in legs]) for k in range(4)])  # (4, 6, T, 5, 3)
     want = hiplib.solve_seq(pose, params, want_fk=False)["angles"]
     opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+    port = 29541 if kind == "peer writes" else 29542
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0), pg_options=opts)
     try:
         d_pose = [torch.from_numpy(np.ascontiguousarray(pose[k:k + 1])).cuda() for k in range(4)]
         streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(2)]
         d_ang = [torch.zeros((1, 6, T, 7), dtype=torch.float64, device="cuda") for _ in range(3)]
-        pipe = sharding.GatherPipeline(dist, 1, 0, d_ang[0], n_buffers=3)
+        if kind == "peer writes":   # no peer to write, but the flag all-reduces and their chaining run on RCCL
+            pipe = peer_gather.PeerWriteGather(dist, 1, 0, d_ang[0], n_buffers=3)
+            assert pipe.ok and pipe.probe()[0]
+        else:
+            pipe = sharding.GatherPipeline(dist, 1, 0, d_ang[0], n_buffers=3)
         got = {}
         for i in range(8):
             b, k = i % 3, i % 4
@@ -207,5 +213,58 @@ def test_gather_pipeline_on_rccl_single_rank(hiplib):
             got[i] = pipe.recv[i % 3][0].cpu().numpy().copy()
         for i in range(8):
             assert np.array_equal(got[i], want[i % 4:i % 4 + 1]), i
+        if kind == "peer writes":
+            pipe.close()
     finally:
         dist.destroy_process_group()
+
+
+def _peer_gather_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from seqikpy_amd import peer_gather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)   # every rank on the one GPU of the box: the mapping / copy path is the same
+    n_buf = 3
+    bufs = [torch.zeros(5, 7, 11, dtype=torch.float64, device="cuda") for _ in range(n_buf)]
+    pipe, how = peer_gather.make_gather(dist, world, rank, bufs[0], n_buffers=n_buf, prefer="peer")
+    assert isinstance(pipe, peer_gather.PeerWriteGather), how
+    seen = []
+    side = torch.cuda.Stream()
+    for step in range(7):
+        b = step % n_buf
+        with torch.cuda.stream(side):          # "solve" of this step on a side stream, as the bench does
+            pipe.wait_buffer(b)
+            bufs[b].fill_(100.0 * step + rank)
+            pipe.submit(b, bufs[b])
+            if rank == 0 and step >= 1:
+                pb = (step - 1) % n_buf
+                pipe.wait_buffer(pb)
+                seen.append([float(t.min().item()) for t in pipe.recv[pb]] + [float(t.max().item()) for t in pipe.recv[pb]])
+    pipe.drain()
+    if rank == 0:
+        last = pipe.recv[6 % n_buf]
+        seen.append([float(t.min().item()) for t in last] + [float(t.max().item()) for t in last])
+        np.save(os.path.join(out_dir, "seen.npy"), np.array(seen))
+    pipe.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_peer_write_gather_between_processes(tmp_path):
+    """Three processes on the box's GPU: rank 0 exports its receive buffers, ranks 1-2 map them and push their
+    block per step with seqik_peer_copy; the 8-byte all-reduce (gloo here, RCCL on a node) is the completion flag.
+    What rank 0 sees for step s is every rank's block of step s, whole (min == max == 100 s + rank)."""
+    world = 3
+    port = 31900 + (os.getpid() % 2000)
+    mp.spawn(_peer_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    seen = np.load(tmp_path / "seen.npy")
+    want = np.array([[100.0 * s + r for r in range(world)] * 2 for s in range(7)])
+    assert np.array_equal(seen, want)
