@@ -1,8 +1,8 @@
 """Branch statistics of the trust-region step on the benchmark data (oracle counters; CPU only).
-    python scripts/branch_stats.py [iid|smooth]"""
+    python tests/tools/branch_stats.py [iid|smooth]"""
 import sys, ctypes, numpy as np
 import os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'sequential-inverse-kinematics_amd'))
 from oracle import c_oracle
 from seqikpy_amd import data, synthetic, utils

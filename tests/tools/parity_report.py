@@ -8,13 +8,13 @@
 Prints one JSON document: per recording / leg / joint  max |d theta|, the number of frames above the 1e-4 rad bar
 and where they are (the documented degenerate LF episode, frames 280-301 of the anipose recording).
 
-    python scripts/parity_report.py > profiles/rNN_parity_report.json          (needs a GPU)
+    python tests/tools/parity_report.py > profiles/rNN_parity_report.json          (needs a GPU)
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
 

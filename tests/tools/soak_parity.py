@@ -2,7 +2,7 @@
 """Soak test: many made-up legs (random segment lengths, joint limits, seeds on bounds) with unreachable /
 degenerate / repeated targets, HIP path vs the C oracle, bit for bit.  Prints one JSON line.
 
-    python scripts/soak_parity.py --cases 20000 --frames 48          (needs a GPU)
+    python tests/tools/soak_parity.py --cases 20000 --frames 48          (needs a GPU)
 """
 import argparse
 import json
@@ -11,7 +11,7 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "sequential-inverse-kinematics_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 
