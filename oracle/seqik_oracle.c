@@ -83,16 +83,25 @@
 #define NULL_ACTIVE_ONLY 0 /* zero columns removed: scipy's own full-rank logic on the active set */
 #define NULL_EXACT_ZERO 1  /* zero columns kept as exactly-zero singular values (m < n: never full rank) */
 /* Branch statistics of the trust-region step (what share of the solves takes which path: used to reason about
- * divergence in the lane-per-chain kernels).  Off by default; not thread-safe.
+ * divergence in the lane-per-chain kernels).  Compiled in only with -DORACLE_STATS (make stats ->
+ * _build/libseqik_oracle_stats.so, used by tests/tools/branch_stats.py); not thread-safe.
  * [kind][0] calls, [1] Gauss-Newton step inside the region, [2] shortcut, [3] root loop entered, [4] sum of its
  * iterations, [5] select_step calls, [6] of which reflective, [8 + k] loops that ran k iterations;
  * kind 0 = stage 1 (rank deficient), 1 = stages 2-3. */
+#ifdef ORACLE_STATS
 static int g_stats_on = 0;
 static long long g_stats[2][24];
 void oracle_stats_reset(int on) { g_stats_on = on; memset(g_stats, 0, sizeof g_stats); }
 void oracle_stats_get(long long *out) { memcpy(out, g_stats, sizeof g_stats); }
 static int g_stats_kind = 0;
 #define STAT(i) do { if (g_stats_on) g_stats[g_stats_kind][i] += 1; } while (0)
+#define STAT_KIND(k) do { if (g_stats_on) g_stats_kind = (k); } while (0)
+#define STAT_LOOP(n) do { if (g_stats_on) { g_stats[g_stats_kind][4] += (n); g_stats[g_stats_kind][8 + (n)] += 1; } } while (0)
+#else
+#define STAT(i) do { } while (0)
+#define STAT_KIND(k) do { } while (0)
+#define STAT_LOOP(n) do { (void)(n); } while (0)
+#endif
 static int g_tr2_shortcut = 1;        /* 0 = scipy's ten-iteration root search verbatim (test hook) */
 static int g_closed_form_2x2 = 1;     /* 2 unknowns: closed-form trust-region step (solve_tr_2x2); 0 = one-sided Jacobi SVD (test hook) */
 #define NULL_WOODBURY 2    /* active columns, m < n: the trust-region step from 3x3 solves instead of an SVD */
@@ -688,7 +697,7 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
     r[0] = FMA(Jh[2][0], f[2], FMA(Jh[1][0], f[1], Jh[0][0] * f[0]));
     r[1] = FMA(Jh[2][1], f[2], FMA(Jh[1][1], f[1], Jh[0][1] * f[0]));
     int full_rank = 0;
-    g_stats_kind = force_deficient ? 0 : 1;
+    STAT_KIND(force_deficient ? 0 : 1);
     STAT(0);
     if (!force_deficient) {
         double h = 0.5 * (a - c);
@@ -748,7 +757,7 @@ static void solve_tr_2x2(double Jh[NRES][MAXN], const double *diag_h, const doub
             alpha -= (phi + Delta) * ratio * inv_Delta;
             if (fabs(phi) < 0.01 * Delta) break;
         }
-        if (g_stats_on) { g_stats[g_stats_kind][4] += n_it; g_stats[g_stats_kind][8 + n_it] += 1; }
+        STAT_LOOP(n_it);
     }
 final_step:
     tr2_apply(a, b, c, alpha, r, pp, NULL);

@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'sequential-inverse-kinematics_amd'))
 from oracle import c_oracle
 from seqikpy_amd import data, synthetic, utils
-c_oracle.build(force=True)
+import subprocess
+subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "stats"])
+c_oracle._SO = os.path.join(ROOT, "oracle", "_build", "libseqik_oracle_stats.so")   # the build with counters
 L = c_oracle.lib()
 legs = data.LEGS
 body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
