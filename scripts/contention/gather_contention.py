@@ -30,7 +30,12 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=4)
     args = ap.parse_args()
-    fr = ctypes.CDLL(os.path.join(HERE, "libfakerecv.so"))
+    so = os.path.join(HERE, "libfakerecv.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(HERE, "fake_recv.hip")):
+        import subprocess
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", so,
+                               os.path.join(HERE, "fake_recv.hip")])
+    fr = ctypes.CDLL(so)
     fr.fake_recv.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
     fr.masked_stream_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), ctypes.c_int32, ctypes.c_int32]
 
