@@ -398,3 +398,36 @@ def test_launches_in_flight_on_several_streams_equal_serial(lib, want_fk):
     lib.release_workspaces()
     again = lib.solve_seq(poses[0], params, want_fk=want_fk)  # workspaces come back on demand
     assert np.array_equal(again["angles"], alone[0]["angles"])
+
+
+@pytest.mark.gpu
+def test_eight_legs_and_single_frame_sequences(lib, oracle):
+    """The ABI's leg-count limit (8 legs per call: six real ones + two repeated with other limits / seeds) and the
+    shortest possible sequences (one frame each, 700 of them: every solve starts from the seeds); nine legs are
+    refused before any launch."""
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    names = legs + ["RF", "LH"]
+    rng = np.random.default_rng(11)
+    params, arrays = [], []
+    for i, l in enumerate(names):
+        seg, b, seeds = z[f"{l}_seg"].copy(), z[f"{l}_bounds"].copy(), z[f"{l}_seeds"].copy()
+        if i >= 6:   # a different morphology / different limits for the repeated legs
+            seg *= 1.0 + 0.1 * rng.random(4)
+            b[:, 0] -= 0.05
+            b[:, 1] += 0.05
+        params.append(lib.leg_params_from_arrays(seg, b, seeds))
+        arrays.append((seg, b, seeds))
+    pose = np.stack([z[f"{l}_pose"][:700] for l in names])            # (8, 700, 5, 3)
+    seqs = np.ascontiguousarray(pose.transpose(1, 0, 2, 3)[:, :, None])   # (700, 8, 1, 5, 3): one frame per sequence
+    got = lib.solve_seq(seqs, params, want_fk=True)
+    for li in (0, 3, 6, 7):
+        seg, b, seeds = arrays[li]
+        for s in (0, 1, 350, 699):
+            ref = oracle.seq_leg(seqs[s, li], seg, b, seeds)
+            assert np.array_equal(got["angles"][s, li], ref["angles"]) and np.array_equal(got["fk"][s, li], ref["fk"])
+    whole = lib.solve_seq(pose[None, :, :40], params, want_fk=False)      # the same 8 legs as ordinary recordings
+    ref = oracle.seq_leg(pose[7, :40], *arrays[7])
+    assert np.array_equal(whole["angles"][0, 7], ref["angles"])
+    with pytest.raises(ValueError, match="n_legs"):
+        lib.solve_seq(np.concatenate([pose, pose[:1]])[None, :, :4], params + params[:1])

@@ -160,3 +160,16 @@ def test_host_objects_are_picklable_like_the_reference_parallel_example_needs():
     gen = pickle.loads(pickle.dumps(LegInvKinGeneric({"RF_leg": z["RF_pose"]}, KinematicChainGeneric(BOUNDS, ["RF"]),
                                                      INITIAL_ANGLES, log_level="ERROR")))
     assert gen.kinematic_chain_class.create_leg_chain("RF").links[-1].name == "RF_Claw"
+
+
+def test_package_import_asks_for_eight_hardware_queues():
+    """Streams of one process only overlap on separate hardware queues (HIP default: 4); the package asks for 8
+    before the runtime starts unless the user has set the variable (Multi-GPU (i))."""
+    import subprocess
+    import sys
+    from conftest import PKG_PARENT
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import seqikpy_amd; "
+            "print(os.environ['GPU_MAX_HW_QUEUES']); os.environ['GPU_MAX_HW_QUEUES'] = '2'; "
+            "import importlib; importlib.reload(seqikpy_amd); print(os.environ['GPU_MAX_HW_QUEUES'])") % PKG_PARENT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["8", "2"]
