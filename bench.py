@@ -196,9 +196,11 @@ def main():
     n_buf = max(2, n_buf)
     d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(n_buf)]
     d_fks = [d_fk] + [torch.zeros_like(d_fk) for _ in range(len(streams) - 1)]
-    # final joint-angle gather: peer writes over xGMI when every rank can map rank 0's buffers and each link
-    # carries a block well within a step (336 MB / 14.5 ms = 23 GB/s), grouped RCCL point-to-point otherwise
-    gather, gather_how = (peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=25.0)
+    # final joint-angle gather: peer writes over xGMI when every rank can map rank 0's buffers and the copies are
+    # not pathologically slow (a block needs 336 MB / 14 ms = 24 GB/s per link to keep up; a link that cannot do
+    # that is no faster under RCCL, and the peer writes at least leave the root's compute units alone), grouped
+    # RCCL point-to-point otherwise; the measured link rate is reported in config.gather
+    gather, gather_how = (peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=8.0)
                           if use_dist else (None, None))
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
