@@ -388,9 +388,11 @@ int workspace_for(hipStream_t stream, size_t bytes, double **out)
             size_t lru = 0;
             for (size_t i = 1; i < g_ws.size(); ++i)
                 if (g_ws[i].last_use < g_ws[lru].last_use) lru = i;
-            if (g_ws[lru].device == dev) {  // (a buffer of another device is left to seqik_release_workspaces)
+            if (g_ws[lru].d) {
+                HIP_TRY(hipSetDevice(g_ws[lru].device));
                 HIP_TRY(hipDeviceSynchronize());
-                if (g_ws[lru].d) HIP_TRY(hipFree(g_ws[lru].d));
+                HIP_TRY(hipFree(g_ws[lru].d));
+                HIP_TRY(hipSetDevice(dev));
             }
             g_ws.erase(g_ws.begin() + lru);
         }

@@ -431,3 +431,25 @@ def test_eight_legs_and_single_frame_sequences(lib, oracle):
     assert np.array_equal(whole["angles"][0, 7], ref["angles"])
     with pytest.raises(ValueError, match="n_legs"):
         lib.solve_seq(np.concatenate([pose, pose[:1]])[None, :, :4], params + params[:1])
+
+
+@pytest.mark.gpu
+def test_more_streams_than_remembered_workspaces(lib):
+    """The library remembers a hand-off workspace for 16 streams; launches on 20 streams (two rounds, so that evicted
+    streams come back) still return the bits of a launch made alone."""
+    import torch
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    pose = np.stack([z[f"{l}_pose"][:30] for l in legs])[None]
+    alone = lib.solve_seq(pose, params, want_fk=False)["angles"]
+    d_pose = torch.from_numpy(np.ascontiguousarray(pose)).cuda()
+    streams = [torch.cuda.Stream() for _ in range(20)]
+    outs = [torch.zeros((1, 6, 30, 7), dtype=torch.float64, device="cuda") for _ in range(40)]
+    torch.cuda.synchronize()
+    for i in range(40):
+        lib.solve_seq_device(d_pose.data_ptr(), 1, 6, 30, params, outs[i].data_ptr(), 0,
+                             stream=streams[i % 20].cuda_stream)
+    torch.cuda.synchronize()
+    assert all(np.array_equal(o.cpu().numpy(), alone) for o in outs)
+    lib.release_workspaces()
