@@ -10,7 +10,9 @@ Metric (BASELINE.json): leg-IK solves/s, one solve = one (frame, leg) = 4 stage 
 warm-started from frame t-1, frame 0 from the seeds -- the reference's semantics applied to many
 recordings), 6 legs each = 93,750 chains.  A step is one pass of the hot path (one launch in which every
 wave takes its chains through stages 1-4; `--staged`: the 4 stage kernels) over that batch with inputs resident in HBM; for N > 1 every step also sends the rank's joint angles to rank 0
-(RCCL gather, overlapped with the next step's kernels).
+(copy-engine peer writes over xGMI into rank 0's IPC-exported buffers, an 8-byte RCCL all-reduce as completion flag;
+grouped RCCL point-to-point if the peer path is unavailable; overlapped with the next steps' kernels; `config.gather`
+says which ran).
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, live HIP-event timing) and, at
 N = 1, `cpu_baseline` (the C oracle on the host cores, bounded sample of the same workload).

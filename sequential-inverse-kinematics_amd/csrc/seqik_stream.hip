@@ -6,7 +6,7 @@
 // with AlignPose.align_leg applied beforehand (seqikpy/alignment.py:436-487; here fused into the
 // kernel prologue through SeqikAffine).
 //
-// Pipeline: HIP streams for H2D copy, compute (two, used alternately, so that the tail of one slab's
+// Pipeline: HIP streams for H2D copy, compute (one per slot, up to three, so that the tail of one slab's
 // kernels overlaps the head of the next -- one when slabs are carried) and D2H copy, and n_slots
 // device slots, chained by events only -- the host thread blocks solely when it wants to reuse a slot whose results
 // have not reached the host yet:
