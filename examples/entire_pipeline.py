@@ -4,7 +4,7 @@ Counterpart of the reference's examples/example_entire_pipeline.py (which notes 
 for the shipped 6000-frame recording).  Input: a pickled anipose pose (pose3d.h5) or an already
 converted segment dictionary (converted_dict.pkl) under --path.
 
-    python examples/entire_pipeline.py -p <dir with pose3d.* or converted_dict.pkl> [--frame-parallel]
+    python examples/entire_pipeline.py -p <dir with pose3d.* or converted_dict.pkl> [--serial]
 """
 import argparse
 import os
@@ -26,7 +26,9 @@ from seqikpy_amd.utils import save_file  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-p", "--path", required=True)
-    ap.add_argument("--frame-parallel", action="store_true", help="verified chunked mode (low latency)")
+    ap.add_argument("--serial", action="store_true",
+                    help="walk every recording serially (bit-exact restatement of the reference) instead of the "
+                         "default verified frame chunks")
     args = ap.parse_args()
     data_path = Path(args.path)
     t0 = time.time()
@@ -43,7 +45,7 @@ def main():
     seq_ik = LegInvKinSeq(aligned_pos=aligned_pos,
                           kinematic_chain_class=KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None),
                           initial_angles=INITIAL_ANGLES, log_level="INFO")
-    leg_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=data_path, frame_parallel=args.frame_parallel)
+    leg_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=data_path, frame_parallel=False if args.serial else "auto")
     save_file(data_path / "body_joint_angles.pkl", {**head_angles, **leg_angles})
     print(f"Total time taken to execute the code: {time.time() - t0:.2f} s")
 

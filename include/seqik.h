@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 1
+#define SEQIK_ABI_VERSION 2
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -71,7 +71,8 @@ typedef struct SeqikLegParams {
 } SeqikLegParams;
 
 typedef struct SeqikOptions {
-    int32_t device;       /* HIP device ordinal (host-buffer entry point only) */
+    int32_t device;       /* HIP device ordinal (host-buffer entry points only); -1 = the calling thread's
+                             current device */
     int32_t block_size;   /* threads per workgroup, multiple of 64; 0 = default (64) */
     void **stage_events;  /* nullable: 5 hipEvent_t handles, recorded on the launch stream in front of the
                              stage-1..4 kernels ([0]..[3], only for stages that run) and behind the last one
@@ -83,6 +84,34 @@ typedef struct SeqikOptions {
                              kernel and [1]..[4] behind it), 1 = always one launch per stage;
                              [2]: 0 = all lanes of a wavefront carry the same leg, 1 = consecutive chains (legs
                              interleaved);  [3]: must be 0.  None of these changes a result bit. */
+    /* ---- frame chunks (ABI 2): ONE long recording on the whole GPU -------------------------------------------
+     * The reference walks a recording serially because frame t is warm-started from frame t-1
+     * (seqikpy/leg_inverse_kinematics.py:259-282).  With frame_chunk != 0 a run of all four stages (no status /
+     * nfev requested) cuts every chain into chunks of frame_chunk frames that are solved concurrently, entirely
+     * on the device:
+     *   1. speculative launch: chunk 0 starts from the seeds (or init_angles) as the reference does, chunk k >= 1
+     *      from the seeds frame_halo frames early (a run-in whose results are dropped);
+     *   2. verification: the state the run-in reached (7 joint angles) is compared with the true last frame of
+     *      chunk k-1; a chunk is consistent when they agree to chunk_tol rad in every joint;
+     *   3. repair: inconsistent chunks whose predecessor is consistent are re-solved from the true state (bit
+     *      identical to what the serial walk does from there), the successors are verified again -- chunk_rounds
+     *      such rounds in parallel, then one serial sweep per chain that leaves every chunk consistent.
+     * Every stored frame was therefore computed by the reference's algorithm from a warm start within chunk_tol of
+     * the serial trajectory's; the result equals the serial one to about chunk_tol where the solver is well-posed
+     * (measured: <= 1.1e-5 rad on the shipped recordings with the defaults, the reference's own run-to-run noise
+     * being ~5e-5); inside kinematic-singularity episodes, where the reference itself is chaotic, a
+     * 1e-6 difference can pick the other branch.  frame_chunk = 0 keeps the serial walk (bit-exact). */
+    int32_t frame_chunk;  /* 0 = serial (default); > 0 = frames per chunk; -1 = automatic (serial for short
+                             recordings, otherwise 8..64 frames so that the chunks fill the GPU) */
+    int32_t frame_halo;   /* run-in frames of a speculative chunk; 0 = default (8) */
+    double chunk_tol;     /* consistency tolerance in rad; 0 = default (1e-6); negative = 0 (a chunk is accepted
+                             only if the run-in reproduced the true state bit for bit) */
+    int32_t chunk_rounds; /* parallel repair rounds before the serial sweep; 0 = default (3) */
+    int32_t pad_;
+    int32_t *chunk_stats; /* nullable int32[8], HOST memory for the host-buffer entry points, DEVICE memory for the
+                             _device ones: [0] chunks, [1] frames per chunk, [2] run-in frames, [3..5] chunks
+                             re-solved in repair rounds 1..3 (later rounds are added to [5]), [6] chunks re-solved
+                             by the serial sweep, [7] chunks found inconsistent by the first verification */
 } SeqikOptions;
 
 /* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.

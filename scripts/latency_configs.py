@@ -1,34 +1,73 @@
-"""Wall-clock of the reference-shaped calls (configs 1, 2, 4): one recording, few chains."""
-import os, sys, time
+"""Wall-clock of the reference-shaped calls (BASELINE configs 1, 2, 4: one recording, few chains) through the
+host-buffer entry point (transfers included): serial walk vs frame chunks (SeqikOptions.frame_chunk), each with
+max |d theta| vs the serial walk and vs the fixture's reference angles."""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
-import numpy as np, torch
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+import numpy as np
+import torch  # noqa: F401  (HIP runtime)
 from seqikpy_amd import _lib
-def run(name, z, legs, sl=slice(None), **kw):
+
+LF_WINDOW = (280, 302)  # tests/conftest.py::LF_DEGENERATE
+
+
+def case(name, z, legs, sl=slice(None)):
     params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
     pose = np.stack([z[f"{l}_pose"][sl] for l in legs])[None]
-    _lib.solve_seq(pose[:, :, :4], params)  # warm-up (library load, allocator)
-    t0 = time.perf_counter(); out = _lib.solve_seq(pose, params, want_fk=True, **kw); dt = time.perf_counter() - t0
-    n = pose.shape[1] * pose.shape[2]
-    print(f"{name}: {pose.shape[1]} legs x {pose.shape[2]} frames: {dt*1e3:.1f} ms wall  ({n/dt:.0f} leg-frames/s)")
-    return out
-za = np.load(os.path.join(ROOT, "tests/golden/anipose_shipped.npz")); zd = np.load(os.path.join(ROOT, "tests/golden/df3d_1000.npz"))
-run("config 1 (RF, 100 frames)", za, ["RF"], slice(0, 100))
-run("config 2 (df3d, 6 legs, 1000 frames)", zd, [str(l) for l in zd["legs"]])
-run("config 4 legs (anipose RF+LF, 6000 frames)", za, ["RF", "LF"])
+    ref = np.stack([z[f"{l}_angles"][sl] for l in legs])[None]
+    ok = np.ones(pose.shape[:3], bool)
+    for i, l in enumerate(legs):
+        if l == "LF" and "anipose" in name:
+            ok[0, i, LF_WINDOW[0]:LF_WINDOW[1]] = False
+    return name, pose, params, ref, ok
 
-from seqikpy_amd.frame_parallel import solve_frame_parallel
-def run_fp(name, z, legs, chunk, halo):
-    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
-    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
-    serial = _lib.solve_seq(pose, params, want_fk=True)
-    st = {}
-    t0 = time.perf_counter(); out = solve_frame_parallel(pose, params, chunk=chunk, halo=halo, stats=st); dt = time.perf_counter() - t0
-    n = pose.shape[1] * pose.shape[2]
-    err = np.abs(out["angles"] - serial["angles"])
-    print(f"{name} frame-parallel chunk={chunk} halo={halo}: {dt*1e3:.1f} ms wall ({n/dt:.0f} leg-frames/s), "
-          f"max |d| vs serial {err.max():.2e}, frames > 1e-6: {(err.max(-1) > 1e-6).sum()}, {st}")
-for chunk, halo in ((64, 16), (32, 16), (128, 16), (32, 8)):
-    run_fp("config 2", zd, [str(l) for l in zd["legs"]], chunk, halo)
-for chunk, halo in ((64, 16), (32, 16), (128, 16)):
-    run_fp("config 4 legs", za, ["RF", "LF"], chunk, halo)
+
+def timed(pose, params, reps=5, **kw):
+    _lib.solve_seq(pose, params, want_fk=True, **kw)  # warm-up: arena, workspace, leg table
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = _lib.solve_seq(pose, params, want_fk=True, **kw)
+        best = min(best, time.perf_counter() - t0)
+    return out, best
+
+
+def main():
+    za = np.load(os.path.join(ROOT, "tests/golden/anipose_shipped.npz"))
+    zd = np.load(os.path.join(ROOT, "tests/golden/df3d_1000.npz"))
+    cases = [case("config 1 (anipose RF, 100 frames)", za, ["RF"], slice(0, 100)),
+             case("config 2 (df3d, 6 legs x 1000 frames)", zd, [str(l) for l in zd["legs"]]),
+             case("config 4 legs (anipose RF + LF, 6000 frames)", za, ["RF", "LF"])]
+    variants = [dict(), dict(frame_chunk=-1)]
+    for c, h in ((4, 4), (4, 8), (8, 4), (8, 8), (16, 8), (32, 8), (32, 16)):
+        for w in (0, 1):
+            variants.append(dict(frame_chunk=c, frame_halo=h, lanes_per_wave=w))
+    rows = []
+    for name, pose, params, ref, ok in cases:
+        serial = None
+        for kw in variants:
+            out, dt = timed(pose, params, **kw)
+            if serial is None:
+                serial = out
+            d_ser = np.abs(out["angles"] - serial["angles"])
+            d_ref = np.abs(out["angles"] - ref)
+            row = dict(case=name, options=kw or "serial", ms=round(dt * 1e3, 3),
+                       leg_frames_per_s=round(pose.shape[1] * pose.shape[2] / dt),
+                       max_abs_vs_serial_outside_LF_window=float(d_ser[ok].max()),
+                       max_abs_vs_serial=float(d_ser.max()),
+                       leg_frames_over_1e4_vs_serial=int((d_ser.max(-1) > 1e-4).sum()),
+                       max_abs_vs_reference_outside_LF_window=float(d_ref[ok].max()),
+                       leg_frames_over_1e4_vs_reference=int((d_ref.max(-1) > 1e-4).sum()),
+                       chunk_stats={k: v for k, v in out["chunk_stats"].items() if v})
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    main()

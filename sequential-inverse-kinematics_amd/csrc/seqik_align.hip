@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/seqik.h"
+#include "seqik_device_scope.hpp"
 
 extern "C" void seqik_set_error(int code, const char *msg);
 
@@ -105,10 +106,11 @@ int seqik_align_stats_open(SeqikAlignStats **out, int32_t n_legs, int64_t capaci
         return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_open: bad sizes (n_legs 1..8, capacity_frames > 0)");
     SeqikAlignStats *s = new (std::nothrow) SeqikAlignStats;
     if (!s) return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_open: out of host memory");
-    s->device = opt ? opt->device : 0;
     s->n_legs = n_legs;
     s->capacity = capacity_frames;
-    hipError_t e = hipSetDevice(s->device);
+    seqik::DeviceScope scope;
+    hipError_t e = seqik::resolve_device(opt ? opt->device : -1, &s->device);
+    if (e == hipSuccess) e = scope.enter(s->device);
     if (e == hipSuccess)
         e = hipMalloc(reinterpret_cast<void **>(&s->d_series), sizeof(double) * kSeries * n_legs * capacity_frames);
     if (e != hipSuccess) {
@@ -127,7 +129,8 @@ int seqik_align_stats_add(SeqikAlignStats *s, const double *pose, int32_t pose_o
     const int64_t add = n_seq * n_frames;
     if (add == 0) return SEQIK_OK;
     if (s->count + add > s->capacity) return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_add: more frames than the capacity");
-    ATRY(hipSetDevice(s->device));
+    seqik::DeviceScope scope;
+    ATRY(scope.enter(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     int64_t pc = n_frames * 15, pr = 3, pf = 15;
     if (layout) {
@@ -163,7 +166,8 @@ int seqik_align_stats_finish(SeqikAlignStats *s, const int64_t *ranks, int32_t n
     if (n_ranks <= 0 || n_ranks > 16) return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_finish: n_ranks must be 1..16");
     if (s->count == 0) return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_finish: no frames were added");
     if (s->count > 0x7fffffffLL) return a_fail(SEQIK_ERR_BAD_ARG, "seqik_align_stats_finish: more than 2^31 frames per leg");
-    ATRY(hipSetDevice(s->device));
+    seqik::DeviceScope scope;
+    ATRY(scope.enter(s->device));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int n_series = kSeries * s->n_legs;
     double *d_sorted = nullptr, *d_out = nullptr;
@@ -208,7 +212,8 @@ int seqik_align_stats_reset(SeqikAlignStats *s)
 int seqik_align_stats_close(SeqikAlignStats *s)
 {
     if (!s) return SEQIK_OK;
-    (void)hipSetDevice(s->device);
+    seqik::DeviceScope scope;
+    (void)scope.enter(s->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(s->d_series);
     (void)hipFree(s->d_stage);

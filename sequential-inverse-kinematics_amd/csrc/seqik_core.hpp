@@ -836,7 +836,14 @@ struct ChainIO {
                             // precedes this chain's first frame) instead of the stage seeds
     double *frames;         // workspace [n_frames][12]: the frame after the active links at the solution of
                             // stage k (rotation 9 + translation 3) = prefix frame of stage k + 1
-    int64_t n_frames;
+    int64_t n_frames;       // frames [0, n_frames) are solved (CHUNKED: [t_begin, n_frames))
+    // --- CHUNKED instantiations only (a piece of a recording, seqik_hip.hip "frame chunks") -----------------
+    int64_t t_begin;        // first frame solved; the workspace is indexed by t - t_begin
+    int64_t t_store;        // first frame whose angles / FK / diagnostics are stored: [t_begin, t_store) is a
+                            // run-in ("halo") that only brings the warm start close to the serial trajectory
+    int64_t init_stride;    // init is read as init[dof * init_stride] (lets it point into an angle array)
+    double *start_state;    // nullable [7]: receives the angles of frame t_store - 1 (the state the run-in reached
+                            // = the warm start the stored frames were computed from) when t_store > t_begin
 };
 
 // Prefix frame of STAGE from the angles of the earlier stages: the "fixed" links of
@@ -884,10 +891,13 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //   WANT_DIAG : also produce scipy's status / nfev (one extra Jacobian per solve: scipy
 //               re-evaluates it after the last accepted step and may overwrite the status
 //               with 1 = gtol).
-template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF>
+//   CHUNKED   : the lane solves frames [io.t_begin, io.n_frames) of its chain and stores only those from
+//               io.t_store on (ChainIO); false = the whole chain from frame 0, everything stored.
+template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
     static_assert(STAGE > 1 || !FROM_ANGLES, "stage 1 has no prefix");
+    static_assert(!(CHUNKED && FROM_ANGLES), "frame chunks start at stage 1 (the run-in has no stored angles)");
     static_assert(STAGE < 4 || !HANDOFF, "stage 4 is the last one");
     using T = StageTraits<STAGE>;
     constexpr int NA = T::NA;
@@ -906,15 +916,17 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // x carries the solution from frame to frame: it is the warm start of the next solve
     double x[2] = {sc.seed[0], (NA == 2) ? sc.seed[1] : 0.0}, f[3] = {0.0, 0.0, 0.0};
     if (io.init) {
-        x[0] = io.init[DOF0];
-        if constexpr (NA == 2) x[1] = io.init[DOF0 + 1];
+        const int64_t is = CHUNKED ? io.init_stride : 1;
+        x[0] = io.init[DOF0 * is];
+        if constexpr (NA == 2) x[1] = io.init[(DOF0 + 1) * is];
     }
     double cost = 0.0, Delta = 0.0, alpha = 0.0;
     double sa = 0.0, ca = 1.0, sb = 0.0, cb = 1.0;  // sin/cos of the active joints at x
     int nfev = 0, status = STATUS_NONE;
     bool first_pass = true, new_solve = true;
     double coxa_end[3] = {0.0, 0.0, 0.0};  // stage 4 + FK only
-    int64_t t = 0;
+    const int64_t t_first = CHUNKED ? io.t_begin : 0;
+    int64_t t = t_first;
     double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
     bool have_pe = false;
 
@@ -926,7 +938,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if constexpr (FROM_ANGLES) {
                     build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, WANT_FK ? coxa_end : nullptr);
                 } else {
-                    const double *w = io.frames + t * 12;
+                    const double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) P.pre.r[i] = w[i];
 #pragma unroll
@@ -1088,24 +1100,30 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 
         if (finished) {
             // ---- solve done: store, advance to the next frame -------------------------------
-            double *ang = io.angles + t * io.ang_frame;
-            ang[DOF0 * io.ang_dof] = x[0];
-            if constexpr (NA == 2) ang[(DOF0 + 1) * io.ang_dof] = x[1];
-            if constexpr (WANT_DIAG) {
-                if (io.status) io.status[t * 4 + STAGE - 1] = (status == STATUS_NONE) ? 0 : status;
-                if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
+            const bool stored = !CHUNKED || t >= io.t_store;  // run-in frames leave nothing but the hand-off
+            if (stored) {
+                double *ang = io.angles + t * io.ang_frame;
+                ang[DOF0 * io.ang_dof] = x[0];
+                if constexpr (NA == 2) ang[(DOF0 + 1) * io.ang_dof] = x[1];
+                if constexpr (WANT_DIAG) {
+                    if (io.status) io.status[t * 4 + STAGE - 1] = (status == STATUS_NONE) ? 0 : status;
+                    if (io.nfev) io.nfev[t * 4 + STAGE - 1] = nfev;
+                }
+            } else if (CHUNKED && t == io.t_store - 1 && io.start_state) {
+                io.start_state[DOF0] = x[0];
+                if constexpr (NA == 2) io.start_state[DOF0 + 1] = x[1];
             }
             if constexpr ((WANT_FK && STAGE >= 2) || HANDOFF) {
                 Frame after;  // frame after the active links at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
                 if constexpr (HANDOFF) {
-                    double *w = io.frames + t * 12;
+                    double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) w[i] = after.r[i];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) w[9 + i] = after.t[i];
                 }
-                if constexpr (WANT_FK && STAGE >= 2) {
+                if (WANT_FK && STAGE >= 2 && stored) {
                     const double *origin = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
                     double *fk = io.fk + t * 27;
                     if constexpr (STAGE == 2) {

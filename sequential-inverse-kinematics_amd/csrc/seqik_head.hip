@@ -3,6 +3,7 @@
 #include <stdio.h>
 
 #include "seqik_head.hpp"
+#include "seqik_device_scope.hpp"
 #include "../../include/seqik.h"
 
 extern "C" void seqik_set_error(int code, const char *msg);
@@ -59,7 +60,8 @@ int seqik_head_angles(const double *r_head, const double *l_head, int64_t n_fram
         return SEQIK_ERR_BAD_ARG;
     }
     if (n_frames == 0) return SEQIK_OK;
-    if (opt) HTRY(hipSetDevice(opt->device));
+    seqik::DeviceScope scope;
+    HTRY(scope.enter(opt ? opt->device : -1));
     const int n_out = compute_ant ? 7 : 3;
     const size_t in_bytes = sizeof(double) * 6 * n_frames;
     const size_t neck_bytes = sizeof(double) * (neck_stride ? 3 * n_frames : 3);

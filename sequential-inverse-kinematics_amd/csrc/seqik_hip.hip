@@ -9,6 +9,7 @@
 
 #include "seqik_core.hpp"
 #include "seqik_consts.hpp"
+#include "seqik_device_scope.hpp"
 
 namespace {
 
@@ -133,6 +134,30 @@ int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt)
     return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);  // <= 256 thin waves of 1-4 lanes
 }
 
+// Frame chunks of a call (SeqikOptions.frame_chunk / frame_halo): false = serial walk.
+// Automatic choice: recordings shorter than 48 frames stay serial; otherwise the chunk length is the one that cuts
+// the call into ~196 608 pieces (three full waves on each of the 1024 SIMDs), rounded up to a multiple of 8 and kept
+// within 8..64 frames: the run-in (8 frames by default) is extra work, so chunks are not made shorter than it, and a
+// chunk longer than 64 frames gains nothing (BENCH sequence-length sweep).
+bool pick_frame_chunks(const SeqikOptions *opt, int64_t n_chains, int64_t n_frames, int32_t &chunk, int32_t &halo,
+                       int64_t &n_chunks)
+{
+    if (!opt || opt->frame_chunk == 0) return false;
+    halo = opt->frame_halo > 0 ? opt->frame_halo : 8;
+    int64_t c = opt->frame_chunk;
+    if (c < 0) {
+        if (n_frames < 48) return false;
+        c = ((n_chains * n_frames / 196608 + 7) / 8) * 8;
+        c = c < 8 ? 8 : (c > 64 ? 64 : c);
+    }
+    if (c >= n_frames) return false;
+    if (c > (1 << 20)) c = 1 << 20;
+    if (halo > (1 << 20)) halo = 1 << 20;
+    chunk = (int32_t)c;
+    n_chunks = (n_frames + c - 1) / c;
+    return true;
+}
+
 // One lane per chain, one launch per stage (the reference's own loop order,
 // leg_inverse_kinematics.py:373-385).  A workgroup is one or more independent wavefronts;
 // the only shared data is the read-only per-leg constant table, staged once into LDS.
@@ -207,6 +232,206 @@ seqik_fused_kernel(KernelArgs a)
     seqik::run_stage<2, WANT_FK, false, false, true>(lc, io);
     seqik::run_stage<3, WANT_FK, false, false, true>(lc, io);
     seqik::run_stage<4, WANT_FK, false, false, false>(lc, io);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Frame chunks (SeqikOptions.frame_chunk, include/seqik.h): one long recording on the whole GPU.
+//
+// A chain of N frames is cut into K = ceil(N / C) chunks; "virtual chain" vc = (seq * K + k) * n_legs + leg is chunk k
+// of real chain c = seq * n_legs + leg.  Launch sequence on the caller's stream, no host round trip:
+//     chunk kernel  (SPEC)     every virtual chain: chunk 0 from the seeds / init at frame 0, chunk k >= 1 from the
+//                              seeds at frame k C - h; the h run-in frames leave only start_state[vc] (7 angles)
+//     R x { scan kernel        which chunks are inconsistent (|start_state - true last frame of chunk k-1| > tol in
+//                              some joint)?  those whose predecessor is consistent go on the work list
+//           chunk kernel (REPAIR)  re-solves the listed chunks from the true state (init = the stored angles of frame
+//                              k C - 1; bit-identical to the serial continuation), start_state[vc] = that state }
+//     scan kernel + chunk kernel (SWEEP)   one wave per real chain walks its chunks left to right and re-solves what is
+//                              still inconsistent: terminates after at most K steps with every chunk consistent
+// Every kernel after a scan that found nothing returns at once (ChunkCtrl), so on well-posed data the tail costs a
+// few empty launches.  Within a round no two adjacent chunks are rewritten, and a chunk is only ever read (its last
+// frame, as warm start) while nobody writes it.
+// ---------------------------------------------------------------------------------------------------------------
+struct ChunkCtrl {
+    int32_t count;    // chunks on the work list of this round
+    int32_t pending;  // chunks this round's scan found inconsistent (listed or not)
+};
+constexpr int kMaxChunkRounds = 8;
+
+struct ChunkArgs {
+    int64_t n_chunks;      // K, chunks per chain
+    int64_t n_vseq;        // n_seq * K
+    int32_t chunk, halo;   // C, h
+    double tol;
+    double *start_state;   // [n_vchains][7]: the warm start the stored frames of a chunk were computed from
+    int32_t *worklist;     // [n_vchains]
+    ChunkCtrl *ctrl;       // [kMaxChunkRounds + 1]
+    int32_t *stats;        // nullable device int32[8] (SeqikOptions.chunk_stats)
+    int32_t round;         // entry of ctrl this launch writes (scan) / reads (repair, sweep)
+    int32_t n_rounds;      // R
+};
+
+enum : int { CHUNK_SPEC = 0, CHUNK_REPAIR = 1, CHUNK_SWEEP = 2 };
+
+// does the warm start chunk k of real chain c was computed from differ from the stored last frame of chunk k - 1?
+__device__ __forceinline__ bool chunk_inconsistent(const KernelArgs &a, const ChunkArgs &ca, int64_t c, int64_t vc, int64_t k)
+{
+    const double *ss = ca.start_state + vc * 7;
+    const double *ang = a.angles + c * a.ang_chain + (k * ca.chunk - 1) * a.ang_frame;
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - ang[d * a.ang_dof]) <= ca.tol);  // NaN counts as a mismatch
+    return bad;
+}
+
+__global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, ChunkArgs ca)
+{
+    __shared__ int s_count, s_pending, s_base;
+    if (ca.round > 0 && ca.ctrl[ca.round - 1].pending == 0) return;  // the previous scan found every chunk consistent
+    if (threadIdx.x == 0) { s_count = 0; s_pending = 0; s_base = 0; }
+    __syncthreads();
+    const int64_t vc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool inc = false, ready = false;
+    if (vc < ca.n_vseq * a.n_legs) {
+        const int64_t vseq = vc / a.n_legs;
+        const int leg = (int)(vc - vseq * a.n_legs);
+        const int64_t seq = vseq / ca.n_chunks, k = vseq - seq * ca.n_chunks;
+        if (k > 0) {
+            const int64_t c = seq * a.n_legs + leg;
+            inc = chunk_inconsistent(a, ca, c, vc, k);
+            // repaired now only if the chunk in front of it is not about to change
+            if (inc) ready = !(k > 1 && chunk_inconsistent(a, ca, c, vc - a.n_legs, k - 1));
+        }
+    }
+    int mine = -1;
+    if (ready) mine = atomicAdd(&s_count, 1);
+    if (inc) atomicAdd(&s_pending, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one device atomic per workgroup
+        if (s_count) s_base = atomicAdd(&ca.ctrl[ca.round].count, s_count);
+        if (s_pending) atomicAdd(&ca.ctrl[ca.round].pending, s_pending);
+        if (ca.stats) {
+            if (ca.round == 0 && s_pending) atomicAdd(&ca.stats[7], s_pending);
+            if (ca.round < ca.n_rounds && s_count) atomicAdd(&ca.stats[3 + (ca.round < 2 ? ca.round : 2)], s_count);
+        }
+    }
+    __syncthreads();
+    if (ready) ca.worklist[s_base + mine] = (int32_t)vc;
+}
+
+// Solves chunks: the four stage bodies back to back, as seqik_fused_kernel, over the frames of one chunk per lane.
+//   CHUNK_SPEC    lane -> virtual chain by chain_of_lane() (leg-pure waves), run-in from the seeds
+//   CHUNK_REPAIR  lanes take the entries of the work list of round ca.round (grid-stride), start from the true state
+//   CHUNK_SWEEP   wave w = real chain w: verify 64 chunks at a time, the lane of the first inconsistent one re-solves
+//                 it, continue behind it (the verification then sees the new last frame)
+template <bool WANT_FK, int mode>
+__global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = (int)(g & 63);
+    const int64_t wave = g >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t K = ca.n_chunks, C = ca.chunk, N = a.n_frames;
+    const int W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
+
+    int64_t cursor = 0, n_items = 0;
+    bool spec_done = false;
+    if (mode == CHUNK_REPAIR) {
+        n_items = ca.ctrl[ca.round].count;
+        cursor = (lane < W) ? wave * W + lane : n_items;
+    } else if (mode == CHUNK_SWEEP) {
+        if (ca.ctrl[ca.round].pending == 0 || wave >= a.n_chains) return;
+        cursor = 1;  // wave-uniform: next chunk of real chain `wave` to verify
+    }
+    for (;;) {
+        int64_t vc = -1;
+        int leg = 0;
+        if (mode == CHUNK_SPEC) {
+            if (spec_done) break;
+            spec_done = true;
+            int64_t c_v;
+            if (chain_of_lane(ca.n_vseq, a.n_legs, a.lanes_per_wave, a.leg_order, c_v, leg)) vc = c_v;
+        } else if (mode == CHUNK_REPAIR) {
+            if (cursor >= n_items) break;
+            vc = ca.worklist[cursor];
+            leg = (int)(vc % a.n_legs);
+            cursor += n_waves * W;
+        } else {
+            const int64_t seq = wave / a.n_legs;
+            leg = (int)(wave - seq * a.n_legs);
+            bool found = false;
+            while (cursor < K) {
+                const int64_t kk = cursor + lane;
+                const int64_t v = (seq * K + kk) * a.n_legs + leg;
+                const bool inc = kk < K && chunk_inconsistent(a, ca, wave, v, kk);
+                const unsigned long long m = __ballot(inc);
+                if (m) {
+                    const int first = __ffsll((long long)m) - 1;
+                    if (lane == first) vc = v;
+                    cursor += first + 1;
+                    found = true;
+                    break;
+                }
+                cursor += 64;
+            }
+            if (!found) break;  // wave-uniform
+        }
+        if (vc >= 0) {
+            const int64_t vseq = vc / a.n_legs;
+            const int64_t seq = vseq / K, k = vseq - seq * K;
+            const int64_t c = seq * a.n_legs + leg;
+            seqik::ChainIO io;
+            io.pose = a.pose + c * a.pose_chain;
+            io.pose_row = a.pose_row;
+            io.pose_frame = a.pose_frame;
+            io.angles = a.angles + c * a.ang_chain;
+            io.ang_dof = a.ang_dof;
+            io.ang_frame = a.ang_frame;
+            io.fk = a.fk ? a.fk + c * N * 27 : nullptr;
+            io.status = nullptr;
+            io.nfev = nullptr;
+            io.frames = a.frames + vc * (C + ca.halo) * 12;
+            io.t_store = k * C;
+            io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
+            double *ss = ca.start_state + vc * 7;
+            if (mode == CHUNK_SPEC) {
+                io.t_begin = (k * C > ca.halo) ? k * C - ca.halo : 0;
+                io.init = (k == 0 && a.init) ? a.init + c * 7 : nullptr;
+                io.init_stride = 1;
+                io.start_state = (k > 0) ? ss : nullptr;
+            } else {
+                io.t_begin = io.t_store;
+                io.init = io.angles + (io.t_store - 1) * a.ang_frame;
+                io.init_stride = a.ang_dof;
+                io.start_state = nullptr;
+#pragma unroll
+                for (int d = 0; d < 7; ++d) ss[d] = io.init[d * a.ang_dof];
+                if (mode == CHUNK_SWEEP && ca.stats) atomicAdd(&ca.stats[6], 1);
+            }
+            const seqik::LegConst &lc = s_legs[leg];
+            seqik::run_stage<1, false, false, false, true, true>(lc, io);
+            seqik::run_stage<2, WANT_FK, false, false, true, true>(lc, io);
+            seqik::run_stage<3, WANT_FK, false, false, true, true>(lc, io);
+            seqik::run_stage<4, WANT_FK, false, false, false, true>(lc, io);
+        }
+        if (mode == CHUNK_SWEEP) __threadfence();  // the next verification reads the frames just stored
+    }
+}
+
+// zeroes the control block / statistics of a chunked call (first thing on the stream)
+__global__ void seqik_chunk_reset_kernel(ChunkArgs ca, int32_t n_chunks_total)
+{
+    const int i = threadIdx.x;
+    if (i <= kMaxChunkRounds) { ca.ctrl[i].count = 0; ca.ctrl[i].pending = 0; }
+    if (ca.stats && i < 8) ca.stats[i] = (i == 0) ? n_chunks_total : (i == 1) ? ca.chunk : (i == 2) ? ca.halo : 0;
 }
 
 // from_angles: first stage of a run that starts after stage 1; handoff: a later stage follows
@@ -289,45 +514,85 @@ seqik_generic_kernel(GenericKernelArgs a)
     seqik::run_generic<WANT_DIAG>(s_legs[leg].gc, s_legs[leg].aff, io);
 }
 
-// Device copy of the per-leg constant table.  Callers almost always pass the same legs on
-// every call, so the table is cached per host thread and device: a repeat call is a pure
-// kernel launch (no allocation, no copy).  When the contents change, the device is drained
-// first because kernels still in flight read the old table in their prologue.
-struct LegTableCache {
-    seqik::LegConst *d = nullptr;
-    int device = -1;
-    std::vector<seqik::LegConst> h;
+// Device copies of the per-leg constant tables.  Callers almost always pass the same legs on every call, so the
+// tables are cached: content-addressed and immutable (a table is never overwritten while kernels that read it may be
+// in flight, so a change of legs needs no device drain), per device, shared by all host threads.  A repeat call is
+// a pure kernel launch (no allocation, no copy).  seqik_release_workspaces() frees them.
+template <typename T>
+struct TableCache {
+    struct Entry {
+        int device;
+        T *d;
+        std::vector<T> h;
+        uint64_t last_use;
+    };
+    static constexpr size_t kMaxEntries = 64;
+    std::mutex mutex;
+    std::vector<Entry> entries;
+    uint64_t clock = 0;
+
+    int get(const std::vector<T> &h, const T **out)
+    {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mutex);
+        for (Entry &e : entries)
+            if (e.device == dev && e.h.size() == h.size() && memcmp(e.h.data(), h.data(), sizeof(T) * h.size()) == 0) {
+                e.last_use = ++clock;
+                *out = e.d;
+                return SEQIK_OK;
+            }
+        if (entries.size() >= kMaxEntries) {  // evict the least recently used one (kernels in flight may read it)
+            size_t lru = 0;
+            for (size_t i = 1; i < entries.size(); ++i)
+                if (entries[i].last_use < entries[lru].last_use) lru = i;
+            HIP_TRY(hipSetDevice(entries[lru].device));
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(entries[lru].d));
+            HIP_TRY(hipSetDevice(dev));
+            entries.erase(entries.begin() + lru);
+        }
+        Entry e;
+        e.device = dev;
+        e.d = nullptr;
+        e.h = h;
+        e.last_use = ++clock;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.d), sizeof(T) * kMaxLegs));
+        hipError_t err = hipMemcpy(e.d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(e.d);
+            return fail(SEQIK_ERR_HIP, "hipMemcpy(leg table): %s", hipGetErrorString(err));
+        }
+        entries.push_back(e);
+        *out = e.d;
+        return SEQIK_OK;
+    }
+
+    int release()
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        int prev = -1;
+        HIP_TRY(hipGetDevice(&prev));
+        for (Entry &e : entries) {
+            HIP_TRY(hipSetDevice(e.device));
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(e.d));
+        }
+        entries.clear();
+        HIP_TRY(hipSetDevice(prev));
+        return SEQIK_OK;
+    }
 };
-thread_local LegTableCache g_cache;
+TableCache<seqik::LegConst> g_leg_tables;
+TableCache<GenericLegTable> g_generic_tables;
 
 int device_leg_table(const SeqikLegParams *legs, const SeqikAffine *affine, int32_t n_legs, const seqik::LegConst **out)
 {
     std::vector<seqik::LegConst> h(n_legs);
     memset(h.data(), 0, sizeof(seqik::LegConst) * n_legs);
     for (int l = 0; l < n_legs; ++l) seqik::make_leg_consts(legs[l], affine ? affine + l : nullptr, h[l]);
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
-    LegTableCache &c = g_cache;
-    const bool same = c.d && c.device == dev && c.h.size() == h.size() &&
-                      memcmp(c.h.data(), h.data(), sizeof(seqik::LegConst) * n_legs) == 0;
-    if (!same) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c.d && c.device != dev) c.d = nullptr;  // belongs to another device: leave it (tiny)
-        if (!c.d) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d), sizeof(seqik::LegConst) * kMaxLegs));
-        HIP_TRY(hipMemcpy(c.d, h.data(), sizeof(seqik::LegConst) * n_legs, hipMemcpyHostToDevice));
-        c.device = dev;
-        c.h = h;
-    }
-    *out = c.d;
-    return SEQIK_OK;
+    return g_leg_tables.get(h, out);
 }
-
-struct GenericTableCache {
-    GenericLegTable *d = nullptr;
-    int device = -1;
-    std::vector<GenericLegTable> h;
-};
-thread_local GenericTableCache g_gen_cache;
 
 int device_generic_table(const SeqikLegParams *legs, const SeqikAffine *affine, int32_t n_legs, const GenericLegTable **out)
 {
@@ -340,21 +605,7 @@ int device_generic_table(const SeqikLegParams *legs, const SeqikAffine *affine, 
         seqik::make_leg_consts(legs[l], affine ? affine + l : nullptr, tmp);
         h[l].aff = tmp.aff;
     }
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
-    GenericTableCache &c = g_gen_cache;
-    const bool same = c.d && c.device == dev && c.h.size() == h.size() &&
-                      memcmp(c.h.data(), h.data(), sizeof(GenericLegTable) * n_legs) == 0;
-    if (!same) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c.d && c.device != dev) c.d = nullptr;
-        if (!c.d) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c.d), sizeof(GenericLegTable) * kMaxLegs));
-        HIP_TRY(hipMemcpy(c.d, h.data(), sizeof(GenericLegTable) * n_legs, hipMemcpyHostToDevice));
-        c.device = dev;
-        c.h = h;
-    }
-    *out = c.d;
-    return SEQIK_OK;
+    return g_generic_tables.get(h, out);
 }
 
 // Stage hand-off workspace (12 doubles per leg-frame), one buffer per (device, stream): launches on one stream are
@@ -416,6 +667,69 @@ int workspace_for(hipStream_t stream, size_t bytes, double **out)
     return SEQIK_OK;
 }
 
+// Context of a host-buffer call (seqik_solve_seq, seqik_solve_generic): a stream and one grow-only device arena
+// that the call's device buffers are carved from.  Contexts are pooled per device: a call takes a free one (or makes
+// one) and gives it back, so repeated calls neither create streams nor call hipMalloc / hipFree (which drains the
+// device), and -- because the stream lives on -- the hand-off workspace keyed by it (workspace_for) is reused instead
+// of stranded.  Concurrent host threads get distinct contexts; seqik_release_workspaces() frees the idle ones.
+struct HostCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    bool busy = false;
+};
+std::mutex g_ctx_mutex;
+std::vector<HostCtx *> g_ctx;
+
+int acquire_ctx(HostCtx **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    for (HostCtx *c : g_ctx)
+        if (c->device == dev && !c->busy) { c->busy = true; *out = c; return SEQIK_OK; }
+    HostCtx *c = new HostCtx;
+    c->device = dev;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(SEQIK_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->busy = true;
+    g_ctx.push_back(c);
+    *out = c;
+    return SEQIK_OK;
+}
+
+void release_ctx(HostCtx *c)
+{
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    c->busy = false;
+}
+
+int ctx_reserve(HostCtx *c, size_t bytes)
+{
+    if (c->arena_bytes >= bytes) return SEQIK_OK;
+    if (c->arena) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->arena));
+        c->arena = nullptr;
+        c->arena_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8;  // a little head room: slightly longer recordings do not reallocate
+    if (hipMalloc(reinterpret_cast<void **>(&c->arena), want) == hipSuccess) { c->arena_bytes = want; return SEQIK_OK; }
+    (void)hipGetLastError();
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->arena), bytes));
+    c->arena_bytes = bytes;
+    return SEQIK_OK;
+}
+
+// bump allocator over the arena (256-byte aligned pieces)
+struct ArenaCursor {
+    char *base;
+    size_t off = 0;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <typename T> T *take(size_t count) { T *p = reinterpret_cast<T *>(base + off); off += padded(sizeof(T) * count); return p; }
+};
+
 int check_args(int64_t n_seq, int32_t n_legs, int64_t n_frames, const SeqikLegParams *legs,
                int32_t first_stage, int32_t last_stage, const void *pose, const void *angles)
 {
@@ -454,27 +768,76 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (block % 64 != 0 || block > kMaxBlock) return fail(SEQIK_ERR_BAD_ARG, "block_size must be a multiple of 64, <= 256%s");
     a.n_seq = n_seq;
     a.leg_order = make_leg_order(legs, n_legs);
-    a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
-    int64_t n_waves = ((n_seq + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
+    const bool diag = d_status || d_nfev;
+    const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
+    if (!fk) a.fk = nullptr;
+    // frame chunks (SeqikOptions.frame_chunk): runs of all four stages without diagnostics only
+    int32_t chunk = 0, halo = 0;
+    int64_t n_chunks = 1;
+    const bool chunked = first_stage == 1 && last_stage == 4 && !diag &&
+                         pick_frame_chunks(opt, a.n_chains, n_frames, chunk, halo, n_chunks);
+    const int64_t n_vchains = a.n_chains * n_chunks;  // virtual chains = chunks (= chains when not chunked)
+    if (n_vchains > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many frame chunks for one launch%s");
+    a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt);
+    int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
     if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
-        n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;
+        n_waves = (n_vchains + a.lanes_per_wave - 1) / a.lanes_per_wave;
         a.lanes_per_wave = -a.lanes_per_wave;
     }
     int64_t grid64 = (n_waves * 64 + block - 1) / block;
     if (grid64 > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
-    const bool diag = d_status || d_nfev;
-    const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
-    if (!fk) a.fk = nullptr;
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
     static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
-    if (last_stage > first_stage) {
+    if (chunked) {
+        const size_t ws_bytes = sizeof(double) * (12 * (size_t)(chunk + halo) + 7) * n_vchains + 128 +
+                                sizeof(int32_t) * (size_t)n_vchains;
+        if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
+    } else if (last_stage > first_stage) {
         const size_t ws_bytes = sizeof(double) * 12 * a.n_chains * n_frames;
         if (pool_workspace) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), ws_bytes, stream));
         else if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     }
     const bool fused = !(opt && opt->reserved[1] == 1) && first_stage == 1 && last_stage == 4 && !diag;
+    if (chunked) {
+        ChunkArgs ca;
+        ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo;
+        ca.tol = (opt->chunk_tol > 0) ? opt->chunk_tol : (opt->chunk_tol < 0 ? 0.0 : 1e-6);
+        ca.n_rounds = (opt->chunk_rounds > 0) ? (opt->chunk_rounds < kMaxChunkRounds ? opt->chunk_rounds : kMaxChunkRounds) : 3;
+        ca.stats = opt->chunk_stats;
+        ca.round = 0;
+        // carve the workspace: hand-off frames | start states | control block | work list
+        char *base = reinterpret_cast<char *>(a.frames);
+        size_t off = sizeof(double) * 12 * (size_t)n_vchains * (chunk + halo);
+        ca.start_state = reinterpret_cast<double *>(base + off); off += sizeof(double) * 7 * (size_t)n_vchains;
+        ca.ctrl = reinterpret_cast<ChunkCtrl *>(base + off); off += 128;
+        ca.worklist = reinterpret_cast<int32_t *>(base + off);
+        if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
+        hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
+        if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
+        else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
+        HIP_TRY(hipGetLastError());
+        const dim3 scan_grid((unsigned)((n_vchains + 255) / 256)), scan_blk(256);
+        const int64_t rep_waves = n_waves < 4096 ? n_waves : 4096;  // the work list is walked grid-stride
+        const dim3 rep_grid((unsigned)((rep_waves * 64 + block - 1) / block));
+        for (int r = 0; r <= ca.n_rounds; ++r) {
+            ca.round = r;
+            hipLaunchKernelGGL(seqik_chunk_scan_kernel, scan_grid, scan_blk, 0, stream, a, ca);
+            if (r < ca.n_rounds) {
+                if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
+            } else {  // serial sweep: one wave per real chain
+                const dim3 sweep_grid((unsigned)a.n_chains), sweep_blk(64);
+                if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SWEEP>), sweep_grid, sweep_blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SWEEP>), sweep_grid, sweep_blk, 0, stream, a, ca);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        if (opt->stage_events)
+            for (int k = 1; k <= 4; ++k) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[k]), stream));
+        return SEQIK_OK;
+    }
     if (fused) {
         if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
@@ -528,7 +891,22 @@ int seqik_release_workspaces(void)
         w.d = nullptr;
     }
     g_ws.clear();
+    {
+        std::lock_guard<std::mutex> ctx_lock(g_ctx_mutex);
+        for (size_t i = 0; i < g_ctx.size();) {
+            HostCtx *c = g_ctx[i];
+            if (c->busy) { ++i; continue; }  // a call is running on another thread
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->arena) HIP_TRY(hipFree(c->arena));
+            HIP_TRY(hipStreamDestroy(c->stream));
+            delete c;
+            g_ctx.erase(g_ctx.begin() + i);
+        }
+    }
     HIP_TRY(hipSetDevice(prev));
+    if (int rc = g_leg_tables.release()) return rc;
+    if (int rc = g_generic_tables.release()) return rc;
     return SEQIK_OK;
 }
 
@@ -630,6 +1008,18 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     return SEQIK_OK;
 }
 
+// device buffers of one host-buffer call, carved from a pooled context's arena
+struct HostCall {
+    HostCtx *ctx = nullptr;
+    ~HostCall() { if (ctx) release_ctx(ctx); }
+};
+
+#define TRY_OUT(expr)                                                                            \
+    {                                                                                            \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_));  \
+    }
+
 int seqik_solve_generic(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                         const SeqikLegParams *legs, double *angles, double *fk, int32_t *status, int32_t *nfev,
                         const double *init_angles, const SeqikAffine *affine, const SeqikOptions *opt)
@@ -639,37 +1029,36 @@ int seqik_solve_generic(const double *pose, int64_t n_seq, int32_t n_legs, int64
         return fail(SEQIK_ERR_BAD_ARG, "bad sizes (n_legs must be 1..8)%s");
     int rc = seqik_validate_legs_generic(legs, n_legs);
     if (rc != SEQIK_OK) return rc;
-    const int64_t n_lf = n_seq * (int64_t)n_legs * n_frames;
+    const size_t n_lf = (size_t)n_seq * n_legs * n_frames;
     if (n_lf == 0) return SEQIK_OK;
-    if (opt) HIP_TRY(hipSetDevice(opt->device));
-    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr, *d_init = nullptr;
-    int32_t *d_status = nullptr, *d_nfev = nullptr;
-    int out = SEQIK_OK;
-    do {
-#define TB(expr) { hipError_t e_ = (expr); if (e_ != hipSuccess) { out = fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); break; } }
-        TB(hipMalloc(reinterpret_cast<void **>(&d_pose), sizeof(double) * 15 * n_lf));
-        TB(hipMalloc(reinterpret_cast<void **>(&d_angles), sizeof(double) * 7 * n_lf));
-        if (fk) TB(hipMalloc(reinterpret_cast<void **>(&d_fk), sizeof(double) * 27 * n_lf));
-        if (status) TB(hipMalloc(reinterpret_cast<void **>(&d_status), sizeof(int32_t) * n_lf));
-        if (nfev) TB(hipMalloc(reinterpret_cast<void **>(&d_nfev), sizeof(int32_t) * n_lf));
-        if (init_angles) {
-            TB(hipMalloc(reinterpret_cast<void **>(&d_init), sizeof(double) * 7 * n_seq * n_legs));
-            TB(hipMemcpy(d_init, init_angles, sizeof(double) * 7 * n_seq * n_legs, hipMemcpyHostToDevice));
-        }
-        TB(hipMemcpy(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice));
-        out = seqik_solve_generic_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk, d_status, d_nfev, d_init,
-                                         nullptr, affine, opt, nullptr);
-        if (out != SEQIK_OK) break;
-        TB(hipDeviceSynchronize());
-        TB(hipMemcpy(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost));
-        if (fk) TB(hipMemcpy(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost));
-        if (status) TB(hipMemcpy(status, d_status, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost));
-        if (nfev) TB(hipMemcpy(nfev, d_nfev, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost));
-#undef TB
-    } while (0);
-    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev);
-    (void)hipFree(d_init);
-    return out;
+    seqik::DeviceScope scope;
+    HIP_TRY(scope.enter(opt ? opt->device : -1));
+    HostCall call;
+    if ((rc = acquire_ctx(&call.ctx)) != SEQIK_OK) return rc;
+    const size_t n_ch = (size_t)n_seq * n_legs;
+    const size_t need = ArenaCursor::padded(sizeof(double) * 15 * n_lf) + ArenaCursor::padded(sizeof(double) * 7 * n_lf) +
+                        (fk ? ArenaCursor::padded(sizeof(double) * 27 * n_lf) : 0) +
+                        (status ? ArenaCursor::padded(sizeof(int32_t) * n_lf) : 0) +
+                        (nfev ? ArenaCursor::padded(sizeof(int32_t) * n_lf) : 0) +
+                        (init_angles ? ArenaCursor::padded(sizeof(double) * 7 * n_ch) : 0);
+    if ((rc = ctx_reserve(call.ctx, need)) != SEQIK_OK) return rc;
+    hipStream_t stream = call.ctx->stream;
+    ArenaCursor cur{call.ctx->arena};
+    double *d_pose = cur.take<double>(15 * n_lf), *d_angles = cur.take<double>(7 * n_lf);
+    double *d_fk = fk ? cur.take<double>(27 * n_lf) : nullptr;
+    int32_t *d_status = status ? cur.take<int32_t>(n_lf) : nullptr, *d_nfev = nfev ? cur.take<int32_t>(n_lf) : nullptr;
+    double *d_init = init_angles ? cur.take<double>(7 * n_ch) : nullptr;
+    if (d_init) TRY_OUT(hipMemcpyAsync(d_init, init_angles, sizeof(double) * 7 * n_ch, hipMemcpyHostToDevice, stream));
+    TRY_OUT(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
+    rc = seqik_solve_generic_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk, d_status, d_nfev, d_init,
+                                    nullptr, affine, opt, stream);
+    if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
+    TRY_OUT(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (fk) TRY_OUT(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost, stream));
+    if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * n_lf, hipMemcpyDeviceToHost, stream));
+    TRY_OUT(hipStreamSynchronize(stream));
+    return SEQIK_OK;
 }
 
 int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
@@ -679,49 +1068,52 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, pose, angles);
     if (rc != SEQIK_OK) return rc;
-    const int64_t n_lf = n_seq * (int64_t)n_legs * n_frames;  // leg-frames
+    const size_t n_lf = (size_t)n_seq * n_legs * n_frames;  // leg-frames
     if (n_lf == 0) return SEQIK_OK;
-    if (opt) HIP_TRY(hipSetDevice(opt->device));
-    hipStream_t stream;
-    HIP_TRY(hipStreamCreate(&stream));
-    double *d_pose = nullptr, *d_angles = nullptr, *d_fk = nullptr, *d_init = nullptr;
-    int32_t *d_status = nullptr, *d_nfev = nullptr;
+    seqik::DeviceScope scope;
+    HIP_TRY(scope.enter(opt ? opt->device : -1));
+    HostCall call;
+    if ((rc = acquire_ctx(&call.ctx)) != SEQIK_OK) return rc;
     const bool want_fk = fk && last_stage == 4;
-    int out = SEQIK_OK;
-    do {
-#define TRY_BREAK(expr)                                                                          \
-    {                                                                                            \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess) { out = fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); break; } \
+    const bool want_stats = opt && opt->chunk_stats;
+    const size_t n_ch = (size_t)n_seq * n_legs;
+    const size_t need = ArenaCursor::padded(sizeof(double) * 15 * n_lf) + ArenaCursor::padded(sizeof(double) * 7 * n_lf) +
+                        (want_fk ? ArenaCursor::padded(sizeof(double) * 27 * n_lf) : 0) +
+                        (status ? ArenaCursor::padded(sizeof(int32_t) * 4 * n_lf) : 0) +
+                        (nfev ? ArenaCursor::padded(sizeof(int32_t) * 4 * n_lf) : 0) +
+                        (init_angles ? ArenaCursor::padded(sizeof(double) * 7 * n_ch) : 0) + 256;
+    if ((rc = ctx_reserve(call.ctx, need)) != SEQIK_OK) return rc;
+    hipStream_t stream = call.ctx->stream;
+    ArenaCursor cur{call.ctx->arena};
+    double *d_pose = cur.take<double>(15 * n_lf), *d_angles = cur.take<double>(7 * n_lf);
+    double *d_fk = want_fk ? cur.take<double>(27 * n_lf) : nullptr;
+    int32_t *d_status = status ? cur.take<int32_t>(4 * n_lf) : nullptr, *d_nfev = nfev ? cur.take<int32_t>(4 * n_lf) : nullptr;
+    double *d_init = init_angles ? cur.take<double>(7 * n_ch) : nullptr;
+    int32_t *d_stats = cur.take<int32_t>(8);
+    if (d_init) TRY_OUT(hipMemcpyAsync(d_init, init_angles, sizeof(double) * 7 * n_ch, hipMemcpyHostToDevice, stream));
+    TRY_OUT(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
+    // angles is in/out: columns of stages that do not run are inputs (earlier stages) or stay as they are
+    if (first_stage > 1 || last_stage < 4)
+        TRY_OUT(hipMemcpyAsync(d_angles, angles, sizeof(double) * 7 * n_lf, hipMemcpyHostToDevice, stream));
+    if (d_status) TRY_OUT(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
+    if (d_nfev) TRY_OUT(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
+    SeqikOptions dev_opt;
+    if (opt) dev_opt = *opt; else memset(&dev_opt, 0, sizeof(dev_opt));
+    if (want_stats) {
+        TRY_OUT(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 8, stream));  // stays zero when the call is not chunked
+        dev_opt.chunk_stats = d_stats;
     }
-        TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_pose), sizeof(double) * 15 * n_lf));
-        TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_angles), sizeof(double) * 7 * n_lf));
-        if (want_fk) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_fk), sizeof(double) * 27 * n_lf));
-        if (status) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_status), sizeof(int32_t) * 4 * n_lf));
-        if (nfev) TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_nfev), sizeof(int32_t) * 4 * n_lf));
-        if (init_angles) {
-            const size_t ib = sizeof(double) * 7 * n_seq * n_legs;
-            TRY_BREAK(hipMalloc(reinterpret_cast<void **>(&d_init), ib));
-            TRY_BREAK(hipMemcpyAsync(d_init, init_angles, ib, hipMemcpyHostToDevice, stream));
-        }
-        TRY_BREAK(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
-        // angles is in/out: earlier-stage columns are inputs when first_stage > 1
-        TRY_BREAK(hipMemcpyAsync(d_angles, angles, sizeof(double) * 7 * n_lf, hipMemcpyHostToDevice, stream));
-        if (d_status) TRY_BREAK(hipMemsetAsync(d_status, 0xff, sizeof(int32_t) * 4 * n_lf, stream));
-        if (d_nfev) TRY_BREAK(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
-        out = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
-                                     d_fk, d_status, d_nfev, d_init, nullptr, affine, opt, stream);
-        if (out != SEQIK_OK) break;
-        TRY_BREAK(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
-        if (want_fk) TRY_BREAK(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
-        if (status) TRY_BREAK(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
-        if (nfev) TRY_BREAK(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
-        TRY_BREAK(hipStreamSynchronize(stream));
-#undef TRY_BREAK
-    } while (0);
-    (void)hipFree(d_pose); (void)hipFree(d_angles); (void)hipFree(d_fk); (void)hipFree(d_status); (void)hipFree(d_nfev); (void)hipFree(d_init);
-    (void)hipStreamDestroy(stream);
-    return out;
+    rc = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
+                                d_fk, d_status, d_nfev, d_init, nullptr, affine, opt ? &dev_opt : nullptr, stream);
+    if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
+    TRY_OUT(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (want_fk) TRY_OUT(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
+    if (want_stats) TRY_OUT(hipMemcpyAsync(opt->chunk_stats, d_stats, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, stream));
+    TRY_OUT(hipStreamSynchronize(stream));
+    return SEQIK_OK;
 }
+#undef TRY_OUT
 
 }  // extern "C"

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/seqik.h"
+#include "seqik_device_scope.hpp"
 
 extern "C" void seqik_set_error(int code, const char *msg);
 
@@ -93,7 +94,8 @@ namespace {
 void destroy(SeqikStream *s)
 {
     if (!s) return;
-    (void)hipSetDevice(s->device);
+    seqik::DeviceScope scope;
+    (void)scope.enter(s->device);
     for (hipStream_t c : s->compute) if (c) (void)hipStreamSynchronize(c);
     if (s->h2d) (void)hipStreamSynchronize(s->h2d);
     if (s->d2h) (void)hipStreamSynchronize(s->d2h);
@@ -112,7 +114,9 @@ void destroy(SeqikStream *s)
 
 int open_impl(SeqikStream *s)
 {
-    STRY(hipSetDevice(s->device));
+    seqik::DeviceScope scope;
+    STRY(seqik::resolve_device(s->device, &s->device));
+    STRY(scope.enter(s->device));
     STRY(hipStreamCreateWithFlags(&s->h2d, hipStreamNonBlocking));
     // carried slabs depend on each other: one in-order stream.  Otherwise one compute stream per slot, up to three
     // (10 M frames x 6 legs with FK: 1 stream 0.47 s, 2 0.40 s, 3 0.38 s; without FK 2 0.26 s, 3 0.24 s).  That is
@@ -122,9 +126,13 @@ int open_impl(SeqikStream *s)
     for (int i = 0; i < s->n_compute; ++i) STRY(hipStreamCreateWithFlags(&s->compute[i], hipStreamNonBlocking));
     STRY(hipStreamCreateWithFlags(&s->d2h, hipStreamNonBlocking));
     const size_t lf = (size_t)s->slab_seq * s->n_legs * s->n_frames;
+    // a custom layout may pad a chain's block (chain stride > dense size): the slots hold whole chain blocks
+    const size_t n_ch = (size_t)s->slab_seq * s->n_legs;
+    const size_t pose_elems = s->have_layout ? (size_t)s->layout.pose_chain * n_ch : 15 * lf;
+    const size_t ang_elems = s->have_layout ? (size_t)s->layout.ang_chain * n_ch : 7 * lf;
     for (Slot &q : s->slots) {
-        STRY(hipMalloc(reinterpret_cast<void **>(&q.d_pose), sizeof(double) * 15 * lf));
-        STRY(hipMalloc(reinterpret_cast<void **>(&q.d_angles), sizeof(double) * 7 * lf));
+        STRY(hipMalloc(reinterpret_cast<void **>(&q.d_pose), sizeof(double) * pose_elems));
+        STRY(hipMalloc(reinterpret_cast<void **>(&q.d_angles), sizeof(double) * ang_elems));
         if (s->want_fk) STRY(hipMalloc(reinterpret_cast<void **>(&q.d_fk), sizeof(double) * 27 * lf));
         STRY(hipEventCreateWithFlags(&q.up, hipEventDisableTiming));
         STRY(hipEventCreateWithFlags(&q.solved, hipEventDisableTiming));
@@ -179,13 +187,27 @@ int seqik_stream_open(SeqikStream **out, int32_t n_legs, const SeqikLegParams *l
     if (rc != SEQIK_OK) return rc;
     SeqikStream *s = new (std::nothrow) SeqikStream;
     if (!s) return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_open: out of host memory");
-    s->device = opt ? opt->device : 0;
+    s->device = opt ? opt->device : -1;  // resolved to the current device in open_impl
     s->n_legs = n_legs; s->slab_seq = slab_seq; s->n_frames = n_frames;
     s->want_fk = want_fk != 0; s->carry = carry != 0; s->generic = generic != 0;
     s->legs.assign(legs, legs + n_legs);
     if (affine) s->affine.assign(affine, affine + n_legs);
-    if (layout) { s->layout = *layout; s->have_layout = true; }
-    if (opt) { s->opt = *opt; s->opt.stage_events = nullptr; }
+    if (layout) {
+        // every element a kernel touches must lie inside its chain's block, and the blocks of a slab are copied
+        // as one contiguous piece of n_seq * n_legs chain strides
+        const int64_t T = n_frames;
+        const bool ok = layout->pose_row > 0 && layout->pose_frame > 0 && layout->ang_dof > 0 && layout->ang_frame > 0 &&
+                        4 * layout->pose_row + (T - 1) * layout->pose_frame + 3 <= layout->pose_chain &&
+                        6 * layout->ang_dof + (T - 1) * layout->ang_frame + 1 <= layout->ang_chain;
+        if (!ok) {
+            delete s;
+            return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_open: layout strides must be positive and every key point / "
+                                              "angle of a chain must lie inside its chain stride");
+        }
+        s->layout = *layout;
+        s->have_layout = true;
+    }
+    if (opt) { s->opt = *opt; s->opt.stage_events = nullptr; s->opt.chunk_stats = nullptr; }
     s->slots.resize(n_slots);
     rc = open_impl(s);
     if (rc != SEQIK_OK) { destroy(s); return rc; }
@@ -204,7 +226,8 @@ int seqik_stream_submit(SeqikStream *s, const double *pose, int64_t n_seq, doubl
             return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_submit: a carried run needs the same n_seq in every slab");
         s->carry_seq = n_seq;
     }
-    STRY(hipSetDevice(s->device));
+    seqik::DeviceScope scope;
+    STRY(scope.enter(s->device));
     Slot &q = s->slots[s->submitted % (int64_t)s->slots.size()];
     if (q.in_flight) { STRY(hipEventSynchronize(q.done)); q.in_flight = false; }
     const size_t lf = (size_t)n_seq * s->n_legs * s->n_frames;
@@ -249,7 +272,8 @@ int seqik_stream_submit(SeqikStream *s, const double *pose, int64_t n_seq, doubl
 int seqik_stream_wait(SeqikStream *s)
 {
     if (!s) return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_wait: null handle");
-    STRY(hipSetDevice(s->device));
+    seqik::DeviceScope scope;
+    STRY(scope.enter(s->device));
     for (Slot &q : s->slots)
         if (q.in_flight) { STRY(hipEventSynchronize(q.done)); q.in_flight = false; }
     return SEQIK_OK;

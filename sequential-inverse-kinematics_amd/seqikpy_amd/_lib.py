@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
 SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip", "seqik_core.hpp",
-           "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp"]
+           "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp", "seqik_device_scope.hpp"]
 COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 
@@ -36,8 +36,22 @@ class SeqikLegParams(ctypes.Structure):
 
 
 class SeqikOptions(ctypes.Structure):
+    """Mirror of ``struct SeqikOptions`` (include/seqik.h, ABI 2)."""
     _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32),
-                ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("reserved", ctypes.c_int32 * 4)]
+                ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("reserved", ctypes.c_int32 * 4),
+                ("frame_chunk", ctypes.c_int32), ("frame_halo", ctypes.c_int32), ("chunk_tol", ctypes.c_double),
+                ("chunk_rounds", ctypes.c_int32), ("pad_", ctypes.c_int32),
+                ("chunk_stats", ctypes.POINTER(ctypes.c_int32))]
+
+
+ABI_VERSION = 2
+CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
+                      "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check")
+
+
+def chunk_stats_dict(stats):
+    """int32[8] of ``SeqikOptions.chunk_stats`` -> dict (all zero: the call ran serially)."""
+    return {k: int(v) for k, v in zip(CHUNK_STATS_FIELDS, stats)}
 
 
 class SeqikLayout(ctypes.Structure):
@@ -118,6 +132,9 @@ def load():
                 pass
         L = ctypes.CDLL(LIB_PATH)
         L.seqik_abi_version.restype = ctypes.c_int
+        if L.seqik_abi_version() != ABI_VERSION:
+            raise SeqikLibraryError(f"{LIB_PATH} has ABI {L.seqik_abi_version()}, this package needs {ABI_VERSION}: "
+                                    "rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)")
         L.seqik_device_count.restype = ctypes.c_int
         L.seqik_last_error.restype = ctypes.c_char_p
         L.seqik_release_workspaces.restype = ctypes.c_int
@@ -215,7 +232,7 @@ class AlignStats:
     the four segment lengths), computed on the GPU.  ``add`` takes host arrays ``(S, L, N, 5, 3)`` (or a raw
     device pointer with ``on_device=True``); ``finish(ranks)`` returns ``(L, 7, len(ranks))``."""
 
-    def __init__(self, n_legs, capacity_frames, device=0):
+    def __init__(self, n_legs, capacity_frames, device=-1):
         self.n_legs = int(n_legs)
         self._h = ctypes.c_void_p()
         opt = SeqikOptions()
@@ -345,7 +362,7 @@ def device_attributes(device=0):
     return cu.value, khz.value, mem.value
 
 
-def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_size=0, affine=None, init_angles=None,
+def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_size=0, affine=None, init_angles=None,
                   lanes_per_wave=0):
     """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
     fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None)."""
@@ -379,7 +396,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=0, block_siz
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)
 
 
-def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=0):
+def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=-1):
     """``seqik_head_angles`` on host arrays: (N, 2, 3), (N, 2, 3), neck (3,) or (N, 3) -> (7 or 3, N)."""
     r_head = np.ascontiguousarray(r_head, dtype=np.float64)
     l_head = np.ascontiguousarray(l_head, dtype=np.float64)
@@ -464,14 +481,20 @@ def _affine_array(affine, n_legs):
 
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
-              device=0, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0, interleave_legs=0):
+              device=-1, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0, interleave_legs=0,
+              frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
     (S, L, N, 7) with earlier-stage columns filled when ``first_stage > 1``.
     ``affine``: optional list of L ``SeqikAffine`` -- ``pose`` then holds RAW key points and the
     alignment is fused into the kernels.  ``lanes_per_wave``: chains per wavefront (0 = automatic, see
-    ``SeqikOptions.reserved[0]``); ``staged=1``: one launch per stage instead of the single fused launch.  Returns dict(angles, fk or None, status or None, nfev or None).
+    ``SeqikOptions.reserved[0]``); ``staged=1``: one launch per stage instead of the single fused launch.
+    ``frame_chunk`` (0 = serial walk, bit-exact; -1 = automatic; > 0 = frames per chunk), ``frame_halo``,
+    ``chunk_tol``, ``chunk_rounds``: frame chunks, see ``SeqikOptions`` in include/seqik.h -- one long recording
+    solved in concurrently running pieces, equal to the serial walk to about ``chunk_tol`` (default 1e-6 rad).
+    ``device``: HIP device ordinal, -1 = the calling thread's current device.
+    Returns dict(angles, fk or None, status or None, nfev or None, chunk_stats).
     """
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
@@ -496,6 +519,9 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
     opt.reserved[2] = interleave_legs
+    opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
+    stats = np.zeros(8, dtype=np.int32)
+    opt.chunk_stats = stats.ctypes.data_as(_ip)
     if init_angles is not None:
         init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
         if init_angles.shape != (S, L, 7):
@@ -510,12 +536,13 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
                              _affine_array(affine, L), ctypes.byref(opt))
     if rc != SEQIK_OK:
         _raise(rc)
-    return dict(angles=angles, fk=fk, status=status, nfev=nfev)
+    return dict(angles=angles, fk=fk, status=status, nfev=nfev, chunk_stats=chunk_stats_dict(stats))
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
                      first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
-                     stage_events=None, lanes_per_wave=0, staged=0, interleave_legs=0):
+                     stage_events=None, lanes_per_wave=0, staged=0, interleave_legs=0,
+                     frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, d_chunk_stats=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
     ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
@@ -526,6 +553,9 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
     opt.reserved[2] = interleave_legs
+    opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
+    if d_chunk_stats:  # device int32[8]
+        opt.chunk_stats = ctypes.cast(ctypes.c_void_p(int(d_chunk_stats)), _ip)
     if stage_events is not None:
         ev = (ctypes.c_void_p * 5)(*[ctypes.c_void_p(int(e)) for e in stage_events])
         opt.stage_events = ctypes.cast(ev, ctypes.POINTER(ctypes.c_void_p))

@@ -112,7 +112,7 @@ class AlignPose:
         self.logger.info("Scale factor for %s leg: %s", leg_name, scale)
         return fixed_coxa, float(scale), np.asarray(self.body_template[f"{leg_name}_Coxa"], dtype=np.float64)
 
-    def leg_affines(self, on_gpu: bool = False, device: int = 0) -> Dict[str, Tuple[np.ndarray, float, np.ndarray]]:
+    def leg_affines(self, on_gpu: bool = False, device: int = -1) -> Dict[str, Tuple[np.ndarray, float, np.ndarray]]:
         """Affine constants of every ``*_leg`` entry, keyed by leg name (for the fused GPU path).
 
         ``on_gpu=True`` computes the whole-recording reductions (seven quantile pairs per leg) on the MI355X

@@ -21,7 +21,7 @@ from .kinematic_chain import KinematicChainSeq
 
 def run_ik_and_fk_many(recordings: Sequence[Dict[str, np.ndarray]], kinematic_chain_class: KinematicChainSeq,
                        initial_angles: Optional[Dict[str, Dict[str, np.ndarray]]] = None,
-                       pad_to_multiple: int = 0, device: int = 0,
+                       pad_to_multiple: int = 0, device: int = -1,
                        leg_affine: Optional[Dict[str, tuple]] = None
                        ) -> List[Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]]:
     """``LegInvKinSeq(rec, kinematic_chain_class, initial_angles).run_ik_and_fk()`` for every ``rec``.

@@ -28,7 +28,7 @@ from . import _lib
 
 
 def solve_frame_parallel(pose: np.ndarray, legs: List, chunk: int = 32, halo: int = 16, tol: float = 1e-6,
-                         want_fk: bool = True, affine=None, device: int = 0, stats: Optional[Dict] = None,
+                         want_fk: bool = True, affine=None, device: int = -1, stats: Optional[Dict] = None,
                          lead: int = 0, init_angles: Optional[np.ndarray] = None):
     """``pose`` (S, L, lead + N, 5, 3) -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None).
 

@@ -35,7 +35,7 @@ def frame_slab(n_frames: int, world: int, rank: int, chunk: int):
 
 
 def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 32, halo: int = 16, tol: float = 1e-6,
-                        want_fk: bool = True, affine=None, device: int = 0, group=None,
+                        want_fk: bool = True, affine=None, device: int = -1, group=None,
                         stats: Optional[Dict] = None):
     """``pose`` (S, L, N, 5, 3) -- the same array on every rank, of which a rank only touches its slab and the
     ``halo`` frames in front of it -- -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) on every rank.

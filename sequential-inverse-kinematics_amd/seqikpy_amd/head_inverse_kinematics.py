@@ -46,7 +46,7 @@ class HeadInverseKinematics:
         self.rest_antenna_pitch = self.get_rest_antenna_pitch()
         self.logger = logging.getLogger(self.__class__.__name__)
         self.logger.setLevel(getattr(logging, log_level.upper(), None))
-        self.device = 0
+        self.device = -1  # HIP device ordinal; -1 = the calling thread's current device
 
     def get_rest_antenna_pitch(self) -> float:
         """Antenna pitch at the zero pose of the biomechanical model."""

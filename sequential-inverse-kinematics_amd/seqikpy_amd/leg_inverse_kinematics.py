@@ -69,7 +69,7 @@ class LegInvKinBase(ABC):
         self.logger = logging.getLogger(self.__class__.__name__)
         self.logger.setLevel(getattr(logging, log_level.upper(), None))
         #: HIP device ordinal used by this object
-        self.device = 0
+        self.device = -1  # HIP device ordinal; -1 = the calling thread's current device
 
     # -- per-frame seam (reference :62-77) ---------------------------------------------
     def calculate_ik(self, kinematic_chain: Chain, target_pos: np.ndarray,
@@ -175,6 +175,8 @@ class LegInvKinSeq(LegInvKinBase):
         #: scipy termination status / nfev of the last run when ``diagnostics=True`` was passed
         self.solver_status = {}
         self.solver_nfev = {}
+        #: chunk statistics of the last launch (``_lib.CHUNK_STATS_FIELDS``; all zero = serial walk)
+        self.frame_chunk_stats = {}
 
     def _leg_params(self, leg_name, initial_angles=None):
         kc = self.kinematic_chain_class
@@ -233,15 +235,34 @@ class LegInvKinSeq(LegInvKinBase):
 
         kwargs: ``stages`` (default [1, 2, 3, 4], consecutive), ``hide_progress_bar`` (accepted,
         unused: there is no per-frame host loop), ``diagnostics`` (also collect scipy status/nfev),
-        ``frame_parallel`` (False, True or a dict of ``frame_parallel.solve_frame_parallel`` options:
-        cut long recordings into verified chunks -- much lower latency for a few long recordings,
-        results equal to the serial mode to ~1e-6 rad; only with the default stages).
+        ``frame_parallel``: how the serial frame loop of the reference (:259-282, frame t warm-started from frame
+        t-1) is mapped to the GPU --
+
+        * ``"auto"`` (default): recordings of 48 frames and more are cut into frame chunks that are solved
+          concurrently, verified against their true predecessor and repaired on the device
+          (``SeqikOptions.frame_chunk = -1``, include/seqik.h).  Every frame is still solved by the reference's
+          algorithm from a warm start within 1e-6 rad of the serial one; the result equals the serial walk to
+          ~1e-5 rad on well-posed frames (the reference's own run-to-run noise is ~5e-5 rad), 10-50x faster for
+          one recording.  Applies to runs of all four stages without diagnostics; others are walked serially.
+        * ``False``: the serial walk (bit-identical to the oracle restatement of the reference).
+        * ``True`` or a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters.
+
+        ``self.frame_chunk_stats`` holds the chunk statistics of the last launch.
         Returns ``(joint_angles_dict, forward_kinematics_dict)``."""
         stages = list(kwargs.get("stages", [1, 2, 3, 4]))
         diagnostics = bool(kwargs.get("diagnostics", False))
-        frame_parallel = kwargs.get("frame_parallel", False)
-        if frame_parallel and (list(stages) != [1, 2, 3, 4] or diagnostics):
-            raise ValueError("frame_parallel needs stages=[1, 2, 3, 4] and diagnostics=False")
+        frame_parallel = kwargs.get("frame_parallel", "auto")
+        chunk_opts = dict(frame_chunk=0)
+        if frame_parallel is not False and frame_parallel is not None:
+            explicit = frame_parallel is True or isinstance(frame_parallel, dict)
+            if explicit and (list(stages) != [1, 2, 3, 4] or diagnostics):
+                raise ValueError("frame_parallel needs stages=[1, 2, 3, 4] and diagnostics=False")
+            fp = frame_parallel if isinstance(frame_parallel, dict) else {}
+            unknown = set(fp) - {"chunk", "halo", "tol", "rounds"}
+            if unknown:
+                raise ValueError(f"unknown frame_parallel options: {sorted(unknown)}")
+            chunk_opts = dict(frame_chunk=int(fp.get("chunk", -1)), frame_halo=int(fp.get("halo", 0)),
+                              chunk_tol=float(fp.get("tol", 0.0)), chunk_rounds=int(fp.get("rounds", 0)))
         if max(stages) > 4 or not all(np.diff(stages) == 1):
             raise ValueError("Maximum stage number is 4 and the list should be strictly incremental.")
         first_stage, last_stage = stages[0], stages[-1]
@@ -260,15 +281,9 @@ class LegInvKinSeq(LegInvKinBase):
             affine = None
             if self.leg_affine is not None:
                 affine = [_lib.make_affine(*self.leg_affine[leg_name]) for _, leg_name, _ in items]
-            if frame_parallel:
-                from .frame_parallel import solve_frame_parallel
-                opts = dict(frame_parallel) if isinstance(frame_parallel, dict) else {}
-                self.frame_parallel_stats = {}
-                out = solve_frame_parallel(pose, legs, want_fk=True, affine=affine, device=self.device,
-                                           stats=self.frame_parallel_stats, **opts)
-            else:
-                out = _lib.solve_seq(pose, legs, first_stage, last_stage, angles=prior, want_fk=True,
-                                     want_diag=diagnostics, device=self.device, affine=affine)
+            out = _lib.solve_seq(pose, legs, first_stage, last_stage, angles=prior, want_fk=True,
+                                 want_diag=diagnostics, device=self.device, affine=affine, **chunk_opts)
+            self.frame_chunk_stats = out["chunk_stats"]
             for li, (segment_name, leg_name, _) in enumerate(items):
                 for stage in stages:
                     for dof in STAGE_DOFS[stage]:

@@ -19,10 +19,11 @@ from .kinematic_chain import KinematicChainSeq
 
 
 def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainSeq,
-                body_template: Dict[str, np.ndarray], initial_angles: Optional[Dict] = None, device: int = 0
-                ) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+                body_template: Dict[str, np.ndarray], initial_angles: Optional[Dict] = None, device: int = -1,
+                frame_parallel="auto") -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """Returns ``(body_joint_angles, forward_kinematics)``: the 7 head / antenna angles (when ``R_head``, ``L_head``
-    and ``Neck`` are present) + 7 angles per leg, and the ``"<leg>_leg" -> (N, 9, 3)`` joint positions."""
+    and ``Neck`` are present) + 7 angles per leg, and the ``"<leg>_leg" -> (N, 9, 3)`` joint positions.
+    ``frame_parallel``: ``"auto"`` (verified frame chunks, as ``LegInvKinSeq.run_ik_and_fk``) or ``False`` (serial)."""
     import torch
     if initial_angles is None:
         initial_angles = INITIAL_ANGLES
@@ -45,7 +46,7 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
         cur = torch.cuda.current_stream()
         leg_stream.wait_stream(cur)
         _lib.solve_seq_device(d_pose.data_ptr(), 1, len(segs), n, legs, d_ang.data_ptr(), d_fk.data_ptr(),
-                              stream=leg_stream.cuda_stream)
+                              stream=leg_stream.cuda_stream, frame_chunk=-1 if frame_parallel else 0)
         if with_head:
             hk = HeadInverseKinematics(aligned_pos, body_template, log_level="ERROR")
             r = np.ascontiguousarray(aligned_pos["R_head"], dtype=np.float64)

@@ -55,7 +55,7 @@ class SeqikStream:
 
     def __init__(self, legs: List[_lib.SeqikLegParams], slab_seq: int, n_frames: int, affine=None, layout=None,
                  want_fk: bool = True, n_slots: int = 3, carry: bool = False, generic: bool = False,
-                 device: int = 0, block_size: int = 0):
+                 device: int = -1, block_size: int = 0):
         self._lib = _lib.load()
         self.n_legs = len(legs)
         self.slab_seq, self.n_frames = int(slab_seq), int(n_frames)
@@ -132,7 +132,7 @@ class SeqikStream:
 
 
 def solve_streamed(pose: np.ndarray, legs, slab_seq: int, affine=None, want_fk: bool = True, n_slots: int = 3,
-                   device: int = 0):
+                   device: int = -1):
     """Convenience: ``pose (S, L, N, 5, 3)`` pushed through a stream in slabs of ``slab_seq`` sequences.
     Returns ``dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None)`` -- equal to ``_lib.solve_seq`` bit for bit."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
@@ -150,7 +150,7 @@ def solve_streamed(pose: np.ndarray, legs, slab_seq: int, affine=None, want_fk: 
 
 
 def solve_streamed_in_time(pose: np.ndarray, legs, slab_frames: int, affine=None, want_fk: bool = True,
-                           n_slots: int = 3, device: int = 0):
+                           n_slots: int = 3, device: int = -1):
     """``pose (S, L, N, 5, 3)`` pushed through a carried stream in slabs of ``slab_frames`` frames (the S
     recordings advance in lock step).  Equal to ``_lib.solve_seq(pose, ...)`` bit for bit."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)

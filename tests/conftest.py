@@ -69,6 +69,9 @@ class HostHarness:
         self.lib.harness_run_chain.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
                                                ctypes.c_int32, dp, dp, ip, ip, ctypes.POINTER(AffineC), dp]
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
+        self.lib.harness_run_chunked.restype = ctypes.c_int
+        self.lib.harness_run_chunked.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
+                                                 ctypes.c_int32, ctypes.c_double, ctypes.c_int32, dp, dp, dp, ip]
         self.lib.harness_run_generic.restype = ctypes.c_int
         self.lib.harness_run_generic.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), dp, dp, ip, ip, dp]
         self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
@@ -107,6 +110,29 @@ class HostHarness:
         if rc != 0:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
+
+    def run_chunked(self, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, want_fk=True, init=None):
+        """Frame chunks: the device core's CHUNKED code + a serial re-enactment of the launch sequence."""
+        dp = ctypes.POINTER(ctypes.c_double)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        n = pose.shape[0]
+        ang, fk = np.zeros((n, 7)), np.full((n, 9, 3), np.nan)
+        stats = np.zeros(8, np.int32)
+        lp = LegParamsC()
+        for i in range(4):
+            lp.seg[i] = seg[i]
+        for i in range(7):
+            lp.bounds[i][0] = bounds[i][0]
+            lp.bounds[i][1] = bounds[i][1]
+        for i in range(27):
+            lp.seeds[i] = seeds[i]
+        rc = self.lib.harness_run_chunked(pose.ctypes.data_as(dp), n, ctypes.byref(lp), chunk, halo, tol, rounds,
+                                          ang.ctypes.data_as(dp), fk.ctypes.data_as(dp) if want_fk else None,
+                                          np.ascontiguousarray(init, dtype=np.float64).ctypes.data_as(dp) if init is not None else None,
+                                          stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        if rc != 0:
+            raise ValueError(f"harness rc={rc}")
+        return dict(angles=ang, fk=fk if want_fk else None, stats=stats)
 
     def run_generic(self, pose, seg, bounds, seeds, init=None):
         dp = ctypes.POINTER(ctypes.c_double)

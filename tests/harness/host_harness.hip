@@ -52,6 +52,86 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
     return SEQIK_OK;
 }
 
+// Frame chunks (SeqikOptions.frame_chunk): the device code's CHUNKED instantiation of run_stage plus a serial
+// re-enactment of the launch sequence of seqik_hip.hip (speculative pass, R x {scan, repair}, scan + sweep) for one
+// chain.  stats as SeqikOptions.chunk_stats.
+static void harness_solve_chunk(const seqik::LegConst &lc, const double *pose, int64_t N, double *angles, double *fk,
+                                int64_t k, int64_t C, int64_t h, bool repair, const double *init0, double *ss, double *ws)
+{
+    seqik::ChainIO io;
+    io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
+    io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
+    io.fk = fk; io.status = nullptr; io.nfev = nullptr;
+    io.frames = ws;
+    io.t_store = k * C;
+    io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
+    if (!repair) {
+        io.t_begin = (k * C > h) ? k * C - h : 0;
+        io.init = (k == 0) ? init0 : nullptr;
+        io.init_stride = 1;
+        io.start_state = (k > 0) ? ss + k * 7 : nullptr;
+    } else {
+        io.t_begin = io.t_store;
+        io.init = angles + (io.t_store - 1) * 7;
+        io.init_stride = 1;
+        io.start_state = nullptr;
+        for (int d = 0; d < 7; ++d) ss[k * 7 + d] = io.init[d];
+    }
+    if (fk) {
+        seqik::run_stage<1, false, false, false, true, true>(lc, io);
+        seqik::run_stage<2, true, false, false, true, true>(lc, io);
+        seqik::run_stage<3, true, false, false, true, true>(lc, io);
+        seqik::run_stage<4, true, false, false, false, true>(lc, io);
+    } else {
+        seqik::run_stage<1, false, false, false, true, true>(lc, io);
+        seqik::run_stage<2, false, false, false, true, true>(lc, io);
+        seqik::run_stage<3, false, false, false, true, true>(lc, io);
+        seqik::run_stage<4, false, false, false, false, true>(lc, io);
+    }
+}
+
+extern "C" int harness_run_chunked(const double *pose, int64_t N, const SeqikLegParams *leg, int32_t C, int32_t h,
+                                   double tol, int32_t rounds, double *angles, double *fk, const double *init,
+                                   int32_t *stats)
+{
+    int rc = seqik::validate_leg(*leg, 1, 4);
+    if (rc != SEQIK_OK) return rc;
+    seqik::LegConst lc;
+    seqik::make_leg_consts(*leg, nullptr, lc);
+    const int64_t K = (N + C - 1) / C;
+    std::vector<double> ss((size_t)K * 7, 0.0), ws((size_t)(C + h) * 12 + 1);
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    stats[0] = (int32_t)K; stats[1] = C; stats[2] = h;
+    for (int64_t k = 0; k < K; ++k) harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, false, init, ss.data(), ws.data());
+    auto inconsistent = [&](int64_t k) {
+        bool bad = false;
+        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[k * 7 + d] - angles[(k * C - 1) * 7 + d]) <= tol);
+        return bad;
+    };
+    for (int r = 0; r <= rounds; ++r) {
+        std::vector<int64_t> ready;
+        int pending = 0;
+        for (int64_t k = 1; k < K; ++k)
+            if (inconsistent(k)) {
+                ++pending;
+                if (!(k > 1 && inconsistent(k - 1))) ready.push_back(k);
+            }
+        if (r == 0) stats[7] = pending;
+        if (pending == 0) break;
+        if (r < rounds) {
+            stats[3 + (r < 2 ? r : 2)] += (int32_t)ready.size();
+            for (int64_t k : ready) harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, true, nullptr, ss.data(), ws.data());
+        } else {
+            for (int64_t k = 1; k < K; ++k)
+                if (inconsistent(k)) {
+                    harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, true, nullptr, ss.data(), ws.data());
+                    stats[6] += 1;
+                }
+        }
+    }
+    return SEQIK_OK;
+}
+
 extern "C" void harness_sincos(double x, double *s, double *c) { seqik::sincos_cw(x, *s, *c); }
 
 // head / antenna angles: the kernel's per-frame device function, run on the host

@@ -38,12 +38,14 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 1
+    assert lib.seqik_abi_version() == 2 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):
     assert ctypes.sizeof(hiplib.SeqikLegParams) == 8 * (4 + 14 + 27)
-    assert ctypes.sizeof(hiplib.SeqikOptions) == 32
+    assert ctypes.sizeof(hiplib.SeqikOptions) == 64  # ABI 2: + frame chunk options
+    assert hiplib.SeqikOptions.frame_chunk.offset == 32 and hiplib.SeqikOptions.chunk_tol.offset == 40
+    assert hiplib.SeqikOptions.chunk_stats.offset == 56
     assert ctypes.sizeof(hiplib.SeqikLayout) == 48 and ctypes.sizeof(hiplib.SeqikAffine) == 56
 
 

@@ -1,0 +1,176 @@
+"""Frame chunks (SeqikOptions.frame_chunk): one long recording cut into concurrently solved pieces, verified and
+repaired on the device.  CPU tier: the device core's CHUNKED code (host harness) against the oracle-built model of the
+launch sequence, bit for bit; the model against the serial walk (tolerance semantics).  GPU tier: the library itself."""
+import numpy as np
+import pytest
+
+from chunk_model import chunked_oracle
+from conftest import leg_arrays, load_golden
+
+CASES = [("df3d_1000", "RF", slice(0, 300), 16, 8), ("df3d_1000", "LH", slice(100, 420), 8, 4),
+         ("anipose_shipped", "RF", slice(0, 500), 32, 8),
+         ("anipose_shipped", "LF", slice(200, 420), 8, 8),   # through the kinematic-singularity episode: repairs
+         ("anipose_shipped", "LF", slice(240, 400), 8, 2)]   # short run-in: many inconsistent chunks, cascades
+
+
+@pytest.mark.parametrize("name,leg,sl,chunk,halo", CASES)
+def test_chunked_core_equals_model(oracle, host_harness, name, leg, sl, chunk, halo):
+    pose, seg, b, seeds = leg_arrays(load_golden(name), leg)
+    pose = pose[sl]
+    for rounds in (3, 1):
+        m = chunked_oracle(oracle, pose, seg, b, seeds, chunk, halo, rounds=rounds)
+        hh = host_harness.run_chunked(pose, seg, b, seeds, chunk, halo, rounds=rounds)
+        assert np.array_equal(hh["angles"], m["angles"])
+        assert np.array_equal(hh["fk"], m["fk"])
+        assert np.array_equal(hh["stats"], m["stats"])
+
+
+def test_every_chunk_ends_up_consistent_and_repairs_happen(oracle):
+    """After the sweep every chunk's warm start is within tol of its predecessor's last frame; on the LF episode
+    chunks do get repaired (the test would be vacuous otherwise)."""
+    pose, seg, b, seeds = leg_arrays(load_golden("anipose_shipped"), "LF")
+    m = chunked_oracle(oracle, pose[240:400], seg, b, seeds, 8, 2, tol=1e-6, rounds=2)
+    assert m["stats"][7] > 0 and m["stats"][3] > 0
+    serial = oracle.seq_leg(pose[240:400], seg, b, seeds)
+    assert np.abs(m["angles"][:40] - serial["angles"][:40]).max() < 1e-4  # in front of the episode: well-posed
+
+
+def test_zero_tolerance_is_the_serial_walk(oracle, host_harness):
+    """chunk_tol < 0 (exact): a chunk is accepted only if the run-in reproduced the true state bit for bit, everything
+    else is re-solved from the true state -> the serial result, bit for bit."""
+    pose, seg, b, seeds = leg_arrays(load_golden("df3d_1000"), "RM")
+    pose = pose[:120]
+    serial = oracle.seq_leg(pose, seg, b, seeds)
+    for rounds in (0, 2):
+        hh = host_harness.run_chunked(pose, seg, b, seeds, 8, 4, tol=0.0, rounds=rounds)
+        assert np.array_equal(hh["angles"], serial["angles"]) and np.array_equal(hh["fk"], serial["fk"])
+
+
+def test_chunked_equals_serial_within_noise_floor_on_recordings(oracle):
+    """Default parameters on whole recordings: the chunked result stays within 2e-5 rad of the serial walk (measured
+    max 1.1e-5; the reference's own run-to-run noise is ~5e-5) outside the LF singularity episode."""
+    for name, legs, n in (("df3d_1000", ["RF", "RM", "LH"], 1000), ("anipose_shipped", ["RF"], 2000)):
+        z = load_golden(name)
+        for leg in legs:
+            pose, seg, b, seeds = leg_arrays(z, leg)
+            serial = oracle.seq_leg(pose[:n], seg, b, seeds)
+            m = chunked_oracle(oracle, pose[:n], seg, b, seeds, 8, 8)
+            assert np.abs(m["angles"] - serial["angles"]).max() < 2e-5, (name, leg)
+            assert np.abs(m["fk"] - serial["fk"]).max() < 2e-5
+
+
+def test_continuation_with_init(oracle, host_harness):
+    pose, seg, b, seeds = leg_arrays(load_golden("df3d_1000"), "LM")
+    first = oracle.seq_leg(pose[:50], seg, b, seeds)
+    init = first["angles"][-1]
+    m = chunked_oracle(oracle, pose[50:200], seg, b, seeds, 16, 8, init=init)
+    hh = host_harness.run_chunked(pose[50:200], seg, b, seeds, 16, 8, init=init)
+    assert np.array_equal(hh["angles"], m["angles"])
+    assert np.array_equal(hh["angles"][:16], oracle.seq_leg(pose[50:66], seg, b, seeds, init=init)["angles"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU tier: the library's device-side implementation (csrc/seqik_hip.hip "Frame chunks") through the C ABI
+# ---------------------------------------------------------------------------------------------------------------
+def _params(hiplib, z, legs):
+    return [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+
+
+def _model_all(oracle, z, legs, sl, chunk, halo, **kw):
+    ms = [chunked_oracle(oracle, z[f"{l}_pose"][sl], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"], chunk, halo, **kw)
+          for l in legs]
+    stats = np.sum([m["stats"] for m in ms], 0)
+    stats[1:3] = ms[0]["stats"][1:3]
+    return np.stack([m["angles"] for m in ms]), np.stack([m["fk"] for m in ms]), stats
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,legs,sl,chunk,halo,rounds", [
+    ("df3d_1000", None, slice(0, 1000), 16, 8, 3),                  # config 2: six legs, no repair expected
+    ("anipose_shipped", ["RF", "LF"], slice(0, 6000), 8, 8, 3),     # config 4: repairs in the LF episode
+    ("anipose_shipped", ["LF", "RF"], slice(200, 420), 8, 2, 1),    # short run-in, one round: the sweep works too
+    ("anipose_shipped", ["LF"], slice(240, 400), 8, 2, 8),          # cascades through many rounds
+    ("df3d_1000", ["RM", "LH"], slice(3, 998), 64, 16, 3),          # ragged last chunk, long halo
+])
+def test_hip_chunks_equal_model(oracle, hiplib, name, legs, sl, chunk, halo, rounds):
+    z = load_golden(name)
+    legs = legs or [str(l) for l in z["legs"]]
+    pose = np.stack([z[f"{l}_pose"][sl] for l in legs])[None]
+    out = hiplib.solve_seq(pose, _params(hiplib, z, legs), frame_chunk=chunk, frame_halo=halo, chunk_rounds=rounds)
+    ang, fk, stats = _model_all(oracle, z, legs, sl, chunk, halo, rounds=rounds)
+    assert np.array_equal(out["angles"][0], ang)
+    assert np.array_equal(out["fk"][0], fk)
+    got = np.array([out["chunk_stats"][k] for k in hiplib.CHUNK_STATS_FIELDS])
+    assert np.array_equal(got, stats), (got, stats)
+
+
+@pytest.mark.gpu
+def test_hip_chunks_several_sequences_planar_layout_and_init(oracle, hiplib):
+    """Device entry point: S sequences x L legs, planar layout, init_angles for chunk 0, lanes-per-wave overrides."""
+    import torch
+    z = load_golden("df3d_1000")
+    legs = ["LF", "RH", "LM"]
+    S, T, C, H = 3, 200, 16, 4
+    pose = np.stack([np.stack([z[f"{l}_pose"][100 + 250 * s:100 + 250 * s + T] for l in legs]) for s in range(S)])
+    first = [[oracle.seq_leg(z[f"{l}_pose"][90 + 250 * s:100 + 250 * s], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"])
+              ["angles"][-1] for l in legs] for s in range(S)]
+    init = np.array(first)
+    want = np.stack([np.stack([chunked_oracle(oracle, pose[s, li], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"], C, H,
+                                              init=init[s, li])["angles"] for li, l in enumerate(legs)]) for s in range(S)])
+    d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+    d_init = torch.from_numpy(init).cuda()
+    for lanes in (0, 1, 5, 64):
+        d_ang = torch.zeros((S, len(legs), 7, T), dtype=torch.float64, device="cuda")
+        d_fk = torch.zeros((S, len(legs), T, 9, 3), dtype=torch.float64, device="cuda")
+        d_stats = torch.zeros(8, dtype=torch.int32, device="cuda")
+        hiplib.solve_seq_device(d_pose.data_ptr(), S, len(legs), T, _params(hiplib, z, legs), d_ang.data_ptr(),
+                                d_fk.data_ptr(), layout=hiplib.planar_layout(T), d_init=d_init.data_ptr(),
+                                frame_chunk=C, frame_halo=H, lanes_per_wave=lanes, d_chunk_stats=d_stats.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_ang.cpu().numpy().transpose(0, 1, 3, 2), want), lanes
+        assert int(d_stats[0]) == S * len(legs) * 13
+
+
+@pytest.mark.gpu
+def test_hip_exact_tolerance_and_automatic_mode(oracle, hiplib):
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    params = _params(hiplib, z, legs)
+    serial = hiplib.solve_seq(pose, params)
+    assert all(v == 0 for v in serial["chunk_stats"].values())
+    exact = hiplib.solve_seq(pose[:, :, :160], params, frame_chunk=8, frame_halo=4, chunk_tol=-1.0, chunk_rounds=2)
+    assert np.array_equal(exact["angles"], serial["angles"][:, :, :160])  # bit for bit the serial walk
+    auto = hiplib.solve_seq(pose, params, frame_chunk=-1)
+    st = auto["chunk_stats"]
+    assert st["chunks"] == 6 * 125 and st["frames_per_chunk"] == 8 and st["run_in_frames"] == 8
+    assert np.abs(auto["angles"] - serial["angles"]).max() < 2e-5
+    assert np.abs(auto["fk"] - serial["fk"]).max() < 2e-5
+    short = hiplib.solve_seq(pose[:, :, :40], params, frame_chunk=-1)  # too short: serial
+    assert short["chunk_stats"]["chunks"] == 0 and np.array_equal(short["angles"], serial["angles"][:, :, :40])
+    # stage subsets and diagnostics are walked serially whatever frame_chunk says
+    diag = hiplib.solve_seq(pose[:, :, :100], params, want_diag=True, frame_chunk=8)
+    assert np.array_equal(diag["angles"], serial["angles"][:, :, :100]) and diag["chunk_stats"]["chunks"] == 0
+
+
+@pytest.mark.gpu
+def test_python_api_default_is_chunked_and_within_parity_of_shipped_golden(hiplib):
+    from conftest import LF_DEGENERATE
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    za = load_golden("anipose_shipped")
+    ik = LegInvKinSeq({"RF_leg": za["RF_pose"], "LF_leg": za["LF_pose"]}, KinematicChainSeq(BOUNDS, ["RF", "LF"]),
+                      INITIAL_ANGLES, log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk()
+    assert ik.frame_chunk_stats["chunks"] == 2 * 750
+    got = np.stack([ang[f"Angle_RF_{d}"] for d in hiplib.DOFS], 1)
+    assert np.abs(got - za["RF_angles"]).max() < 1e-4
+    ok = np.ones(6000, bool)
+    ok[LF_DEGENERATE[0]:LF_DEGENERATE[1]] = False
+    got = np.stack([ang[f"Angle_LF_{d}"] for d in hiplib.DOFS], 1)
+    assert np.abs(got - za["LF_angles"])[ok].max() < 1e-4
+    assert np.abs(fk["RF_leg"] - za["RF_fk"]).max() < 1e-4
+    serial_ang, _ = LegInvKinSeq({"RF_leg": za["RF_pose"][:300]}, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES,
+                                 log_level="ERROR").run_ik_and_fk(frame_parallel=False)
+    assert np.abs(serial_ang["Angle_RF_ThC_yaw"] - ang["Angle_RF_ThC_yaw"][:300]).max() < 2e-5

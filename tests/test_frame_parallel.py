@@ -82,11 +82,11 @@ def test_frame_parallel_on_gpu(hiplib):
     za = load_golden("anipose_shipped")
     ik = LegInvKinSeq({"RF_leg": za["RF_pose"], "LF_leg": za["LF_pose"]}, KinematicChainSeq(BOUNDS, ["RF", "LF"]),
                       INITIAL_ANGLES, log_level="ERROR")
-    ang, fk = ik.run_ik_and_fk(frame_parallel=True)
+    ang, fk = ik.run_ik_and_fk(frame_parallel=dict(chunk=32, halo=16))
     got = np.stack([ang[f"Angle_RF_{d}"] for d in hiplib.DOFS], 1)
     assert np.abs(got - za["RF_angles"]).max() < 1e-4
     ok = np.ones(6000, bool)
     ok[LF_DEGENERATE[0]:LF_DEGENERATE[1]] = False
     got = np.stack([ang[f"Angle_LF_{d}"] for d in hiplib.DOFS], 1)
     assert np.abs(got - za["LF_angles"])[ok].max() < 1e-4
-    assert ik.frame_parallel_stats["chunks"] == 188  # 6000 frames / 32 per chunk (the default), 1 recording
+    assert ik.frame_chunk_stats["chunks"] == 2 * 188  # 6000 frames / 32 per chunk, 2 legs (device-side chunks)
