@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the sequential leg-IK hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]   (N > 1: launched by torch.distributed.run)
 
 Metric (BASELINE.json): leg-IK solves/s, one solve = one (frame, leg) = 4 stage sub-solves ->
-7 joint angles (+ the stage-4 forward kinematics).  Workload at every N: BASELINE config 3,
-"synthetic 1M frames x 6 legs, random in-workspace target key points", PER GPU (weak scaling):
-1,000,000 frames are cut into 15,625 independent sequences of 64 frames (frame t of a sequence is
-warm-started from frame t-1, frame 0 from the seeds -- the reference's semantics applied to many
-recordings), 6 legs each = 93,750 chains.  A step is one pass of the hot path (one launch in which every
-wave takes its chains through stages 1-4; `--staged`: the 4 stage kernels) over that batch with inputs resident in HBM; for N > 1 every step also sends the rank's joint angles to rank 0
-(copy-engine peer writes over xGMI into rank 0's IPC-exported buffers, an 8-byte RCCL all-reduce as completion flag;
-grouped RCCL point-to-point if the peer path is unavailable; overlapped with the next steps' kernels; `config.gather`
-says which ran).
+7 joint angles (+ the stage-4 forward kinematics); and max |d theta| vs the reference (`parity`).
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, live HIP-event timing) and, at
-N = 1, `cpu_baseline` (the C oracle on the host cores, bounded sample of the same workload).
+Workload: BASELINE config 3, "synthetic 1M frames x 6 legs, random in-workspace target key points".
+  --scaling weak   (default) 1,000,000 frames PER GPU, cut into 15,625 independent sequences of 64 frames (frame t
+                   of a sequence is warm-started from frame t-1, frame 0 from the seeds -- the reference's semantics
+                   applied to many recordings), 6 legs each = 93,750 chains per GPU
+  --scaling strong config 3 literally: 1,000,000 frames IN TOTAL, rank r solves sequences [r S/N, (r+1) S/N)
+A step is one pass of the hot path (one launch in which every wave takes its chains through stages 1-4;
+`--staged`: the 4 stage kernels) over the rank's batch with inputs resident in HBM; consecutive steps overlap on
+`--streams` HIP streams.  For N > 1 every step also sends the rank's joint angles to rank 0 (copy-engine peer writes
+over xGMI into rank 0's IPC-exported buffers, an 8-byte RCCL all-reduce as completion flag; grouped RCCL
+point-to-point if the peer path is unavailable, or when SEQIK_GATHER=rccl; `config.gather` says which ran).
+
+Prints ONE JSON line on rank 0: `value` (pipeline throughput of the timed region), `roofline` (dominant kernel, live
+HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figures are kept beside it) and, at N = 1,
+  single_job         the same batch with ONE launch in flight at a time (no overlap between steps)
+  variants           the other synthetic variant (smooth <-> iid), same pipeline
+  single_recording   ONE recording of 1M frames x 6 legs (real locomotion poses repeated), walked as the reference
+                     walks a recording, by frame chunks (SeqikOptions.frame_chunk)
+  strong_projection  the per-rank share of the fixed 1M-frame problem at N = 2, 4, 8, timed on this GPU
+  parity             HIP vs the committed reference fixtures (shipped anipose outputs, df3d reference-source run):
+                     max |d theta|, leg-frames over 1e-4 rad and where, for the serial walk and for frame chunks
+  cpu_baseline       the C oracle on the host cores, bounded sample of the same workload (+ Python/scipy pool)
 """
 import argparse
 import json
@@ -40,12 +51,15 @@ import torch  # noqa: E402  (loads the HIP runtime that libseqik_hip.so binds to
 
 from seqikpy_amd import _lib, data, peer_gather, sharding, synthetic, utils  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TF = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes x 2 flop x 2.4 GHz
 # Algorithmic HBM bytes per leg-frame (DESIGN.md "Kernels"):
 BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
 BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 + 24, 4: 48 + 96 + 8 + 144}
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
+TRAFFIC_FILES = ("traffic_r02.json", "traffic_r01.json")  # newest first; used only if it matches the workload
+LF_WINDOW = (280, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
 def parse():
@@ -55,7 +69,9 @@ def parse():
     # edge still costs 5 % (20 steps 4.11e8, 400 steps 4.30e8, 1500 steps 4.31e8 solves/s)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=1_000_000, help="frames per GPU (x 6 legs)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --frames per GPU; strong: --frames in total, split over the ranks (BASELINE config 3 literally)")
+    ap.add_argument("--frames", type=int, default=1_000_000, help="frames (x 6 legs) per GPU (weak) or in total (strong)")
     ap.add_argument("--frames-per-seq", type=int, default=64)
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
     ap.add_argument("--block", type=int, default=0)
@@ -70,6 +86,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-python-baseline", action="store_true",
                     help="skip the Python + scipy process-pool leg of the CPU baseline (about 20 s)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip single_job / variants / single_recording / strong_projection / parity (profiling runs)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=8192,
                     help="sequences of the batch the CPU baseline solves (8192 x 6 x 64 = 3.1 M leg-frames: 10-20 s on 16 cores)")
     return ap.parse_args()
@@ -145,6 +163,142 @@ def cpu_baseline(pose, legs, body, n_seq_sample, python_pool=True):
     return out
 
 
+class Batch:
+    """One rank's batch resident in HBM (planar layout) + the launch of one step on a given stream."""
+
+    def __init__(self, pose, params, args, n_streams):
+        self.S, self.L, self.T = pose.shape[:3]
+        self.params, self.args = params, args
+        self.layout = _lib.planar_layout(self.T)
+        # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
+        self.d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+        self.main = torch.cuda.current_stream()
+        self.streams = [self.main] + [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
+        self.d_fks = [torch.zeros((self.S, self.L, self.T, 9, 3), dtype=torch.float64, device="cuda")
+                      for _ in self.streams]
+        self.units = self.S * self.L * self.T
+
+    def angle_buffer(self):
+        return torch.zeros((self.S, self.L, 7, self.T), dtype=torch.float64, device="cuda")
+
+    def launch(self, i, buf, events=None, n_streams=None):
+        k = i % (n_streams or len(self.streams))
+        stream = self.streams[k]
+        a = self.args
+        # ONE C-ABI call = the whole hot path; the library records the given HIP events around its kernels
+        _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.T, self.params, buf.data_ptr(),
+                              self.d_fks[k].data_ptr(), stream=stream.cuda_stream, block_size=a.block, layout=self.layout,
+                              lanes_per_wave=a.lanes_per_wave, staged=int(a.staged), interleave_legs=a.interleave_legs,
+                              stage_events=[e.cuda_event for e in events] if events else None)
+        return stream
+
+
+def timed_steps(batch, bufs, steps, n_streams, warmup=2):
+    """`steps` launches round-robin over `n_streams` streams; returns seconds (host clock around a full drain)."""
+    for i in range(warmup):
+        with torch.cuda.stream(batch.streams[i % n_streams]):
+            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(batch.streams[i % n_streams]):
+            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def single_recording(n_frames=1_000_000, steps=4):
+    """Config 3's size on ONE recording: 1M frames x 6 legs walked as the reference would walk them (frame t
+    warm-started from frame t-1 over the whole recording), solved by frame chunks with automatic parameters
+    (SeqikOptions.frame_chunk = -1).  The key points are the df3d locomotion recording of the fixtures (1000 frames
+    x 6 legs, tests/golden/df3d_1000.npz) repeated end to end: real, temporally continuous fly poses -- on the
+    synthetic random poses of the sequence benchmark the warm start selects among several equivalent leg
+    configurations, the run-in of a chunk often lands in another one than the serial walk, and most chunks have to be
+    repaired (DESIGN.md "Frame chunks", measured)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    L = len(legs)
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    base = np.stack([z[f"{l}_pose"] for l in legs])                  # (L, 1000, 5, 3)
+    reps = -(-n_frames // base.shape[1])
+    N = n_frames
+    rec = np.ascontiguousarray(np.tile(base, (1, reps, 1, 1))[:, :N].transpose(0, 2, 1, 3))  # [L][5][N][3] planar
+    d_pose = torch.from_numpy(rec).cuda()
+    d_ang = torch.zeros((1, L, 7, N), dtype=torch.float64, device="cuda")
+    d_fk = torch.zeros((1, L, N, 9, 3), dtype=torch.float64, device="cuda")
+    d_stats = torch.zeros(8, dtype=torch.int32, device="cuda")
+    layout = _lib.planar_layout(N)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        _lib.solve_seq_device(d_pose.data_ptr(), 1, L, N, params, d_ang.data_ptr(), d_fk.data_ptr(), stream=stream,
+                              layout=layout, frame_chunk=-1, d_chunk_stats=d_stats.data_ptr())
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    stats = _lib.chunk_stats_dict(d_stats.cpu().numpy())
+    # the first 2000 frames walked serially (bit-exact restatement): chunk 0 must reproduce that walk bit for bit,
+    # the other chunks to the noise floor of the verification tolerance; and against the fixture's reference angles
+    n_head = min(N, 2000)
+    h_pose = torch.from_numpy(np.ascontiguousarray(rec[:, :, :n_head])).cuda()
+    h_ang = torch.zeros((1, L, 7, n_head), dtype=torch.float64, device="cuda")
+    _lib.solve_seq_device(h_pose.data_ptr(), 1, L, n_head, params, h_ang.data_ptr(), 0, stream=stream,
+                          layout=_lib.planar_layout(n_head))
+    torch.cuda.synchronize()
+    c = max(stats["frames_per_chunk"], 1)
+    diff = (d_ang[0, :, :, :n_head] - h_ang[0]).abs()
+    ref = torch.from_numpy(np.stack([z[f"{l}_angles"] for l in legs]).transpose(0, 2, 1)).cuda()  # (L, 7, 1000)
+    n_ref = min(N, 1000)
+    out = {"value": L * N / dt, "unit": "leg-frame solves/s", "ms_per_step": dt * 1e3, "frames": N, "legs": L,
+           "data": "df3d locomotion recording (fixture, 1000 frames x 6 legs) repeated end to end",
+           "mode": "frame chunks, automatic parameters (SeqikOptions.frame_chunk = -1), 7 angles + FK",
+           "chunk_stats": stats,
+           "check": {"frames_walked_serially": n_head,
+                     "first_chunk_equals_serial_bit_for_bit": bool((diff[:, :, :c] == 0).all().item()),
+                     "max_abs_vs_serial": float(diff.max().item()),
+                     "leg_frames_over_1e-4_vs_serial": int((diff.amax(1) > 1e-4).sum().item()),
+                     "max_abs_vs_reference_first_1000_frames": float((d_ang[0, :, :, :n_ref] - ref[:, :, :n_ref]).abs().max().item())}}
+    del d_pose, d_ang, d_fk, h_pose, h_ang
+    return out
+
+
+def parity_report():
+    """HIP vs the committed reference fixtures, on the GPU, fixtures only (no oracle involved): the shipped anipose
+    outputs (reference's leg_joint_angles.pkl, RF + LF x 6000 frames) and the df3d recording solved by the
+    reference's unmodified source over real scipy in the build container (6 legs x 1000 frames)."""
+    rep = {"tolerance_rad": 1e-4,
+           "lf_window": "anipose LF frames %d-%d: kinematic-singularity episode, the reference itself is not "
+                        "reproducible there (tests/conftest.py::LF_DEGENERATE, profiles/r02_perturbation_report.json)" % (LF_WINDOW[0], LF_WINDOW[1] - 1)}
+    for name in ("anipose_shipped", "df3d_1000"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+        legs = [str(l) for l in z["legs"]]
+        params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+        pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+        ref = np.stack([z[f"{l}_angles"] for l in legs])
+        ok = np.ones(ref.shape[:2], bool)
+        if name == "anipose_shipped":
+            ok[legs.index("LF"), LF_WINDOW[0]:LF_WINDOW[1]] = False
+        entry = {"legs": legs, "frames": int(pose.shape[2])}
+        for mode, kw in (("serial_walk", {}), ("frame_chunks", dict(frame_chunk=-1))):
+            out = _lib.solve_seq(pose, params, want_fk=False, **kw)
+            err = np.abs(out["angles"][0] - ref)              # (L, N, 7)
+            bad = np.argwhere(err.max(-1) > 1e-4)
+            entry[mode] = {"max_abs_dtheta": float(err[ok].max()),
+                           "max_abs_dtheta_incl_lf_window": float(err.max()),
+                           "leg_frames_over_1e-4": int(len(bad)),
+                           "leg_frames_over_1e-4_outside_lf_window": int(sum(ok[i, t] for i, t in bad)),
+                           "where": [[legs[i], int(t)] for i, t in bad[:32]],
+                           "median_abs_dtheta": float(np.median(err))}
+            if kw:
+                entry[mode]["chunk_stats"] = {k: v for k, v in out["chunk_stats"].items() if v}
+        rep[name] = entry
+    return rep
+
+
 def main():
     args = parse()
     # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when its communicator
@@ -181,23 +335,26 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     T = args.frames_per_seq
-    S = args.frames // T
-    legs, body, pose, params = make_workload(S, T, args.variant, synthetic.SEED_BASE + 1000 * rank)
+    S_total = args.frames // T
+    lo, hi, S_job = sharding.rank_share(S_total, world, rank, args.scaling)
+    if args.scaling == "strong":
+        # the fixed problem: S_total sequences, generated identically on every rank, rank r solves its slice
+        legs, body, pose_all, params = make_workload(S_total, T, args.variant, synthetic.SEED_BASE)
+        pose = pose_all[lo:hi]
+        del pose_all
+    else:
+        legs, body, pose, params = make_workload(S_total, T, args.variant, synthetic.SEED_BASE + 1000 * rank)
+    S = pose.shape[0]
     L = len(legs)
-    units_per_step = S * L * T  # leg-frames per GPU per step
-
-    # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
-    layout = _lib.planar_layout(T)
-    d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
-    d_fk = torch.zeros((S, L, T, 9, 3), dtype=torch.float64, device="cuda")
-    main_stream = torch.cuda.current_stream()
-    streams = [main_stream] + [torch.cuda.Stream() for _ in range(max(0, args.streams - 1))]
+    batch = Batch(pose, params, args, args.streams)
+    units_per_step = batch.units  # leg-frames per step on this rank
+    units_all = S_job * L * T  # leg-frames per step over all ranks
+    streams = batch.streams
+    main_stream = batch.main
     # angle buffers: one per batch in flight + two spare, so that a gather that is still draining (it only gets
     # CU slots as solver waves retire) does not hold back the launch that wants to reuse its buffer
-    n_buf = len(streams) + (2 if use_dist else 0)
-    n_buf = max(2, n_buf)
-    d_ang = [torch.zeros((S, L, 7, T), dtype=torch.float64, device="cuda") for _ in range(n_buf)]
-    d_fks = [d_fk] + [torch.zeros_like(d_fk) for _ in range(len(streams) - 1)]
+    n_buf = max(2, len(streams) + (2 if use_dist else 0))
+    d_ang = [batch.angle_buffer() for _ in range(n_buf)]
     # final joint-angle gather: peer writes over xGMI when every rank can map rank 0's buffers and the copies are
     # not pathologically slow (a block needs 336 MB / 14 ms = 24 GB/s per link to keep up; a link that cannot do
     # that is no faster under RCCL, and the peer writes at least leave the root's compute units alone), grouped
@@ -212,18 +369,12 @@ def main():
 
     def step(i, events=None):
         b = i % n_buf
-        buf = d_ang[b]
-        stream = streams[i % len(streams)]
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(streams[i % len(streams)]):
             if gather:
                 gather.wait_buffer(b)  # the gather that last read this buffer has completed
-            # ONE C-ABI call = the four stage kernels; the library records the given HIP events between them
-            _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, buf.data_ptr(),
-                                  d_fks[i % len(streams)].data_ptr(), stream=stream.cuda_stream,
-                                  block_size=args.block, layout=layout, lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs,
-                                  stage_events=[e.cuda_event for e in events] if events else None)
+            batch.launch(i, d_ang[b], events)
             if gather:
-                gather.submit(b, buf)
+                gather.submit(b, d_ang[b])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -251,90 +402,150 @@ def main():
     # Outside the timed region: every buffer the overlapped launches wrote must hold, bit for bit, what one launch
     # made alone writes (all steps solve the same batch) -- a measurement of launches that disturbed each other
     # would be worthless.
-    chk_ang, chk_fk = torch.zeros_like(d_ang[0]), torch.zeros_like(d_fk)
-    _lib.solve_seq_device(d_pose.data_ptr(), S, L, T, params, chk_ang.data_ptr(), chk_fk.data_ptr(),
-                          stream=main_stream.cuda_stream, block_size=args.block, layout=layout,
+    chk_ang, chk_fk = torch.zeros_like(d_ang[0]), torch.zeros_like(batch.d_fks[0])
+    _lib.solve_seq_device(batch.d_pose.data_ptr(), S, L, T, params, chk_ang.data_ptr(), chk_fk.data_ptr(),
+                          stream=main_stream.cuda_stream, block_size=args.block, layout=batch.layout,
                           lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs)
     torch.cuda.synchronize()
     used = range(min(n_buf, args.steps + args.warmup))
     if not all(torch.equal(d_ang[b], chk_ang) for b in used) or \
-            not all(torch.equal(f, chk_fk) for f in d_fks[:min(len(d_fks), args.steps + args.warmup)]):
+            not all(torch.equal(f, chk_fk) for f in batch.d_fks[:min(len(batch.d_fks), args.steps + args.warmup)]):
         raise SystemExit("bench: overlapped launches did not reproduce a launch made alone -- result invalid")
     del chk_ang, chk_fk
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
     stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(args.steps)])
     mean_stage_ms = stage_ms.mean(0)
+    ms_per_step = elapsed / args.steps * 1e3
     if args.staged:
         dom = int(np.argmax(mean_stage_ms)) + 1
         kname, key, bytes_unit, dom_ms = f"seqik_stage_kernel<{dom}, ...>", f"stage{dom}", BYTES_STAGE[dom], float(mean_stage_ms[dom - 1])
     else:  # one kernel per step: event [0] is recorded in front of it, [1] behind it
         kname, key, bytes_unit, dom_ms = "seqik_fused_kernel<true>", "fused", BYTES_PATH, float(mean_stage_ms[0])
-    ach = bytes_unit * units_per_step / (dom_ms * 1e-3) / 1e9
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01_staged.json" if args.staged else "traffic_r01.json")
-    if os.path.exists(tpath):
+    ach_gbs = bytes_unit * units_per_step / (dom_ms * 1e-3) / 1e9
+    traffic, valu, fp64 = None, None, None
+    for fn in TRAFFIC_FILES:
+        tpath = os.path.join(ROOT, "profiles", fn.replace(".json", "_staged.json") if args.staged else fn)
+        if not os.path.exists(tpath):
+            continue
         tj = json.load(open(tpath))
-        if tj.get("units_per_launch") == units_per_step and tj.get("variant") == args.variant:
-            traffic = tj.get(f"{key}_hbm_bytes_per_launch")
-            names = [f"stage{k}" for k in (1, 2, 3, 4)] if args.staged else ["fused"]
-            insts = [tj.get(f"{n}_valu_insts_per_launch") for n in names]
-            if all(v is not None for v in insts):
-                # What actually bounds the path: VALU issue.  A wave64 VALU instruction occupies its SIMD's 16
-                # f64 lanes for >= 4 cycles (f64 FMA/MUL/ADD: exactly 4; rcp/rsq seeds: more), so the step cannot
-                # be shorter than  instructions x 4 / (SIMDs x clock).
-                n_cu, clock_khz, _ = _lib.device_attributes(device_index)
-                simds, clock_hz = n_cu * 4, clock_khz * 1e3
-                floor_ms = sum(insts) * 4.0 / (simds * clock_hz) * 1e3
-                valu = {"valu_insts_per_step": sum(insts), "simds": simds, "clock_MHz": clock_khz / 1e3,
-                        "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": elapsed / args.steps * 1e3,
-                        "frac_of_valu_issue_peak": floor_ms / (elapsed / args.steps * 1e3),
-                        "lane_utilisation": [tj.get(f"{n}_valu_lane_utilisation") for n in names],
-                        "source": "SQ_INSTS_VALU / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch from "
-                                  f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc), timing live"}
-                mix = {c: [tj.get(f"{n}_f64_{c}_insts_per_launch") for n in names] for c in ("add", "mul", "fma", "trans")}
-                utils_ = valu["lane_utilisation"]
-                if all(v is not None for vs in mix.values() for v in vs) and all(u is not None for u in utils_):
-                    # FP64 operations actually performed: wave-level instruction counts by class x 64 lanes x the
-                    # share of active lanes (FMA = 2 flops), against the 78.6 TFLOP/s FP64 vector peak
-                    flops = sum((mix["add"][i] + mix["mul"][i] + mix["trans"][i] + 2.0 * mix["fma"][i]) * 64.0 * utils_[i]
-                                for i in range(len(names)))
-                    tfl = flops / (elapsed / args.steps) / 1e12
-                    peak = simds * 16 * 2 * clock_hz / 1e12
-                    valu["fp64"] = {"f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
-                                    "thread_level_TFLOPs": tfl, "vector_peak_TFLOPs": peak, "frac": tfl / peak,
-                                    "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_unit": bytes_unit, "avg_launch_ms": dom_ms,
-                "valu": valu,
-                "note": "FP64-VALU-issue-bound solver: ~1e4 f64 instructions per 392 B; HBM fraction << 1% by "
-                        "construction (SURVEY 8d); `valu` is the roofline that binds"}
+        if tj.get("units_per_launch") != units_per_step or tj.get("variant") != args.variant:
+            continue
+        traffic = tj.get(f"{key}_hbm_bytes_per_launch")
+        names = [f"stage{k}" for k in (1, 2, 3, 4)] if args.staged else ["fused"]
+        insts = [tj.get(f"{n}_valu_insts_per_launch") for n in names]
+        mix = {c: [tj.get(f"{n}_f64_{c}_insts_per_launch") for n in names] for c in ("add", "mul", "fma", "trans")}
+        utils_ = [tj.get(f"{n}_valu_lane_utilisation") for n in names]
+        if all(v is not None for v in insts) and all(v is not None for vs in mix.values() for v in vs):
+            # What actually bounds the path: VALU issue.  A wave64 FP64 instruction occupies its SIMD's 16 f64 lanes
+            # for 4 cycles; every other VALU instruction (selects, compares, moves, 64-bit address arithmetic) takes
+            # 2 cycles on the SIMD-32 when several waves share a SIMD (MI355X_MICROARCH.md, "Execution model" and the
+            # cycle-constants row `v_fma_f32` wave64).  The quarter-rate rcp / rsq / sqrt seeds are priced like the
+            # other f64 instructions, so this is a FLOOR: the step cannot be shorter than
+            #     (f64 instructions x 4 + other VALU instructions x 2) / (SIMDs x clock).
+            n_cu, clock_khz, _ = _lib.device_attributes(device_index)
+            simds, clock_hz = n_cu * 4, clock_khz * 1e3
+            n_f64 = sum(sum(vs) for vs in mix.values())
+            n_all = sum(insts)
+            floor_ms = (n_f64 * 4.0 + (n_all - n_f64) * 2.0) / (simds * clock_hz) * 1e3
+            valu = {"valu_insts_per_step": n_all, "f64_insts_per_step": n_f64, "simds": simds, "clock_MHz": clock_khz / 1e3,
+                    "cycles_per_inst": {"f64": 4, "other": 2},
+                    "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": ms_per_step,
+                    "frac_of_valu_issue_floor": floor_ms / ms_per_step,
+                    "lane_utilisation": utils_,
+                    "source": "SQ_INSTS_VALU / SQ_INSTS_VALU_*_F64 / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch "
+                              f"from profiles/{os.path.basename(tpath)} (rocprofv3 --pmc, own passes), timing live"}
+            if all(u is not None for u in utils_):
+                # FP64 operations actually performed: wave-level instruction counts by class x 64 lanes x the
+                # share of active lanes (FMA = 2 flops), against the 78.6 TFLOP/s FP64 vector peak
+                flops = sum((mix["add"][i] + mix["mul"][i] + mix["trans"][i] + 2.0 * mix["fma"][i]) * 64.0 * utils_[i]
+                            for i in range(len(names)))
+                fp64 = {"flops_per_step": flops, "f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
+                        "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
+        break
+    hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+           "bytes_per_unit": bytes_unit,
+           "note": "algorithmic bytes x units per launch / the kernel's average launch duration (launches of "
+                   f"{len(streams)} steps overlap, so a launch lasts ~{len(streams)}x a step); HBM is not what binds: "
+                   "~1e4 f64 instructions per 392 B"}
+    if fp64:
+        tfl = fp64["flops_per_step"] / (ms_per_step * 1e-3) / 1e12
+        roofline = {"bound": "valu-fp64", "kernel": kname, "achieved": tfl, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": tfl / FP64_VECTOR_PEAK_TF, "traffic": traffic, "avg_launch_ms": dom_ms,
+                    "fp64": fp64, "valu_issue": valu, "hbm": hbm,
+                    "note": "the path is bound by FP64 VALU issue, not by HBM or MFMA: `achieved` = FP64 operations "
+                            "actually performed by active lanes per second (PMC instruction mix x lane share, live "
+                            "timing) against the vector FP64 peak; `valu_issue` = how close the step is to the floor its "
+                            "wave-instruction count allows; `hbm` = the algorithmic-bytes figure"}
+    else:  # no matching PMC summary for this workload: only the HBM figure can be stated
+        roofline = {"bound": "hbm", "kernel": kname, **hbm, "traffic": traffic, "avg_launch_ms": dom_ms,
+                    "note": hbm["note"] + " (no PMC summary under profiles/ matches this workload, so the VALU figures are absent)"}
     if args.staged:
         roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
         roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
 
     if rank == 0:
-        total_units = units_per_step * world * args.steps
         out = {
-            "metric": "leg-IK solves/s (frames x 6 legs)",
-            "value": total_units / elapsed,
+            "metric": "leg-IK solves/s (frames x 6 legs); max |d theta| vs reference in `parity`",
+            "value": units_all * args.steps / elapsed,
             "unit": "leg-frame solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "config 3: synthetic 1M frames x 6 legs per GPU, in-workspace targets",
+            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs per GPU, in-workspace targets" if args.scaling == "weak"
+                                    else "config 3: synthetic 1M frames x 6 legs IN TOTAL, sequences split over the ranks"),
                        "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
                        "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
-                       "streams": len(streams), "launches_per_step": 4 if args.staged else 1,
+                       "streams": len(streams),
+                       "pipeline": f"{len(streams)} independent batches in flight (consecutive steps overlap); "
+                                   "`single_job` is one launch at a time",
+                       "launches_per_step": 4 if args.staged else 1,
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
                        **({"gather": gather_how} if gather_how else {})},
             "roofline": roofline,
             "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
                         "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
         }
+        if world == 1 and not args.no_extras:
+            # ---- one launch at a time --------------------------------------------------------------------------
+            n1 = max(4, min(16, args.steps // 6))
+            dt1 = timed_steps(batch, d_ang, n1, 1)
+            out["single_job"] = {"value": units_per_step * n1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / n1 * 1e3,
+                                 "steps": n1, "streams": 1,
+                                 "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
+                                         "FP64 latency; `value` above is the pipelined rate"}
+            # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU ----------------------
+            proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU with the same pipeline; "
+                            "no gather; projected_value = 6M leg-frames / that time", "by_n_gpus": {}}
+            for n in (2, 4, 8):
+                sub = Batch(pose[: S // n], params, args, args.streams)
+                bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
+                k = max(12, min(60, args.steps // 2))
+                dt = timed_steps(sub, bufs, k, len(sub.streams))
+                proj["by_n_gpus"][str(n)] = {"ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                                             "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
+                del sub, bufs
+            out["strong_projection"] = proj
+            # ---- the other synthetic variant -------------------------------------------------------------------
+            other = "smooth" if args.variant == "iid" else "iid"
+            _, _, pose_o, _ = make_workload(S, T, other, synthetic.SEED_BASE)
+            bo = Batch(pose_o, params, args, args.streams)
+            ko = max(12, min(40, args.steps // 2))
+            dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=3)
+            out["variants"] = {other: {"value": bo.units * ko / dto, "unit": "leg-frame solves/s", "ms_per_step": dto / ko * 1e3,
+                                       "steps": ko, "streams": len(bo.streams)},
+                               "note": "smooth = temporally continuous targets (band-limited random walk): the realistic "
+                                       "case; iid = every frame an unrelated pose"}
+            del bo
+            # ---- config 3 as ONE recording (frame chunks) ------------------------------------------------------
+            del d_ang[1:]
+            torch.cuda.empty_cache()
+            del pose_o
+            out["single_recording"] = single_recording(args.frames)
+            # ---- parity vs the committed reference fixtures ----------------------------------------------------
+            out["parity"] = parity_report()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -127,9 +127,15 @@ LegOrder make_leg_order(const SeqikLegParams *legs, int32_t n_legs)
 // wave; but every wave -- however thin -- occupies its SIMD's issue slots for the whole pass, and a thousand thin
 // waves on all CUs run slower than the same chains in a hundred full waves on a few CUs (consistent with a
 // power-limited clock), so from about a thousand chains on full waves win.
-int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt)
+// Frame chunks (chunked = true) are short (12-72 frames), so a call is over before the power / issue argument for full
+// waves applies: measured on the shipped recordings (scripts/latency_lanes.py, profiles/r02_latency_lanes.jsonl) the
+// wall-clock is flat within ~10 % around  chunks / 256  lanes per wave up to several thousand chunks
+// (1 500 chunks: W = 1 4.4, 3 3.8, 8 3.9, 64 5.0 ms; 3 000 chunks: W = 1 4.0, 6-16 3.6, 64 4.0 ms), so the thin-wave rule
+// simply continues until it reaches full waves at 16 384 chunks.
+int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt, bool chunked = false)
 {
     if (opt && opt->reserved[0] >= 1 && opt->reserved[0] <= 64) return opt->reserved[0];
+    if (chunked && n_chains < 16384) return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);
     if (n_chains >= 1024) return 64;
     return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);  // <= 256 thin waves of 1-4 lanes
 }
@@ -340,12 +346,16 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
     const int64_t wave = g >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t K = ca.n_chunks, C = ca.chunk, N = a.n_frames;
-    const int W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
+    int64_t W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
 
     int64_t cursor = 0, n_items = 0;
     bool spec_done = false;
     if (mode == CHUNK_REPAIR) {
         n_items = ca.ctrl[ca.round].count;
+        // the listed chunks are spread over the waves of the grid as thinly as possible (a handful of repairs run one
+        // per wave: a pass of a wave costs the union of the code paths its lanes take)
+        W = (n_items + n_waves - 1) / n_waves;
+        W = W < 1 ? 1 : (W > 64 ? 64 : W);
         cursor = (lane < W) ? wave * W + lane : n_items;
     } else if (mode == CHUNK_SWEEP) {
         if (ca.ctrl[ca.round].pending == 0 || wave >= a.n_chains) return;
@@ -778,7 +788,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
                          pick_frame_chunks(opt, a.n_chains, n_frames, chunk, halo, n_chunks);
     const int64_t n_vchains = a.n_chains * n_chunks;  // virtual chains = chunks (= chains when not chunked)
     if (n_vchains > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many frame chunks for one launch%s");
-    a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt);
+    a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked);
     int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
     if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
         n_waves = (n_vchains + a.lanes_per_wave - 1) / a.lanes_per_wave;

@@ -16,6 +16,20 @@ def partition(n_units: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def rank_share(n_seq: int, world_size: int, rank: int, scaling: str) -> Tuple[int, int, int]:
+    """Sequences a rank solves in the benchmark's two scaling modes: ``(start, stop, total)``.
+
+    ``"weak"``: every rank has ``n_seq`` sequences of its own (the job grows with the number of GPUs);
+    ``"strong"``: the problem is fixed at ``n_seq`` sequences (BASELINE config 3: "1M frames x 6 legs ... 1->8 MI355X
+    frame-sharded") and rank r solves the contiguous slice ``partition(n_seq, world_size, r)``."""
+    if scaling == "weak":
+        return rank * n_seq, (rank + 1) * n_seq, n_seq * world_size
+    if scaling == "strong":
+        a, b = partition(n_seq, world_size, rank)
+        return a, b, n_seq
+    raise ValueError("scaling must be 'weak' or 'strong'")
+
+
 def all_gather_rows(local, counts: List[int], group=None):
     """All-gathers tensors that differ only in dim 0 (``counts[r]`` rows on rank r) into one tensor
     on every rank: a single padded ``all_gather_into_tensor``-style collective."""

@@ -268,3 +268,79 @@ def test_peer_write_gather_between_processes(tmp_path):
     seen = np.load(tmp_path / "seen.npy")
     want = np.array([[100.0 * s + r for r in range(world)] * 2 for s in range(7)])
     assert np.array_equal(seen, want)
+
+
+def _strong_worker(rank, world, port, out_dir):
+    """bench.py --scaling strong, dry run: the fixed problem's slice per rank (sharding.rank_share), solved (oracle as
+    the solver), gathered to rank 0; the pieces must tile the fixed problem exactly."""
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from oracle import c_oracle
+    from seqikpy_amd import data, sharding, synthetic, utils
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    legs = data.LEGS[:2]
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    S_total, T = 7, 6
+    pose = synthetic.synthetic_pose(S_total, T, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                    variant="smooth", seed=synthetic.SEED_BASE)  # identical on every rank
+    lo, hi, total = sharding.rank_share(S_total, world, rank, "strong")
+    par = [c_oracle.leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
+
+    def solve(p):
+        out = np.zeros(p.shape[:3] + (7,))
+        for s in range(p.shape[0]):
+            for li in range(len(legs)):
+                out[s, li] = c_oracle.seq_leg(p[s, li], *par[li], want_fk=False)["angles"]
+        return out
+
+    mine = torch.from_numpy(solve(pose[lo:hi]))
+    counts = [sharding.rank_share(S_total, world, r, "strong") for r in range(world)]
+    allr = sharding.all_gather_rows(mine, [b - a for a, b, _ in counts])
+    units = torch.tensor([(hi - lo) * len(legs) * T])
+    dist.all_reduce(units)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), allr.numpy())
+        np.save(os.path.join(out_dir, "single.npy"), solve(pose))
+        np.save(os.path.join(out_dir, "units.npy"), np.array([int(units.item()), total * len(legs) * T]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_strong_scaling_shares_tile_the_fixed_problem(tmp_path, world):
+    from seqikpy_amd.sharding import rank_share
+    assert [rank_share(10, 4, r, "weak") for r in range(4)] == [(0, 10, 40), (10, 20, 40), (20, 30, 40), (30, 40, 40)]
+    assert [rank_share(10, 4, r, "strong")[:2] for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        rank_share(10, 2, 0, "sideways")
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert np.array_equal(np.load(tmp_path / "gathered.npy"), np.load(tmp_path / "single.npy"))
+    u = np.load(tmp_path / "units.npy")
+    assert u[0] == u[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
+    """The real bench.py under torch.distributed.run with two ranks sharing the box's GPU (gloo as the process-group
+    backend): --scaling strong splits the fixed problem, the line says so."""
+    import json
+    import subprocess
+    env = dict(os.environ, SEQIK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(34500 + os.getpid() % 1000), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--scaling", "strong", "--frames", "8192", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    assert b["scaling"] == "strong" and b["n_gpus"] == 2
+    assert b["config"]["sequences_per_gpu"] == 64 and b["config"]["frames_per_gpu"] == 4096
+    assert abs(b["value"] - 8192 * 6 * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) < 1e-6 * b["value"]

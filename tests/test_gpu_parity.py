@@ -153,7 +153,7 @@ def test_python_stagewise_api_and_per_frame_seam(lib):
     pose = z["RF_pose"][:60]
     kc = KinematicChainSeq(BOUNDS, ["RF"])
     ik = LegInvKinSeq({"RF_leg": pose}, kc, INITIAL_ANGLES, log_level="ERROR")
-    full_ang, full_fk = ik.run_ik_and_fk()
+    full_ang, full_fk = ik.run_ik_and_fk(frame_parallel=False)
     full_ang = {k: v.copy() for k, v in full_ang.items()}
     ik2 = LegInvKinSeq({"RF_leg": pose}, kc, INITIAL_ANGLES, log_level="ERROR")
     for stage in (1, 2, 3, 4):
@@ -332,7 +332,7 @@ def test_many_recordings_of_different_length_in_one_call(lib):
     kc = KinematicChainSeq(data.BOUNDS_LOCOMOTION, legs, calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs))
     cuts = [(0, 100), (300, 357), (500, 600), (900, 908)]
     recs = [{f"{l}_leg": z[f"{l}_pose"][a:b] for l in legs} | {"Neck": np.zeros((1, 1, 3))} for a, b in cuts]
-    single = [LegInvKinSeq(r, kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR").run_ik_and_fk() for r in recs]
+    single = [LegInvKinSeq(r, kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR").run_ik_and_fk(frame_parallel=False) for r in recs]
     for pad in (0, 64):
         many = run_ik_and_fk_many(recs, kc, data.INITIAL_ANGLES_LOCOMOTION, pad_to_multiple=pad)
         assert len(many) == len(recs)
