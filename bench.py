@@ -407,9 +407,9 @@ def main():
                           stream=main_stream.cuda_stream, block_size=args.block, layout=batch.layout,
                           lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs)
     torch.cuda.synchronize()
-    used = range(min(n_buf, args.steps + args.warmup))
-    if not all(torch.equal(d_ang[b], chk_ang) for b in used) or \
-            not all(torch.equal(f, chk_fk) for f in batch.d_fks[:min(len(batch.d_fks), args.steps + args.warmup)]):
+    n_used = max(args.steps, args.warmup)  # warm-up and timed steps both count from 0
+    if not all(torch.equal(d_ang[b], chk_ang) for b in range(min(n_buf, n_used))) or \
+            not all(torch.equal(f, chk_fk) for f in batch.d_fks[:min(len(batch.d_fks), n_used)]):
         raise SystemExit("bench: overlapped launches did not reproduce a launch made alone -- result invalid")
     del chk_ang, chk_fk
 

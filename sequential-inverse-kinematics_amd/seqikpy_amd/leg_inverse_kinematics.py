@@ -79,8 +79,10 @@ class LegInvKinBase(ABC):
         One single-frame, single-stage launch of the HIP solver (the batched entry points are
         the fast path; this seam exists for API compatibility)."""
         spec = kinematic_chain.spec
+        if spec.get("kind") == "generic":
+            return self._calculate_ik_generic(kinematic_chain, target_pos, initial_angles)
         if spec.get("kind") != "seq":
-            raise NotImplementedError("calculate_ik is implemented for KinematicChainSeq chains")
+            raise ValueError("calculate_ik needs a chain made by KinematicChainSeq / KinematicChainGeneric")
         stage, leg, factory = spec["stage"], spec["leg"], spec["factory"]
         n = STAGE_LINKS[stage]
         x0 = np.zeros(n) if initial_angles is None else np.asarray(initial_angles, dtype=np.float64)
@@ -107,6 +109,34 @@ class LegInvKinBase(ABC):
         names = [l.name for l in kinematic_chain.links]
         for dof in STAGE_DOFS[stage]:
             res[names.index(f"{leg}_{dof}")] = out["angles"][0, 0, 0, DOFS.index(dof)]
+        return res
+
+    def _calculate_ik_generic(self, kinematic_chain: Chain, target_pos, initial_angles) -> np.ndarray:
+        """Per-frame seam for the 9-link generic chain (reference :62-69 works with any chain): one single-frame
+        launch of ``seqik_solve_generic``; returns the 9 link variables (base and claw keep their start values, made
+        strictly feasible as scipy does)."""
+        spec = kinematic_chain.spec
+        leg, factory = spec["leg"], spec["factory"]
+        x0 = np.zeros(9) if initial_angles is None else np.asarray(initial_angles, dtype=np.float64)
+        if x0.shape != (9,):
+            raise ValueError(f"Your joints vector length is {x0.size} but you have 9 links")
+        seeds = {leg: {f"stage_{k}": np.zeros(STAGE_LINKS[k]) for k in (1, 2, 3)}}
+        seeds[leg]["stage_4"] = x0
+        lp = _lib.make_leg_params(leg, factory.bounds_dof, factory.body_size, seeds)
+        pose = np.zeros((1, 1, 1, 5, 3))
+        pose[0, 0, 0, 4] = np.asarray(target_pos, dtype=np.float64)
+        out = _lib.solve_generic(pose, [lp], want_fk=False, device=self.device)
+        res = x0.copy()
+        lo = np.array([l.bounds[0] for l in kinematic_chain.links])
+        hi = np.array([l.bounds[1] for l in kinematic_chain.links])
+        with np.errstate(invalid="ignore"):  # the base link is unbounded (-inf, inf)
+            near_lo = np.isfinite(lo) & (res - lo <= np.minimum(hi - res, 1e-10 * np.maximum(1, np.abs(lo))))
+            near_hi = np.isfinite(hi) & (hi - res <= np.minimum(res - lo, 1e-10 * np.maximum(1, np.abs(hi))))
+            res[near_lo] = (lo + 1e-10 * np.maximum(1, np.abs(lo)))[near_lo]
+            res[near_hi] = (hi - 1e-10 * np.maximum(1, np.abs(hi)))[near_hi]
+        names = [l.name for l in kinematic_chain.links]
+        for d, dof in enumerate(DOFS):
+            res[names.index(f"{leg}_{dof}")] = out["angles"][0, 0, 0, d]
         return res
 
     def calculate_fk(self, kinematic_chain: Chain, joint_angles: np.ndarray) -> np.ndarray:

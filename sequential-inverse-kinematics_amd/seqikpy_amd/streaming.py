@@ -19,30 +19,33 @@ import numpy as np
 from . import _lib
 
 
+def pinned_array(shape) -> np.ndarray:
+    """A float64 numpy array over pinned (page-locked) host memory from ``seqik_host_alloc``.  The memory belongs to
+    the array: it is returned to the driver when the array AND every view of it have been garbage collected (a
+    finalizer on the buffer object all of them keep alive), so an expression like ``pinned_array(shape)[:n]`` or an
+    array handed to ``SeqikStream.submit`` can never outlive its memory."""
+    import weakref
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape))
+    lib = _lib.load()
+    ptr = lib.seqik_host_alloc(max(n, 1) * 8)
+    if not ptr:
+        _lib._raise(_lib.ERR_HIP)
+    buf = (ctypes.c_double * max(n, 1)).from_address(ptr)
+    weakref.finalize(buf, lib.seqik_host_free, ctypes.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=np.float64, count=n).reshape(shape)
+
+
 class PinnedArray:
-    """A float64 numpy array over pinned (page-locked) host memory from ``seqik_host_alloc``."""
+    """Holder of a ``pinned_array`` (kept for callers that want an explicit handle).  ``.array`` is safe to keep after
+    the holder is gone; ``free()`` drops the holder's reference only -- the memory goes when the last view does."""
 
     def __init__(self, shape):
         self.shape = tuple(int(v) for v in shape)
-        n = int(np.prod(self.shape))
-        self._lib = _lib.load()
-        self._ptr = self._lib.seqik_host_alloc(max(n, 1) * 8)
-        if not self._ptr:
-            _lib._raise(_lib.ERR_HIP)
-        buf = (ctypes.c_double * max(n, 1)).from_address(self._ptr)
-        self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.shape)
+        self.array = pinned_array(self.shape)
 
     def free(self):
-        if self._ptr:
-            self.array = None
-            self._lib.seqik_host_free(ctypes.c_void_p(self._ptr))
-            self._ptr = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+        self.array = None
 
 
 class SeqikStream:

@@ -68,6 +68,16 @@ def test_generic_on_gpu(hiplib, oracle):
     order = ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
     assert list(ang.keys()) == [f"Angle_{l}_{d}" for l in legs for d in order]
     assert np.array_equal(np.stack([ang[f"Angle_RF_{d}"] for d in DOFS], 1), out["angles"][0, 0])
-    assert fk["LF_leg"].shape == (100, 9, 3) and np.abs(fk["LF_leg"][:, 8] - z["LF_pose"][:, 4]).max() < 1e-6
+    # the claw of the reference's own LegInvKinGeneric run (fixture: reference source over real scipy), not just the target
+    for leg in legs:
+        assert fk[f"{leg}_leg"].shape == (100, 9, 3)
+        assert np.abs(fk[f"{leg}_leg"][:, 8] - z[f"{leg}_fk"][:, 8]).max() < 1e-6
+        assert np.abs(fk[f"{leg}_leg"][:, 8] - z[f"{leg}_pose"][:, 4]).max() < 1e-6
+    # per-frame seam with a generic chain (reference :62-69 accepts any chain)
+    chain = KinematicChainGeneric(BOUNDS, legs).create_leg_chain("RF")
+    x = ik.calculate_ik(chain, z["RF_pose"][0, 4] - z["RF_pose"][0, 0], INITIAL_ANGLES["RF"]["stage_4"])
+    names = [l.name for l in chain.links]
+    assert x.shape == (9,) and all(x[names.index(f"RF_{d}")] == out["angles"][0, 0, 0, i] for i, d in enumerate(DOFS))
+    assert np.abs(ik.calculate_fk(chain, x)[8] - (z["RF_pose"][0, 4] - z["RF_pose"][0, 0])).max() < 1e-6
     fk1 = ik.calculate_ik_stage(z["RF_pose"][:, 4], z["RF_pose"][:, 0], INITIAL_ANGLES["RF"]["stage_4"], "RF")
     assert np.array_equal(fk1, fk["RF_leg"])

@@ -453,3 +453,40 @@ def test_more_streams_than_remembered_workspaces(lib):
     torch.cuda.synchronize()
     assert all(np.array_equal(o.cpu().numpy(), alone) for o in outs)
     lib.release_workspaces()
+
+
+def test_host_calls_do_not_strand_device_memory(lib):
+    """host-buffer calls reuse one pooled context (stream + arena + hand-off workspace) instead of
+    leaving a workspace behind per call; seqik_release_workspaces() gives everything back."""
+    import threading
+    import torch
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = [lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    base = np.stack([z[f"{l}_pose"][:64] for l in legs])
+    pose = np.ascontiguousarray(np.broadcast_to(base, (512,) + base.shape))     # 196 608 leg-frames per call
+    per_call = pose.shape[0] * 6 * 64 * (120 + 56 + 216 + 96)                   # arena + hand-off workspace, bytes
+    ref = lib.solve_seq(pose[:2], params)
+    torch.cuda.synchronize()
+    lib.release_workspaces()
+    free0 = torch.cuda.mem_get_info()[0]
+    for i in range(40):
+        out = lib.solve_seq(pose[: 512 - (i % 3)], params)
+    assert np.array_equal(out["angles"][:2], ref["angles"])
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < 1.6 * per_call, (used, per_call)      # one context, not one workspace per call
+    # concurrent callers get their own contexts and the same bits
+    res = [None] * 4
+    def work(k):
+        res[k] = lib.solve_seq(pose[:128], params)["angles"]
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(np.array_equal(r[:2], ref["angles"]) for r in res)
+    lib.release_workspaces()
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) <= 8 << 20
+    # still works afterwards (everything is re-created on demand), and the caller's device is untouched
+    dev = torch.cuda.current_device()
+    assert np.array_equal(lib.solve_seq(pose[:2], params, device=0)["angles"], ref["angles"])
+    assert torch.cuda.current_device() == dev
+    lib.release_workspaces()

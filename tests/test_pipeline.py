@@ -34,6 +34,15 @@ def test_entire_pipeline(tmp_path, oracle, hiplib, monkeypatch, frame_parallel):
         assert os.path.exists(tmp_path / name), name
     body = pickle.load(open(tmp_path / "body_joint_angles.pkl", "rb"))
     assert len(body) == 21 and all(v.shape == (1500,) for v in body.values())
+    # what the reference's consumers need from these files (visualization.py:191-213, 443-492; utils.py:235-245)
+    import loader_contract as lc
+    joint_angles, aligned_pose = lc.load_grid_plot_data(tmp_path)
+    lc.check_joint_angles(joint_angles, ["RF", "LF"], 1500, with_head=True)
+    lc.check_points3d(aligned_pose, 1500, leg_points=5)
+    lc.check_points3d(lc.load_file(tmp_path / "forward_kinematics.pkl"), 1500, leg_points=9)
+    os.remove(tmp_path / "body_joint_angles.pkl")  # the loader's second branch: head + leg files merged
+    merged, _ = lc.load_grid_plot_data(tmp_path)
+    assert set(merged) == set(body) and all(np.array_equal(merged[k], body[k]) for k in body)
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
     from seqikpy_amd.utils import calculate_body_size
     body_size = calculate_body_size(NMF_TEMPLATE, ["RF", "LF"])

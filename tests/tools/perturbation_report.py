@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- reproducibility / perturbation report.
+
+The reference's answers are a property of scipy-TRF's *iteration path*: a 1-ulp change of the input can move which
+iteration trips `ftol`, and in stages 2-3 the step is shaped by LAPACK null-space round-off.  So "the build agrees with
+the reference to 1e-4 rad" can only be judged against how well the reference agrees with ITSELF.  For every fixture
+recording and for samples of the benchmark's synthetic workload (config 3, i.i.d. and smooth) this tool runs, per chain,
+
+    A   real scipy (oracle/scipy_oracle.py: scipy.optimize.least_squares called the way IKPy calls it)
+    B   real scipy, every key-point coordinate moved by +1 ulp
+    C   the C restatement (oracle/seqik_oracle.c)             D   the C restatement, +1 ulp input
+    E   the C restatement with the zero Jacobian columns KEPT as exact-zero singular values in stages 2-3 too
+        (oracle_set_null_mode(1): scipy's m < n "never full rank" logic, deterministic -- the candidate for reaching
+        scipy's damped stage-2/3 path without LAPACK's null-space garbage)
+
+and reports (i) trajectory agreement (share of leg-frames with all seven angles within 1e-4 rad) for A~B (the
+reference's own reproducibility), C~A, C~D, E~A; (ii) ONE-STEP agreement per stage: every (frame, stage) solve repeated
+from scipy's own warm start and earlier-stage angles -- by the C restatement (C1) and by scipy on the +1 ulp target
+(B1) -- so that a divergence is attributed to the solve that caused it and not to the frames it then propagates
+through; the mismatches are classified (2 pi wrap, equal end-effector residual = another equivalent pose, better /
+worse residual); (iii) the first-divergence stage histogram of the trajectories; (iv) per-frame detail for the two
+places the parity tests special-case: the anipose LF singularity episode (which frames does any pair disagree on?) and
+the df3d RM TiTa_pitch frame that sits at 84 % of the parity budget.
+
+    python tests/tools/perturbation_report.py [--quick] > profiles/r02_perturbation_report.json      (CPU only)
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+
+import numpy as np  # noqa: E402
+
+TOL = 1e-4
+DOFS = ["ThC_yaw", "ThC_pitch", "ThC_roll", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
+STAGE_COLS = {1: [0, 1], 2: [2, 3], 3: [4, 5], 4: [6]}
+
+
+def ulp_up(a):
+    return np.nextafter(a, np.inf)
+
+
+def scipy_run(pose, seg, bounds, seeds, leg, one_step_oracle=None, one_step_ulp=False):
+    """Trajectory A (scipy) with, optionally, the one-step repeats of every solve."""
+    from oracle import scipy_oracle as so
+    from ikpy.chain import Chain
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    body = {f"{leg}_{s}": float(seg[i]) for i, s in enumerate(so.SEGMENTS)}
+    bd = {f"{leg}_{d}": (float(bounds[i][0]), float(bounds[i][1])) for i, d in enumerate(so.DOFS)}
+    cuts = np.cumsum([0, 4, 6, 8, 9])
+    init = {leg: {f"stage_{k + 1}": np.asarray(seeds[cuts[k]:cuts[k + 1]], dtype=np.float64) for k in range(4)}}
+    n = pose.shape[0]
+    factory = KinematicChainSeq(bd, [leg], body)
+    angles = np.zeros((n, 7))
+    nfev = np.zeros((n, 4), np.int32)
+    c1 = np.full((n, 7), np.nan)      # C restatement, one step from scipy's state
+    b1 = np.full((n, 7), np.nan)      # scipy, +1 ulp target, one step from scipy's state
+    cost_a = np.zeros((n, 4))
+    cost_c1 = np.full((n, 4), np.nan)
+    origin = pose[:, 0]
+    adict = {}
+    for stage in (1, 2, 3, 4):
+        target = pose[:, stage] - origin
+        target_u = ulp_up(pose[:, stage]) - ulp_up(origin)
+        seed = init[leg][f"stage_{stage}"]
+        sol = np.empty((n, len(seed)))
+        chain = so._to_ikpy(factory.create_leg_chain(leg, stage=1)) if stage == 1 else None
+        for t in range(n):
+            if stage > 1:
+                chain = so._to_ikpy(factory.create_leg_chain(leg, stage=stage, angles=adict, t=t))
+            x0 = seed if t == 0 else sol[t - 1]
+            Chain.solve_log = []
+            sol[t] = chain.inverse_kinematics(target_position=target[t], initial_position=x0)
+            nfev[t, stage - 1] = Chain.solve_log[-1][1]
+            Chain.solve_log = None
+            r = chain.forward_kinematics(sol[t])[:3, 3] - target[t]
+            cost_a[t, stage - 1] = 0.5 * float(r @ r)
+            if one_step_ulp:
+                xb = chain.inverse_kinematics(target_position=target_u[t], initial_position=x0)
+                for link, dof in so.STORED[stage]:
+                    b1[t, dof] = xb[link]
+            if one_step_oracle is not None:
+                xc, _, _ = one_step_oracle.stage_solve(stage, seg, bounds, angles[t], target[t], np.asarray(x0, float))
+                for link, dof in so.STORED[stage]:
+                    c1[t, dof] = xc[link]
+                rc = chain.forward_kinematics(xc)[:3, 3] - target[t]
+                cost_c1[t, stage - 1] = 0.5 * float(rc @ rc)
+            for link, dof in so.STORED[stage]:
+                angles[t, dof] = sol[t, link]
+        for link, dof in so.STORED[stage]:
+            adict[f"Angle_{leg}_{so.DOFS[dof]}"] = angles[:, dof]
+    return dict(angles=angles, nfev=nfev, c1=c1, b1=b1, cost=cost_a, cost_c1=cost_c1)
+
+
+def chain_task(args):
+    """All runs of one chain (one leg of one recording / sequence)."""
+    name, leg, pose, seg, bounds, seeds, golden = args
+    warnings.filterwarnings("ignore")
+    from oracle import c_oracle
+    c_oracle.reset_variants()
+    c_oracle.lib().oracle_set_null_mode(-1)
+    A = scipy_run(pose, seg, bounds, seeds, leg, one_step_oracle=c_oracle, one_step_ulp=True)
+    B = scipy_run(ulp_up(pose), seg, bounds, seeds, leg)
+    C = c_oracle.seq_leg(pose, seg, bounds, seeds)
+    D = c_oracle.seq_leg(ulp_up(pose), seg, bounds, seeds)
+    c_oracle.lib().oracle_set_null_mode(1)
+    E = c_oracle.seq_leg(pose, seg, bounds, seeds)
+    c_oracle.lib().oracle_set_null_mode(-1)
+    return dict(name=name, leg=leg, A=A["angles"], B=B["angles"], C=C["angles"], D=D["angles"], E=E["angles"],
+                nfev_A=A["nfev"], nfev_C=C["nfev"], nfev_E=E["nfev"], c1=A["c1"], b1=A["b1"],
+                cost_a=A["cost"], cost_c1=A["cost_c1"], golden=golden)
+
+
+def agree(x, y):
+    return np.abs(x - y).max(-1) <= TOL
+
+
+def classify(d_angles, cost_x, cost_a):
+    """Kind of a one-step mismatch in a stage: its angles differ by > TOL."""
+    two_pi = np.all((np.abs(d_angles) <= TOL) | (np.abs(np.abs(d_angles) - 2 * np.pi) <= 1e-3), axis=-1)
+    same = np.abs(cost_x - cost_a) <= 1e-9 * (1.0 + cost_a)
+    return np.where(two_pi, "two_pi_wrap", np.where(same, "equal_residual_other_pose",
+                                                    np.where(cost_x < cost_a, "lower_residual_than_scipy", "higher_residual_than_scipy")))
+
+
+def summarise(rows):
+    cat = lambda k: np.concatenate([r[k] for r in rows])  # noqa: E731
+    A, B, C, D, E = (cat(k) for k in "ABCDE")
+    out = {"chains": len(rows), "leg_frames": int(A.shape[0]),
+           "trajectory_agreement_all_7_within_1e-4": {
+               "scipy_vs_scipy_plus_1ulp": float(agree(A, B).mean()),
+               "c_restatement_vs_scipy": float(agree(C, A).mean()),
+               "c_restatement_vs_itself_plus_1ulp": float(agree(C, D).mean()),
+               "c_with_zero_columns_kept_vs_scipy": float(agree(E, A).mean())},
+           "trajectory_agreement_per_leg_c_vs_scipy": {}, "trajectory_agreement_per_leg_scipy_vs_itself": {}}
+    for leg in sorted({r["leg"] for r in rows}):
+        rr = [r for r in rows if r["leg"] == leg]
+        out["trajectory_agreement_per_leg_c_vs_scipy"][leg] = float(np.concatenate([agree(r["C"], r["A"]) for r in rr]).mean())
+        out["trajectory_agreement_per_leg_scipy_vs_itself"][leg] = float(np.concatenate([agree(r["A"], r["B"]) for r in rr]).mean())
+    out["median_abs_diff"] = {"c_vs_scipy": float(np.median(np.abs(C - A))), "scipy_vs_scipy_plus_1ulp": float(np.median(np.abs(A - B)))}
+    # one-step agreement per stage (same warm start, same earlier-stage angles)
+    c1, b1, ca, cc = cat("c1"), cat("b1"), cat("cost_a"), cat("cost_c1")
+    nfA, nfC, nfE = cat("nfev_A"), cat("nfev_C"), cat("nfev_E")
+    one = {}
+    for stage, cols in STAGE_COLS.items():
+        dc = c1[:, cols] - A[:, cols]
+        db = b1[:, cols] - A[:, cols]
+        bad_c = np.abs(dc).max(-1) > TOL
+        bad_b = np.abs(db).max(-1) > TOL
+        kinds = classify(dc[bad_c], cc[bad_c, stage - 1], ca[bad_c, stage - 1]) if bad_c.any() else np.array([])
+        one[f"stage_{stage}"] = {
+            "c_restatement_differs_from_scipy": float(bad_c.mean()),
+            "scipy_plus_1ulp_differs_from_scipy": float(bad_b.mean()),
+            "c_mismatch_kinds": {k: int((kinds == k).sum()) for k in ("two_pi_wrap", "equal_residual_other_pose",
+                                                                       "lower_residual_than_scipy", "higher_residual_than_scipy")},
+            "median_abs_diff_c_vs_scipy": float(np.median(np.abs(dc))),
+            "nfev_equal_scipy_trajectory": float((nfA[:, stage - 1] == nfC[:, stage - 1]).mean()),
+            "mean_nfev": {"scipy": float(nfA[:, stage - 1].mean()), "c": float(nfC[:, stage - 1].mean()),
+                          "c_zero_columns_kept": float(nfE[:, stage - 1].mean())}}
+    out["one_step_per_stage"] = one
+    # first divergence of the trajectories: per chain, the first frame on which C and A differ, and the first stage there
+    hist = {f"stage_{s}": 0 for s in (1, 2, 3, 4)}
+    hist_self = {f"stage_{s}": 0 for s in (1, 2, 3, 4)}
+    for r in rows:
+        for x, y, h in ((r["C"], r["A"], hist), (r["B"], r["A"], hist_self)):
+            bad = np.where(~agree(x, y))[0]
+            if len(bad):
+                t = bad[0]
+                for s, cols in STAGE_COLS.items():
+                    if np.abs(x[t, cols] - y[t, cols]).max() > TOL:
+                        h[f"stage_{s}"] += 1
+                        break
+    out["first_divergence_stage_histogram"] = {"c_vs_scipy": hist, "scipy_plus_1ulp_vs_scipy": hist_self,
+                                               "chains_never_diverging_c_vs_scipy": int(sum(agree(r["C"], r["A"]).all() for r in rows))}
+    return out
+
+
+def frame_detail(rows, name, leg, lo, hi):
+    """Per-frame disagreement flags of every pair on frames [lo, hi) of one chain."""
+    r = [x for x in rows if x["name"] == name and x["leg"] == leg][0]
+    g = r["golden"]
+    pairs = {"scipy_vs_shipped_or_fixture": (r["A"], g), "scipy_plus_1ulp_vs_scipy": (r["B"], r["A"]),
+             "c_vs_shipped_or_fixture": (r["C"], g), "c_vs_scipy": (r["C"], r["A"]), "c_plus_1ulp_vs_c": (r["D"], r["C"])}
+    out = {}
+    for k, (x, y) in pairs.items():
+        bad = np.where(~agree(x[lo:hi], y[lo:hi]))[0] + lo
+        out[k] = {"frames_over_1e-4": [int(t) for t in bad], "span": [int(bad.min()), int(bad.max())] if len(bad) else None}
+    allbad = sorted({t for v in out.values() for t in v["frames_over_1e-4"]})
+    out["union_span"] = [allbad[0], allbad[-1]] if allbad else None
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true", help="short cuts of every data set (smoke run)")
+    ap.add_argument("--processes", type=int, default=min(8, os.cpu_count() or 1))
+    ap.add_argument("--synthetic-seqs", type=int, default=16)
+    args = ap.parse_args()
+    from oracle import c_oracle
+    from seqikpy_amd import data, synthetic, utils
+    c_oracle.build()
+    tasks = []
+
+    def golden(name):
+        return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+    za, zd = golden("anipose_shipped"), golden("df3d_1000")
+    n_a, n_d = (400, 120) if args.quick else (6000, 1000)
+    for leg in ("RF", "LF"):
+        tasks.append(("anipose_shipped", leg, za[f"{leg}_pose"][:n_a], za[f"{leg}_seg"], za[f"{leg}_bounds"], za[f"{leg}_seeds"],
+                      za[f"{leg}_angles"][:n_a]))
+    for leg in [str(l) for l in zd["legs"]]:
+        tasks.append(("df3d_1000", leg, zd[f"{leg}_pose"][:n_d], zd[f"{leg}_seg"], zd[f"{leg}_bounds"], zd[f"{leg}_seeds"],
+                      zd[f"{leg}_angles"][:n_d]))
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    S = 2 if args.quick else args.synthetic_seqs
+    for variant in ("iid", "smooth"):
+        pose = synthetic.synthetic_pose(S, 64, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                        variant=variant, seed=synthetic.SEED_BASE)  # the benchmark's first sequences
+        for s in range(S):
+            for li, leg in enumerate(legs):
+                seg, b, seeds = c_oracle.leg_params(leg, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+                tasks.append((f"config3_{variant}", leg, pose[s, li], seg, b, seeds, None))
+    # longest chains first
+    tasks.sort(key=lambda t: -t[2].shape[0])
+    with mp.get_context("fork").Pool(args.processes) as pool:
+        rows = pool.map(chain_task, tasks, chunksize=1)
+    rep = {"tolerance_rad": TOL,
+           "what": "reproducibility of the reference (real scipy) under a +1 ulp input change, and the C restatement "
+                   "against it; see the module docstring of tests/tools/perturbation_report.py",
+           "scipy_version": __import__("scipy").__version__, "numpy_version": np.__version__,
+           "datasets": {}}
+    for name in ("anipose_shipped", "df3d_1000", "config3_iid", "config3_smooth"):
+        rr = [r for r in rows if r["name"] == name]
+        rep["datasets"][name] = summarise(rr)
+        rep["datasets"][name]["frames_per_chain"] = int(rr[0]["A"].shape[0])
+    # the anipose LF singularity episode: which frames does ANY pair disagree on?
+    lo, hi = (250, 340)
+    rep["anipose_LF_episode"] = frame_detail(rows, "anipose_shipped", "LF", lo, min(hi, n_a))
+    rep["anipose_LF_outside_frames_250_340"] = {
+        k: int((~agree(x, y)).sum()) for k, (x, y) in {
+            "scipy_vs_shipped": ([r for r in rows if r["name"] == "anipose_shipped" and r["leg"] == "LF"][0]["A"][np.r_[0:lo, min(hi, n_a):n_a]],
+                                 [r for r in rows if r["name"] == "anipose_shipped" and r["leg"] == "LF"][0]["golden"][np.r_[0:lo, min(hi, n_a):n_a]]),
+            "c_vs_shipped": ([r for r in rows if r["name"] == "anipose_shipped" and r["leg"] == "LF"][0]["C"][np.r_[0:lo, min(hi, n_a):n_a]],
+                             [r for r in rows if r["name"] == "anipose_shipped" and r["leg"] == "LF"][0]["golden"][np.r_[0:lo, min(hi, n_a):n_a]])}.items()}
+    # the frame that sits closest to the parity bar on the df3d recording (C restatement vs the reference-source run)
+    worst = None
+    for r in rows:
+        if r["name"] != "df3d_1000":
+            continue
+        e = np.abs(r["C"] - r["golden"])
+        t, j = np.unravel_index(np.argmax(e), e.shape)
+        if worst is None or e[t, j] > worst["abs_c_vs_fixture"]:
+            w = slice(max(0, t - 2), t + 3)
+            worst = {"leg": r["leg"], "frame": int(t), "joint": DOFS[j], "abs_c_vs_fixture": float(e[t, j]),
+                     "abs_scipy_vs_fixture_same_frame": float(np.abs(r["A"] - r["golden"])[t, j]),
+                     "abs_scipy_plus_1ulp_vs_scipy_same_frame": float(np.abs(r["B"] - r["A"])[t, j]),
+                     "abs_c_plus_1ulp_vs_c_same_frame": float(np.abs(r["D"] - r["C"])[t, j]),
+                     "max_abs_scipy_plus_1ulp_vs_scipy_this_leg_this_joint": float(np.abs(r["B"] - r["A"])[:, j].max()),
+                     "max_abs_scipy_plus_1ulp_vs_scipy_this_leg_any_joint": float(np.abs(r["B"] - r["A"]).max()),
+                     "nfev_scipy_neighbourhood": r["nfev_A"][w].tolist(), "nfev_c_neighbourhood": r["nfev_C"][w].tolist()}
+    rep["df3d_closest_to_the_bar"] = worst
+    print(json.dumps(rep, indent=1))
+
+
+if __name__ == "__main__":
+    main()
