@@ -59,7 +59,7 @@ BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
 TRAFFIC_FILES = ("traffic_r02.json", "traffic_r01.json")  # newest first; used only if it matches the workload
-LF_WINDOW = (280, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
+LF_WINDOW = (284, 288)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
 def parse():
@@ -517,16 +517,23 @@ def main():
                                  "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
                                          "FP64 latency; `value` above is the pipelined rate"}
             # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU ----------------------
-            proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU with the same pipeline; "
-                            "no gather; projected_value = 6M leg-frames / that time", "by_n_gpus": {}}
+            proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU; no gather; "
+                            "projected_value = 6M leg-frames / that time.  `streams`: launches in flight -- a share of "
+                            "1/N fills 1/N of the wave slots, so as many more independent steps can overlap (3 at N = 1)",
+                    "by_n_gpus": {}}
             for n in (2, 4, 8):
-                sub = Batch(pose[: S // n], params, args, args.streams)
-                bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
-                k = max(12, min(60, args.steps // 2))
-                dt = timed_steps(sub, bufs, k, len(sub.streams))
-                proj["by_n_gpus"][str(n)] = {"ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
-                                             "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
-                del sub, bufs
+                best = None
+                for n_streams in (args.streams, min(8, args.streams * n)):
+                    sub = Batch(pose[: S // n], params, args, n_streams)
+                    bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
+                    k = max(4 * n_streams, min(60, args.steps // 2))
+                    dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=n_streams)
+                    row = {"streams": n_streams, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                           "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
+                    if best is None or row["ms_per_step"] < best["ms_per_step"]:
+                        best = row
+                    del sub, bufs
+                proj["by_n_gpus"][str(n)] = best
             out["strong_projection"] = proj
             # ---- the other synthetic variant -------------------------------------------------------------------
             other = "smooth" if args.variant == "iid" else "iid"

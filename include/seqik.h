@@ -83,7 +83,12 @@ typedef struct SeqikOptions {
                              chains through stages 1, 2, 3, 4 in turn; stage_events[0] is then recorded in front of that
                              kernel and [1]..[4] behind it), 1 = always one launch per stage;
                              [2]: 0 = all lanes of a wavefront carry the same leg, 1 = consecutive chains (legs
-                             interleaved);  [3]: must be 0.  None of these changes a result bit. */
+                             interleaved);
+                             [3]: stage pipeline -- a workgroup of four wavefronts per group of chains, wavefront k
+                             running stage k of frame t while wavefront k-1 is already at frame t+1, the prefix frames
+                             handed over through LDS: 0 = automatic (runs of all four stages without diagnostics over
+                             at most 1024 chains / frame chunks, where the serial path per frame is what counts),
+                             1 = never, 2 = whenever applicable.  None of these changes a result bit. */
     /* ---- frame chunks (ABI 2): ONE long recording on the whole GPU -------------------------------------------
      * The reference walks a recording serially because frame t is warm-started from frame t-1
      * (seqikpy/leg_inverse_kinematics.py:259-282).  With frame_chunk != 0 a run of all four stages (no status /

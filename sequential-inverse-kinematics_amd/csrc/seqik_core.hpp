@@ -824,6 +824,45 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
 // ---------------------------------------------------------------------------
 // Stage driver
 // ---------------------------------------------------------------------------
+// Stage pipeline (PIPED instantiations, seqik_hip.hip "Stage pipeline"): the four stages of a chain run in four
+// wavefronts of one workgroup, stage k + 1 following stage k one frame behind.  The hand-off frame (12 doubles) goes
+// through a small ring in LDS instead of the HBM workspace; two counters per stage boundary and lane order the
+// accesses:  produced = frames the upstream stage has published, consumed = frames the downstream stage has taken.
+//   upstream, before starting frame i:   wait until consumed + PIPE_DEPTH > i   (slot i % PIPE_DEPTH is free again)
+//   upstream, frame i solved:            write slot, then produced = i + 1 (release)
+//   downstream, before starting frame i: wait until produced > i (acquire), read slot, then consumed = i + 1
+// "wait" = the lane sits out the pass (flat state machine: the other lanes of the wave carry on); a wave whose lanes
+// all wait sleeps a few cycles.  No cycle of waits exists: stage 1 only waits for stage 2 to free a slot, stage 4
+// waits for nobody downstream, so the oldest unfinished frame can always advance; every wave leaves its loop when its
+// lanes have done all frames.
+constexpr int PIPE_DEPTH = 2;
+constexpr int PIPE_SPIN_LIMIT = 1 << 24;  // watchdog: ~1 s of waiting on one frame (a frame takes ~10-100 us)
+struct PipeLane {
+    // element k of slot j of this lane at ring[(j * 12 + k) * lane_stride]
+    double *ring_in, *ring_out;     // LDS; null for the first / last stage
+    int *produced_in, *consumed_in; // counters of the boundary in front of this stage
+    int *produced_out, *consumed_out;
+    int lane_stride;                // lanes interleaved in LDS (bank-conflict free)
+};
+
+SEQIK_HD int pipe_load(const int *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    return *p;
+#endif
+}
+
+SEQIK_HD void pipe_store(int *p, int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    *p = v;
+#endif
+}
+
 struct ChainIO {
     const double *pose;     // key point (row, t) of this chain at pose + row * pose_row + t * pose_frame (x, y, z)
     int64_t pose_row, pose_frame;
@@ -844,6 +883,8 @@ struct ChainIO {
     int64_t init_stride;    // init is read as init[dof * init_stride] (lets it point into an angle array)
     double *start_state;    // nullable [7]: receives the angles of frame t_store - 1 (the state the run-in reached
                             // = the warm start the stored frames were computed from) when t_store > t_begin
+    // --- PIPED instantiations only ----------------------------------------------------------------------------
+    PipeLane pipe;
 };
 
 // Prefix frame of STAGE from the angles of the earlier stages: the "fixed" links of
@@ -893,9 +934,11 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //               with 1 = gtol).
 //   CHUNKED   : the lane solves frames [io.t_begin, io.n_frames) of its chain and stores only those from
 //               io.t_store on (ChainIO); false = the whole chain from frame 0, everything stored.
-template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false>
+//   PIPED     : the hand-off goes through the LDS ring of io.pipe (stage pipeline, see PipeLane) instead of io.frames.
+template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
+    static_assert(!(PIPED && FROM_ANGLES), "the stage pipeline starts at stage 1");
     static_assert(STAGE > 1 || !FROM_ANGLES, "stage 1 has no prefix");
     static_assert(!(CHUNKED && FROM_ANGLES), "frame chunks start at stage 1 (the run-in has no stored angles)");
     static_assert(STAGE < 4 || !HANDOFF, "stage 4 is the last one");
@@ -927,16 +970,57 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     double coxa_end[3] = {0.0, 0.0, 0.0};  // stage 4 + FK only
     const int64_t t_first = CHUNKED ? io.t_begin : 0;
     int64_t t = t_first;
+    int pipe_spins = 0;  // PIPED: consecutive passes this lane sat out (watchdog only)
     double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
     bool have_pe = false;
 
+    // (Tried and dropped: keeping finished lanes in the loop and letting all 64 lanes execute a burst of dummy
+    // multiply-adds per pass while fewer than 16 lanes are still working, to keep the wave out of the slow sparse-EXEC
+    // mode of scripts/microbench/exec_*.hip during the end-of-stage tail: 14.2 -> 15.0 ms per benchmark step.)
     while (t < io.n_frames) {
+        if constexpr (PIPED) {
+            // may this lane start frame t?  (only asked at a frame boundary; a lane in the middle of a solve runs on)
+            bool stall = false;
+            if (new_solve) {
+                const int i = (int)(t - t_first);
+                if constexpr (STAGE > 1) stall = pipe_load(io.pipe.produced_in) <= i;
+                if constexpr (HANDOFF) stall = stall || (pipe_load(io.pipe.consumed_out) + PIPE_DEPTH <= i);
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__ballot(stall) == __ballot(1)) __builtin_amdgcn_s_sleep(2);  // every lane still in the loop waits
+#endif
+            if (stall) {
+                if (++pipe_spins > PIPE_SPIN_LIMIT) {
+                    // Cannot happen by construction (see PipeLane); should it ever, never hang the GPU: mark this
+                    // lane's remaining results NaN, release the neighbours, leave.
+                    const double nan = __builtin_nan("");
+                    for (int64_t tt = t; tt < io.n_frames; ++tt) {
+                        if (CHUNKED && tt < io.t_store) continue;
+                        io.angles[tt * io.ang_frame + DOF0 * io.ang_dof] = nan;
+                        if constexpr (NA == 2) io.angles[tt * io.ang_frame + (DOF0 + 1) * io.ang_dof] = nan;
+                    }
+                    if constexpr (HANDOFF) pipe_store(io.pipe.produced_out, 0x3fffffff);
+                    if constexpr (STAGE > 1) pipe_store(io.pipe.consumed_in, 0x3fffffff);
+                    break;
+                }
+                continue;
+            }
+            pipe_spins = 0;
+        }
         if (new_solve) {
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + STAGE * io.pose_row;
             if constexpr (STAGE > 1) {
                 if constexpr (FROM_ANGLES) {
                     build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, WANT_FK ? coxa_end : nullptr);
+                } else if constexpr (PIPED) {
+                    const int fi = (int)(t - t_first);
+                    const double *w = io.pipe.ring_in + (fi % PIPE_DEPTH) * 12 * io.pipe.lane_stride;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) P.pre.r[i] = w[i * io.pipe.lane_stride];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) P.pre.t[i] = w[(9 + i) * io.pipe.lane_stride];
+                    pipe_store(io.pipe.consumed_in, fi + 1);
                 } else {
                     const double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
@@ -1116,7 +1200,15 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             if constexpr ((WANT_FK && STAGE >= 2) || HANDOFF) {
                 Frame after;  // frame after the active links at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
-                if constexpr (HANDOFF) {
+                if constexpr (HANDOFF && PIPED) {
+                    const int fi = (int)(t - t_first);
+                    double *w = io.pipe.ring_out + (fi % PIPE_DEPTH) * 12 * io.pipe.lane_stride;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) w[i * io.pipe.lane_stride] = after.r[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) w[(9 + i) * io.pipe.lane_stride] = after.t[i];
+                    pipe_store(io.pipe.produced_out, fi + 1);
+                } else if constexpr (HANDOFF) {
                     double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) w[i] = after.r[i];

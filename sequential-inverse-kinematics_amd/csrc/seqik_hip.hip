@@ -14,6 +14,13 @@
 namespace {
 
 constexpr int kMaxLegs = 8;   // LegConst table staged in LDS (a fly has 6 legs)
+// Automatic choice of the stage pipeline (measured: profiles/r02_launch_shape.jsonl, r02_latency_configs.jsonl): with
+// thin waves replicated (chain_of_wave_lane) it beats the lane-per-chain kernels for every call that does not fill the
+// GPU -- serial walks 1.9-2.0x (config 4: 295 -> 149 ms), frame chunks 1.3-1.5x (config 4: 3.35 -> 2.54 ms), 8 196
+// chains x 64 frames 8.2 -> 4.5 ms, 32 784 chains 8.9 -> 4.9 ms -- and loses once all SIMD slots are taken anyway
+// (93 750 chains: 24.8 vs 32.5 ms: a workgroup of four stage waves holds its slots for the time of its slowest stage).
+constexpr int64_t kPipeMaxChains = 40000;
+constexpr int64_t kPipeMaxChunks = 40000;
 constexpr int kMaxBlock = 256;
 
 // Register budget: waves per SIMD the stage kernels are compiled for (512 / N registers per lane).  With the
@@ -81,17 +88,24 @@ struct KernelArgs {
 //     code paths its lanes take, so a handful of chains run best as one-lane waves; at a thousand chains and
 //     more W = 64.
 // W < 0 encodes the leg-interleaved mapping with |W| lanes.  Returns false for lanes that carry no chain.
-__device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int32_t W, const LegOrder &order,
-                                              int64_t &c, int &leg)
+//   * REPLICATION.  A wavefront that keeps fewer than 16 lanes active for more than a few tens of microseconds drops
+//     into a mode in which its vector instructions issue ~4.6x slower once it shares its CU with other waves (measured:
+//     scripts/microbench/exec_density.hip, exec_mode.hip, profiles/r02_sparse_exec_microbench.jsonl; the threshold is
+//     the number of ACTIVE lanes, wherever they sit, exited or masked alike).  So a wave that carries W < 16 chains
+//     runs every chain on R = 64 / W lanes: the replicas load the same operands, take the same branches and store the
+//     same values to the same addresses -- no additional instruction is issued, and the wave stays in the fast mode.
+__device__ __forceinline__ int lane_replication(int W) { return W < 16 ? 64 / W : 1; }
+
+__device__ __forceinline__ bool chain_of_wave_lane(int64_t wave, int lane, int64_t n_seq, int32_t n_legs, int32_t W,
+                                                   const LegOrder &order, int64_t &c, int &leg)
 {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = (int)(g & 63);
-    const int64_t wave = g >> 6;
     if (W < 0) {
+        lane /= lane_replication(-W);
         c = wave * (-W) + lane;
         leg = (int)(c % n_legs);
         return lane < -W && c < n_seq * n_legs;
     }
+    lane /= lane_replication(W);
     const int64_t n_grp = (n_seq + W - 1) / W;  // waves per leg
     const int64_t slot = wave / n_grp;          // which leg, in dispatch order
     if (slot >= n_legs) return false;
@@ -99,6 +113,13 @@ __device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int
     const int64_t seq = (wave - slot * n_grp) * W + lane;
     c = seq * n_legs + leg;
     return lane < W && seq < n_seq;
+}
+
+__device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int32_t W, const LegOrder &order,
+                                              int64_t &c, int &leg)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    return chain_of_wave_lane(g >> 6, (int)(g & 63), n_seq, n_legs, W, order, c, leg);
 }
 
 // Dispatch order of the legs: descending total width of the joint limits (stable).
@@ -131,11 +152,13 @@ LegOrder make_leg_order(const SeqikLegParams *legs, int32_t n_legs)
 // waves applies: measured on the shipped recordings (scripts/latency_lanes.py, profiles/r02_latency_lanes.jsonl) the
 // wall-clock is flat within ~10 % around  chunks / 256  lanes per wave up to several thousand chunks
 // (1 500 chunks: W = 1 4.4, 3 3.8, 8 3.9, 64 5.0 ms; 3 000 chunks: W = 1 4.0, 6-16 3.6, 64 4.0 ms), so the thin-wave rule
-// simply continues until it reaches full waves at 16 384 chunks.
+// simply continues (1-16 chunks per wave) up to 4 096 chunks; from there on full waves (stage pipeline, 8 196 chains:
+// 16 per group 5.0 ms, 64 per group 4.5 ms; 11 718 chains, three launches in flight: 46 per group 6.7, 64 per group 5.4).
+// `chunked` also stands for "on the stage pipeline".
 int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt, bool chunked = false)
 {
     if (opt && opt->reserved[0] >= 1 && opt->reserved[0] <= 64) return opt->reserved[0];
-    if (chunked && n_chains < 16384) return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);
+    if (chunked && n_chains < 4096) return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);
     if (n_chains >= 1024) return 64;
     return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);  // <= 256 thin waves of 1-4 lanes
 }
@@ -241,6 +264,77 @@ seqik_fused_kernel(KernelArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Stage pipeline: one WORKGROUP of four wavefronts per group of chains, wavefront k = stage k + 1.
+//
+// The lane-per-chain kernels above walk a chain stage by stage (all frames of stage 1, then all of stage 2, ...): fine
+// when there are thousands of chains, but a handful of recordings (the reference's own use: one recording, 1-6 legs)
+// then runs at the speed of ONE lane doing 4 x N solves one after the other.  The dependencies allow more: stage s of
+// frame t needs stage s - 1 of frame t and stage s of frame t - 1, so the four stages can work on four consecutive
+// frames at once.  Here wave k of a workgroup runs stage k + 1 for the workgroup's chains (lane = chain, as before) and
+// receives the prefix frame of every time step from wave k - 1 through a two-slot ring in LDS (PipeLane in
+// seqik_core.hpp): no HBM workspace, and the serial path per frame shrinks from the sum of the four stage solves to the
+// longest of them (stage 1: ~40 % of the sum on the recordings) -- what BASELINE.json's north star sketches as "one
+// wavefront per chain with link transforms staged in LDS", per stage.  Same run_stage bodies, same bits.
+// ---------------------------------------------------------------------------------------------------------------
+struct PipeShared {
+    double ring[3][seqik::PIPE_DEPTH][12][64];  // [boundary][slot][element][lane]: lanes interleaved, conflict free
+    int produced[3][64];
+    int consumed[3][64];
+};
+
+template <bool WANT_FK, bool CHUNK_SPEC_MODE>
+__device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane)
+{
+    seqik::PipeLane &pl = io.pipe;
+    pl.lane_stride = 64;
+    pl.ring_in = stage_wave > 0 ? &sh.ring[stage_wave - 1][0][0][lane] : nullptr;
+    pl.produced_in = stage_wave > 0 ? &sh.produced[stage_wave - 1][lane] : nullptr;
+    pl.consumed_in = stage_wave > 0 ? &sh.consumed[stage_wave - 1][lane] : nullptr;
+    pl.ring_out = stage_wave < 3 ? &sh.ring[stage_wave][0][0][lane] : nullptr;
+    pl.produced_out = stage_wave < 3 ? &sh.produced[stage_wave][lane] : nullptr;
+    pl.consumed_out = stage_wave < 3 ? &sh.consumed[stage_wave][lane] : nullptr;
+    switch (stage_wave) {  // wave-uniform
+    case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
+    case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
+    case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
+    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true>(lc, io); break;
+    }
+}
+
+template <bool WANT_FK>
+__global__ void __launch_bounds__(256) seqik_pipe_kernel(KernelArgs a)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    __shared__ PipeShared sh;
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) { (&sh.produced[0][0])[i] = 0; (&sh.consumed[0][0])[i] = 0; }
+    }
+    __syncthreads();  // the only barrier: from here on the four waves are coupled by the ring counters alone
+    const int stage_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t c;
+    int leg;
+    if (!chain_of_wave_lane(blockIdx.x, lane, a.n_seq, a.n_legs, a.lanes_per_wave, a.leg_order, c, leg)) return;
+    seqik::ChainIO io;
+    io.pose = a.pose + c * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
+    io.status = nullptr;
+    io.nfev = nullptr;
+    io.init = a.init ? a.init + c * 7 : nullptr;
+    io.frames = nullptr;
+    io.n_frames = a.n_frames;
+    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Frame chunks (SeqikOptions.frame_chunk, include/seqik.h): one long recording on the whole GPU.
 //
 // A chain of N frames is cut into K = ceil(N / C) chunks; "virtual chain" vc = (seq * K + k) * n_legs + leg is chunk k
@@ -324,6 +418,43 @@ __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, Chu
     if (ready) ca.worklist[s_base + mine] = (int32_t)vc;
 }
 
+// ChainIO of virtual chain vc (chunk k of real chain c): speculative (run-in from the seeds / the caller's init) or
+// repair (from the stored last frame of chunk k - 1, which also becomes the chunk's recorded start state)
+__device__ __forceinline__ void chunk_io(const KernelArgs &a, const ChunkArgs &ca, int64_t vc, int leg, bool spec,
+                                         seqik::ChainIO &io)
+{
+    const int64_t K = ca.n_chunks, C = ca.chunk, N = a.n_frames;
+    const int64_t vseq = vc / a.n_legs;
+    const int64_t seq = vseq / K, k = vseq - seq * K;
+    const int64_t c = seq * a.n_legs + leg;
+    io.pose = a.pose + c * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c * N * 27 : nullptr;
+    io.status = nullptr;
+    io.nfev = nullptr;
+    io.frames = a.frames + vc * (C + ca.halo) * 12;
+    io.t_store = k * C;
+    io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
+    double *ss = ca.start_state + vc * 7;
+    if (spec) {
+        io.t_begin = (k * C > ca.halo) ? k * C - ca.halo : 0;
+        io.init = (k == 0 && a.init) ? a.init + c * 7 : nullptr;
+        io.init_stride = 1;
+        io.start_state = (k > 0) ? ss : nullptr;
+    } else {
+        io.t_begin = io.t_store;
+        io.init = io.angles + (io.t_store - 1) * a.ang_frame;
+        io.init_stride = a.ang_dof;
+        io.start_state = nullptr;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) ss[d] = io.init[d * a.ang_dof];
+    }
+}
+
 // Solves chunks: the four stage bodies back to back, as seqik_fused_kernel, over the frames of one chunk per lane.
 //   CHUNK_SPEC    lane -> virtual chain by chain_of_lane() (leg-pure waves), run-in from the seeds
 //   CHUNK_REPAIR  lanes take the entries of the work list of round ca.round (grid-stride), start from the true state
@@ -356,7 +487,8 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
         // per wave: a pass of a wave costs the union of the code paths its lanes take)
         W = (n_items + n_waves - 1) / n_waves;
         W = W < 1 ? 1 : (W > 64 ? 64 : W);
-        cursor = (lane < W) ? wave * W + lane : n_items;
+        const int cl = lane / lane_replication((int)W);  // thin waves: every item on 64 / W lanes (see chain_of_wave_lane)
+        cursor = (cl < W) ? wave * W + cl : n_items;
     } else if (mode == CHUNK_SWEEP) {
         if (ca.ctrl[ca.round].pending == 0 || wave >= a.n_chains) return;
         cursor = 1;  // wave-uniform: next chunk of real chain `wave` to verify
@@ -395,37 +527,9 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
             if (!found) break;  // wave-uniform
         }
         if (vc >= 0) {
-            const int64_t vseq = vc / a.n_legs;
-            const int64_t seq = vseq / K, k = vseq - seq * K;
-            const int64_t c = seq * a.n_legs + leg;
             seqik::ChainIO io;
-            io.pose = a.pose + c * a.pose_chain;
-            io.pose_row = a.pose_row;
-            io.pose_frame = a.pose_frame;
-            io.angles = a.angles + c * a.ang_chain;
-            io.ang_dof = a.ang_dof;
-            io.ang_frame = a.ang_frame;
-            io.fk = a.fk ? a.fk + c * N * 27 : nullptr;
-            io.status = nullptr;
-            io.nfev = nullptr;
-            io.frames = a.frames + vc * (C + ca.halo) * 12;
-            io.t_store = k * C;
-            io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
-            double *ss = ca.start_state + vc * 7;
-            if (mode == CHUNK_SPEC) {
-                io.t_begin = (k * C > ca.halo) ? k * C - ca.halo : 0;
-                io.init = (k == 0 && a.init) ? a.init + c * 7 : nullptr;
-                io.init_stride = 1;
-                io.start_state = (k > 0) ? ss : nullptr;
-            } else {
-                io.t_begin = io.t_store;
-                io.init = io.angles + (io.t_store - 1) * a.ang_frame;
-                io.init_stride = a.ang_dof;
-                io.start_state = nullptr;
-#pragma unroll
-                for (int d = 0; d < 7; ++d) ss[d] = io.init[d * a.ang_dof];
-                if (mode == CHUNK_SWEEP && ca.stats) atomicAdd(&ca.stats[6], 1);
-            }
+            chunk_io(a, ca, vc, leg, mode == CHUNK_SPEC, io);
+            if (mode == CHUNK_SWEEP && ca.stats) atomicAdd(&ca.stats[6], 1);
             const seqik::LegConst &lc = s_legs[leg];
             seqik::run_stage<1, false, false, false, true, true>(lc, io);
             seqik::run_stage<2, WANT_FK, false, false, true, true>(lc, io);
@@ -434,6 +538,32 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
         }
         if (mode == CHUNK_SWEEP) __threadfence();  // the next verification reads the frames just stored
     }
+}
+
+// The speculative pass of a chunked call on the stage pipeline (seqik_pipe_kernel): a workgroup of four waves per group
+// of chunks.  In a workgroup the stage-1 wave of a chunk runs at most PIPE_DEPTH frames ahead of its stage-2 wave; all
+// four store into the chunk's rows / start_state exactly what the lane-per-chunk kernel stores.
+template <bool WANT_FK>
+__global__ void __launch_bounds__(256) seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    __shared__ PipeShared sh;
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < 3 * 64; i += blockDim.x) { (&sh.produced[0][0])[i] = 0; (&sh.consumed[0][0])[i] = 0; }
+    }
+    __syncthreads();
+    const int stage_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t vc;
+    int leg;
+    if (!chain_of_wave_lane(blockIdx.x, lane, ca.n_vseq, a.n_legs, a.lanes_per_wave, a.leg_order, vc, leg)) return;
+    seqik::ChainIO io;
+    chunk_io(a, ca, vc, leg, true, io);
+    // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
+    pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane);
 }
 
 // zeroes the control block / statistics of a chunked call (first thing on the stream)
@@ -788,15 +918,22 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
                          pick_frame_chunks(opt, a.n_chains, n_frames, chunk, halo, n_chunks);
     const int64_t n_vchains = a.n_chains * n_chunks;  // virtual chains = chunks (= chains when not chunked)
     if (n_vchains > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many frame chunks for one launch%s");
-    a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked);
+    // stage pipeline (four waves per group of chains, seqik_pipe_kernel): SeqikOptions.reserved[3] = 0 automatic (calls
+    // with at most kPipeMaxChains chains / chunks: too few for the lane-per-chain kernels to fill the GPU, so the
+    // serial path per frame is what counts), 1 = never, 2 = whenever applicable
+    const int pipe_opt = opt ? opt->reserved[3] : 0;
+    const bool piped = first_stage == 1 && last_stage == 4 && !diag &&
+                       (pipe_opt == 2 || (pipe_opt == 0 && n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
+    a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked || piped);
     int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
     if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
         n_waves = (n_vchains + a.lanes_per_wave - 1) / a.lanes_per_wave;
         a.lanes_per_wave = -a.lanes_per_wave;
     }
     int64_t grid64 = (n_waves * 64 + block - 1) / block;
-    if (grid64 > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
+    if (grid64 > 0x7fffffffLL || n_waves > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
+    const dim3 pipe_grid((unsigned)n_waves), pipe_blk(256);  // one workgroup (4 stage waves) per group of W chains
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
     static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
@@ -804,12 +941,12 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         const size_t ws_bytes = sizeof(double) * (12 * (size_t)(chunk + halo) + 7) * n_vchains + 128 +
                                 sizeof(int32_t) * (size_t)n_vchains;
         if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
-    } else if (last_stage > first_stage) {
+    } else if (last_stage > first_stage && !piped) {
         const size_t ws_bytes = sizeof(double) * 12 * a.n_chains * n_frames;
         if (pool_workspace) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), ws_bytes, stream));
         else if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     }
-    const bool fused = !(opt && opt->reserved[1] == 1) && first_stage == 1 && last_stage == 4 && !diag;
+    const bool fused = (piped || !(opt && opt->reserved[1] == 1)) && first_stage == 1 && last_stage == 4 && !diag;
     if (chunked) {
         ChunkArgs ca;
         ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo;
@@ -825,7 +962,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         ca.worklist = reinterpret_cast<int32_t *>(base + off);
         if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
-        if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
+        if (piped) {
+            if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false>), pipe_grid, pipe_blk, 0, stream, a, ca);
+        } else if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         HIP_TRY(hipGetLastError());
         const dim3 scan_grid((unsigned)((n_vchains + 255) / 256)), scan_blk(256);
@@ -850,7 +990,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     }
     if (fused) {
         if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
-        if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
+        if (piped) {
+            if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true>), pipe_grid, pipe_blk, 0, stream, a);
+            else hipLaunchKernelGGL((seqik_pipe_kernel<false>), pipe_grid, pipe_blk, 0, stream, a);
+        } else if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
         else hipLaunchKernelGGL((seqik_fused_kernel<false>), grid, blk, 0, stream, a);
         HIP_TRY(hipGetLastError());
         if (opt && opt->stage_events)  // one kernel: [0] in front of it, [1..4] behind it

@@ -482,7 +482,7 @@ def _affine_array(affine, n_legs):
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
               device=-1, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0, interleave_legs=0,
-              frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0):
+              frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, pipeline=0):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
@@ -493,6 +493,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     ``frame_chunk`` (0 = serial walk, bit-exact; -1 = automatic; > 0 = frames per chunk), ``frame_halo``,
     ``chunk_tol``, ``chunk_rounds``: frame chunks, see ``SeqikOptions`` in include/seqik.h -- one long recording
     solved in concurrently running pieces, equal to the serial walk to about ``chunk_tol`` (default 1e-6 rad).
+    ``pipeline``: stage pipeline (``SeqikOptions.reserved[3]``): 0 = automatic (few chains), 1 = never, 2 = always.
     ``device``: HIP device ordinal, -1 = the calling thread's current device.
     Returns dict(angles, fk or None, status or None, nfev or None, chunk_stats).
     """
@@ -519,6 +520,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
     opt.reserved[2] = interleave_legs
+    opt.reserved[3] = pipeline
     opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
     stats = np.zeros(8, dtype=np.int32)
     opt.chunk_stats = stats.ctypes.data_as(_ip)
@@ -542,7 +544,7 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
                      first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
                      stage_events=None, lanes_per_wave=0, staged=0, interleave_legs=0,
-                     frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, d_chunk_stats=0):
+                     frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, d_chunk_stats=0, pipeline=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
     ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
@@ -553,6 +555,7 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     opt.reserved[0] = lanes_per_wave
     opt.reserved[1] = staged
     opt.reserved[2] = interleave_legs
+    opt.reserved[3] = pipeline
     opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
     if d_chunk_stats:  # device int32[8]
         opt.chunk_stats = ctypes.cast(ctypes.c_void_p(int(d_chunk_stats)), _ip)

@@ -18,12 +18,14 @@ for p in (PKG_PARENT, ROOT):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DOFS = ["ThC_yaw", "ThC_pitch", "ThC_roll", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
 
-# Frames of the shipped anipose recording (LF leg) where the reference itself is not
-# reproducible: stage 2 sits in a kinematic singularity (CTr_pitch pinned at its upper bound 0,
-# ThC_roll at its upper bound) and leaves it a few frames earlier or later depending on
-# round-off (shipped golden: frame 287; reference source re-run here over real scipy: 284;
-# this build: 288).  SURVEY.md 7.4(1).
-LF_DEGENERATE = (280, 302)
+# Frames of the shipped anipose recording (LF leg) where the reference itself is not reproducible: stage 2 sits in a
+# kinematic singularity (CTr_pitch pinned at its upper bound 0, ThC_roll at its upper bound) and leaves it a few frames
+# earlier or later depending on round-off.  The window is what tests/tools/perturbation_report.py measures
+# (profiles/r02_perturbation_report.json, "anipose_LF_episode"): real scipy differs from the shipped outputs on frames
+# 284-287 AND from itself under a +1 ulp change of the key points on the same four frames; the C restatement differs
+# from the shipped outputs on 286-287; outside 284-287 no pair of runs disagrees by more than 1e-4 rad on any of the
+# 6000 frames.  SURVEY.md 7.4(1).
+LF_DEGENERATE = (284, 288)
 
 
 def pytest_configure(config):

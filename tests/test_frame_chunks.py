@@ -174,3 +174,60 @@ def test_python_api_default_is_chunked_and_within_parity_of_shipped_golden(hipli
     serial_ang, _ = LegInvKinSeq({"RF_leg": za["RF_pose"][:300]}, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES,
                                  log_level="ERROR").run_ik_and_fk(frame_parallel=False)
     assert np.abs(serial_ang["Angle_RF_ThC_yaw"] - ang["Angle_RF_ThC_yaw"][:300]).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Stage pipeline (SeqikOptions.reserved[3]): four wavefronts per group of chains, hand-off through LDS
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [0, 1, 3, 64])
+def test_stage_pipeline_equals_oracle_bit_for_bit(oracle, hiplib, lanes):
+    """Serial walk on the stage pipeline == lane-per-chain kernel == C oracle, whatever the number of chains per
+    workgroup (every lane has its own ring slots and counters)."""
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(hiplib, z, legs)
+    pose = np.stack([np.stack([z[f"{l}_pose"][o:o + 90] for l in legs]) for o in (0, 200, 411, 640, 900)])  # S = 5
+    piped = hiplib.solve_seq(pose, params, pipeline=2, lanes_per_wave=lanes)
+    plain = hiplib.solve_seq(pose, params, pipeline=1)
+    assert np.array_equal(piped["angles"], plain["angles"]) and np.array_equal(piped["fk"], plain["fk"])
+    for s, o in enumerate((0, 200, 411, 640, 900)):
+        for li, l in enumerate(legs):
+            ref = oracle.seq_leg(z[f"{l}_pose"][o:o + 90], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"])
+            assert np.array_equal(piped["angles"][s, li], ref["angles"]) and np.array_equal(piped["fk"][s, li], ref["fk"])
+
+
+@pytest.mark.gpu
+def test_stage_pipeline_edge_cases(oracle, hiplib):
+    """One frame, two frames (shorter than the ring), init_angles, no FK, nasty made-up legs, the LF episode."""
+    from conftest import random_leg_case
+    z = load_golden("anipose_shipped")
+    params = _params(hiplib, z, ["RF", "LF"])
+    pose = np.stack([z["RF_pose"][200:420], z["LF_pose"][200:420]])[None]
+    ser = hiplib.solve_seq(pose, params, pipeline=1)
+    for n in (1, 2, 3, 220):
+        p = hiplib.solve_seq(pose[:, :, :n], params, pipeline=2, want_fk=(n != 3))
+        assert np.array_equal(p["angles"], ser["angles"][:, :, :n])
+    init = ser["angles"][:, :, 99]
+    cont = hiplib.solve_seq(pose[:, :, 100:], params, pipeline=2, init_angles=init)
+    assert np.array_equal(cont["angles"], ser["angles"][:, :, 100:]) and np.array_equal(cont["fk"], ser["fk"][:, :, 100:])
+    rng = np.random.default_rng(5)
+    for _ in range(24):
+        kp, seg, b, seeds = random_leg_case(rng, 40)
+        lp = hiplib.leg_params_from_arrays(seg, b, seeds)
+        got = hiplib.solve_seq(kp[None, None], [lp], pipeline=2)
+        ref = oracle.seq_leg(kp, seg, b, seeds)
+        assert np.array_equal(got["angles"][0, 0], ref["angles"]) and np.array_equal(got["fk"][0, 0], ref["fk"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk,halo,rounds", [(8, 8, 3), (8, 2, 1), (16, 4, 3)])
+def test_chunks_on_the_stage_pipeline_equal_model(oracle, hiplib, chunk, halo, rounds):
+    z = load_golden("anipose_shipped")
+    legs = ["LF", "RF"]
+    sl = slice(200, 520)
+    pose = np.stack([z[f"{l}_pose"][sl] for l in legs])[None]
+    out = hiplib.solve_seq(pose, _params(hiplib, z, legs), frame_chunk=chunk, frame_halo=halo, chunk_rounds=rounds, pipeline=2)
+    ang, fk, stats = _model_all(oracle, z, legs, sl, chunk, halo, rounds=rounds)
+    assert np.array_equal(out["angles"][0], ang) and np.array_equal(out["fk"][0], fk)
+    assert np.array_equal(np.array([out["chunk_stats"][k] for k in hiplib.CHUNK_STATS_FIELDS]), stats)

@@ -87,12 +87,13 @@ def test_algorithm_variants_kept_as_hooks(oracle):
       * the generic chain's SVD-free step reaches the same claw positions as its SVD variant."""
     from conftest import random_leg_case
     try:
-        cases = []
-        z = load_golden("df3d_1000")
-        for leg in ("RF", "LM", "RH"):
-            cases.append((z[f"{leg}_pose"][:400], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"]))
-        za = load_golden("anipose_shipped")
-        cases.append((za["LF_pose"][200:700], za["LF_seg"], za["LF_bounds"], za["LF_seeds"]))
+        cases, refs = [], []
+        for name in ("anipose_shipped", "anipose_scipy_cut", "df3d_100", "df3d_1000"):   # every fixture, full length
+            z = load_golden(name)
+            for leg in [str(l) for l in z["legs"]]:
+                cases.append((z[f"{leg}_pose"], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"]))
+                refs.append((name, leg, z[f"{leg}_angles"]))
+        n_fixture = len(cases)
         rng = np.random.default_rng(5)
         cases += [random_leg_case(rng, 40) for _ in range(150)]
         for c in cases:
@@ -102,13 +103,20 @@ def test_algorithm_variants_kept_as_hooks(oracle):
             b = oracle.seq_leg(*c)
             for k in ("angles", "fk", "status", "nfev"):
                 assert np.array_equal(a[k], b[k]), k
-        for c in cases[:3]:
-            oracle.set_variant(closed_form_2x2=False)
+        worst = 0.0
+        for c, (name, leg, ref) in zip(cases[:n_fixture], refs):
+            # scipy's loop verbatim (one-sided Jacobi SVD of the augmented matrix + the ten-iteration root search)
+            oracle.set_variant(closed_form_2x2=False, tr2_shortcut=False)
             a = oracle.seq_leg(*c)
-            oracle.set_variant(closed_form_2x2=True)
+            oracle.set_variant(closed_form_2x2=True, tr2_shortcut=True)
             b = oracle.seq_leg(*c)
-            assert np.abs(a["angles"] - b["angles"]).max() < 1e-5
+            ok = good_frames(leg, len(ref)) if name.startswith("anipose") else np.ones(len(ref), bool)
+            assert np.abs(a["angles"] - b["angles"])[ok].max() < 1e-5, (name, leg)
             assert (a["nfev"] == b["nfev"]).mean() > 0.99
+            # ... and the verbatim variant is exactly as far from the reference outputs as the default one
+            assert np.abs(a["angles"] - ref)[ok].max() < 1e-4, (name, leg)
+            worst = max(worst, np.abs(a["angles"] - ref)[ok].max())
+        assert worst < 9e-5   # profiles/r02_oracle_variants.json: 8.39e-5 for the default and the verbatim variant alike
         zg = load_golden("generic_rf_100")
         oracle.set_variant(generic_svd=True)
         a = oracle.generic_leg(zg["RF_pose"], zg["RF_seg"], zg["RF_bounds"], zg["RF_seeds"][18:27])
