@@ -59,7 +59,7 @@ BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
 TRAFFIC_FILES = ("traffic_r02.json", "traffic_r01.json")  # newest first; used only if it matches the workload
-LF_WINDOW = (284, 288)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
+LF_WINDOW = (284, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
 def parse():

@@ -54,6 +54,28 @@ def _mean_quantile(vector: np.ndarray, quantile_diff: float = 0.05) -> float:
     return 0.5 * (np.quantile(vector, q=0.5 - quantile_diff) + np.quantile(vector, q=0.5 + quantile_diff))
 
 
+def linear_quantile_index(n: int, q: float) -> Tuple[int, int, float]:
+    """``(previous index, next index, gamma)`` of numpy's default ("linear") quantile of ``n`` values, with the
+    floating-point expression of the numpy that is installed: its own method table when it can be reached
+    (``_QuantileMethods["linear"]``; ``(n - 1) q`` in numpy 1.22-2.x, which is NOT bit-identical to the general
+    ``n q + (alpha + q (1 - alpha - beta)) - 1`` form other methods use), the same expression otherwise; neighbours
+    and gamma as ``_get_indexes`` / ``_get_gamma``.  tests/test_alignment.py checks it against ``np.quantile`` itself
+    for every n up to 3000."""
+    vi = None
+    try:
+        from numpy.lib import _function_base_impl as _impl
+        vi = float(_impl._QuantileMethods["linear"]["get_virtual_index"](n, q))
+    except Exception:  # other numpy layout: the documented expression of the "linear" method
+        vi = float((n - 1) * q)
+    lo = int(np.floor(vi))
+    hi = lo + 1
+    if vi >= n - 1:       # numpy: indexes above the bounds -> both neighbours are the last element
+        lo = hi = n - 1
+    if vi < 0:
+        lo = hi = 0
+    return lo, hi, float(vi - np.floor(vi))
+
+
 class AlignPose:
     """Aligns the 3D leg key points to the template (coxa position and leg size).
 
@@ -128,13 +150,15 @@ class AlignPose:
             raise ValueError("on_gpu=True needs the same number of frames for every leg")
         n = n.pop()
         pose = np.stack([np.asarray(arr, dtype=np.float64)[:, :5, :] for _, arr in segs])[None]   # (1, L, N, 5, 3)
+        if not np.isfinite(pose).all():
+            # numpy's quantile of a series that holds a NaN is NaN; a radix sort would just push the NaN to the end
+            return {seg[:2]: self.leg_affine(arr, seg[:2]) for seg, arr in segs}
         qs = (0.5 - 0.05, 0.5 + 0.05)
         ranks, gammas = [], []
-        for q in qs:  # numpy's "linear" quantile: virtual index (n - 1) q, neighbours floor / floor + 1
-            vi = (n - 1) * q
-            lo = int(np.floor(vi))
-            ranks += [lo, min(lo + 1, n - 1)]
-            gammas.append(vi - lo)
+        for q in qs:
+            lo, hi, gamma = linear_quantile_index(n, q)
+            ranks += [lo, hi]
+            gammas.append(gamma)
         with _lib.AlignStats(len(segs), n, device=device) as st:
             st.add(pose)
             order = st.finish(ranks)                                                                  # (L, 7, 4)

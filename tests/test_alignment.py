@@ -188,3 +188,24 @@ def test_alignment_statistics_on_gpu(df3d, hiplib):
     assert np.array_equal(whole[legs.index("RM"), 1], srt[ranks])
     lengths = np.sort(np.linalg.norm(np.diff(raw["LH_leg"], axis=1), axis=2)[:, 2])
     assert np.array_equal(whole[legs.index("LH"), 5], lengths[ranks])
+
+
+def test_linear_quantile_index_equals_numpy_for_every_n():
+    """the GPU path must interpolate between the same two order statistics with the same gamma as
+    np.quantile.  On the series 0, 1, ..., n-1 the quantile is the virtual index itself, so numpy's own result exposes
+    both: checked for every n up to 3000 and for large recordings.  (The installed numpy 2.2 evaluates the "linear"
+    method as (n - 1) q; the helper asks numpy's own method table, so another numpy's expression is followed too.)"""
+    from seqikpy_amd.alignment import linear_quantile_index
+
+    def lerp(a, b, g):  # numpy.lib._function_base_impl._lerp
+        r = a + (b - a) * g
+        return b - (b - a) * (1 - g) if g >= 0.5 else r
+
+    ns = list(range(1, 3001)) + [6000, 99991, 1_000_000, 10_000_019, 2**31 - 1]
+    for n in ns:
+        for q in (0.45, 0.55, 0.5 - 0.05, 0.5 + 0.05, 0.0, 1.0):
+            lo, hi, g = linear_quantile_index(n, q)
+            assert 0 <= lo <= hi <= n - 1 and 0.0 <= g < 1.0
+            if n <= 100_000:
+                want = np.quantile(np.arange(n, dtype=np.float64), q)
+                assert lerp(float(lo), float(hi), g) == want, (n, q)

@@ -12,6 +12,8 @@ recording and for samples of the benchmark's synthetic workload (config 3, i.i.d
     E   the C restatement with the zero Jacobian columns KEPT as exact-zero singular values in stages 2-3 too
         (oracle_set_null_mode(1): scipy's m < n "never full rank" logic, deterministic -- the candidate for reaching
         scipy's damped stage-2/3 path without LAPACK's null-space garbage)
+    F   (anipose LF only) real scipy with the link matrices of the forward kinematics multiplied right to left instead
+        of left to right -- the same product, another rounding (SURVEY.md 7.4's "noise floor" experiment)
 
 and reports (i) trajectory agreement (share of leg-frames with all seven angles within 1e-4 rad) for A~B (the
 reference's own reproducibility), C~A, C~D, E~A; (ii) ONE-STEP agreement per stage: every (frame, stage) solve repeated
@@ -98,6 +100,21 @@ def scipy_run(pose, seg, bounds, seeds, leg, one_step_oracle=None, one_step_ulp=
     return dict(angles=angles, nfev=nfev, c1=c1, b1=b1, cost=cost_a, cost_c1=cost_c1)
 
 
+def fk_right_to_left(self, joints, full_kinematics=False):
+    """Chain.forward_kinematics of the IKPy stand-in with the product associated from the right."""
+    mats = [l.get_link_frame_matrix(t) for l, t in zip(self.links, joints)]
+    if full_kinematics:
+        out, f = [], np.eye(4)
+        for m in mats:
+            f = np.dot(f, m)
+            out.append(f)
+        return out
+    f = mats[-1]
+    for m in reversed(mats[:-1]):
+        f = np.dot(m, f)
+    return f
+
+
 def chain_task(args):
     """All runs of one chain (one leg of one recording / sequence)."""
     name, leg, pose, seg, bounds, seeds, golden = args
@@ -112,7 +129,17 @@ def chain_task(args):
     c_oracle.lib().oracle_set_null_mode(1)
     E = c_oracle.seq_leg(pose, seg, bounds, seeds)
     c_oracle.lib().oracle_set_null_mode(-1)
-    return dict(name=name, leg=leg, A=A["angles"], B=B["angles"], C=C["angles"], D=D["angles"], E=E["angles"],
+    F = None
+    if name == "anipose_shipped" and leg == "LF":
+        from oracle import scipy_oracle
+        from ikpy.chain import Chain
+        orig = Chain.forward_kinematics
+        Chain.forward_kinematics = fk_right_to_left
+        try:
+            F = scipy_oracle.seq_leg_arrays(pose[:340], seg, bounds, seeds, leg)["angles"]
+        finally:
+            Chain.forward_kinematics = orig
+    return dict(name=name, leg=leg, F=F, A=A["angles"], B=B["angles"], C=C["angles"], D=D["angles"], E=E["angles"],
                 nfev_A=A["nfev"], nfev_C=C["nfev"], nfev_E=E["nfev"], c1=A["c1"], b1=A["b1"],
                 cost_a=A["cost"], cost_c1=A["cost_c1"], golden=golden)
 
@@ -187,6 +214,10 @@ def frame_detail(rows, name, leg, lo, hi):
     g = r["golden"]
     pairs = {"scipy_vs_shipped_or_fixture": (r["A"], g), "scipy_plus_1ulp_vs_scipy": (r["B"], r["A"]),
              "c_vs_shipped_or_fixture": (r["C"], g), "c_vs_scipy": (r["C"], r["A"]), "c_plus_1ulp_vs_c": (r["D"], r["C"])}
+    if r.get("F") is not None:  # the right-to-left run covers the first frames only (they include the episode)
+        n = len(r["F"])
+        pairs["scipy_fk_right_to_left_vs_shipped"] = (r["F"], g[:n])
+        pairs["scipy_fk_right_to_left_vs_scipy"] = (r["F"], r["A"][:n])
     out = {}
     for k, (x, y) in pairs.items():
         bad = np.where(~agree(x[lo:hi], y[lo:hi]))[0] + lo
