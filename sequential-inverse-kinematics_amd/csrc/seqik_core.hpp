@@ -843,6 +843,8 @@ struct PipeLane {
     int *produced_in, *consumed_in; // counters of the boundary in front of this stage
     int *produced_out, *consumed_out;
     int lane_stride;                // lanes interleaved in LDS (bank-conflict free)
+    int base;                       // frames this lane's four waves have put through the ring before this chain
+                                    // (a lane that solves several chains in turn keeps counting)
 };
 
 SEQIK_HD int pipe_load(const int *p)
@@ -982,7 +984,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             // may this lane start frame t?  (only asked at a frame boundary; a lane in the middle of a solve runs on)
             bool stall = false;
             if (new_solve) {
-                const int i = (int)(t - t_first);
+                const int i = io.pipe.base + (int)(t - t_first);
                 if constexpr (STAGE > 1) stall = pipe_load(io.pipe.produced_in) <= i;
                 if constexpr (HANDOFF) stall = stall || (pipe_load(io.pipe.consumed_out) + PIPE_DEPTH <= i);
             }
@@ -1014,7 +1016,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if constexpr (FROM_ANGLES) {
                     build_prefix<STAGE>(P.pre, lc, io.angles + t * io.ang_frame, io.ang_dof, WANT_FK ? coxa_end : nullptr);
                 } else if constexpr (PIPED) {
-                    const int fi = (int)(t - t_first);
+                    const int fi = io.pipe.base + (int)(t - t_first);
                     const double *w = io.pipe.ring_in + (fi % PIPE_DEPTH) * 12 * io.pipe.lane_stride;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) P.pre.r[i] = w[i * io.pipe.lane_stride];
@@ -1201,7 +1203,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 Frame after;  // frame after the active links at the solution
                 frame_after_active<STAGE>(P, sa, ca, sb, cb, after);
                 if constexpr (HANDOFF && PIPED) {
-                    const int fi = (int)(t - t_first);
+                    const int fi = io.pipe.base + (int)(t - t_first);
                     double *w = io.pipe.ring_out + (fi % PIPE_DEPTH) * 12 * io.pipe.lane_stride;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) w[i * io.pipe.lane_stride] = after.r[i];

@@ -283,10 +283,12 @@ struct PipeShared {
 };
 
 template <bool WANT_FK, bool CHUNK_SPEC_MODE>
-__device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane)
+__device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane,
+                                         int base = 0)
 {
     seqik::PipeLane &pl = io.pipe;
     pl.lane_stride = 64;
+    pl.base = base;
     pl.ring_in = stage_wave > 0 ? &sh.ring[stage_wave - 1][0][0][lane] : nullptr;
     pl.produced_in = stage_wave > 0 ? &sh.produced[stage_wave - 1][lane] : nullptr;
     pl.consumed_in = stage_wave > 0 ? &sh.consumed[stage_wave - 1][lane] : nullptr;
@@ -543,9 +545,10 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
 // The speculative pass of a chunked call on the stage pipeline (seqik_pipe_kernel): a workgroup of four waves per group
 // of chunks.  In a workgroup the stage-1 wave of a chunk runs at most PIPE_DEPTH frames ahead of its stage-2 wave; all
 // four store into the chunk's rows / start_state exactly what the lane-per-chunk kernel stores.
-template <bool WANT_FK>
+template <bool WANT_FK, int mode>
 __global__ void __launch_bounds__(256) seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
 {
+    static_assert(mode == CHUNK_SPEC || mode == CHUNK_REPAIR, "the sweep stays on the lane-per-chunk kernel");
     __shared__ seqik::LegConst s_legs[kMaxLegs];
     __shared__ PipeShared sh;
     {
@@ -557,13 +560,31 @@ __global__ void __launch_bounds__(256) seqik_chunk_pipe_kernel(KernelArgs a, Chu
     }
     __syncthreads();
     const int stage_wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int64_t vc;
-    int leg;
-    if (!chain_of_wave_lane(blockIdx.x, lane, ca.n_vseq, a.n_legs, a.lanes_per_wave, a.leg_order, vc, leg)) return;
-    seqik::ChainIO io;
-    chunk_io(a, ca, vc, leg, true, io);
-    // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
-    pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane);
+    if (mode == CHUNK_SPEC) {
+        int64_t vc;
+        int leg;
+        if (!chain_of_wave_lane(blockIdx.x, lane, ca.n_vseq, a.n_legs, a.lanes_per_wave, a.leg_order, vc, leg)) return;
+        seqik::ChainIO io;
+        chunk_io(a, ca, vc, leg, true, io);
+        // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
+        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane);
+    } else {
+        // the work list of round ca.round, spread over the workgroups as thinly as possible; the four stage waves of a
+        // workgroup walk the same entries in the same order (the ring counters of a lane keep counting across entries)
+        const int64_t n_items = ca.ctrl[ca.round].count, n_groups = gridDim.x;
+        int64_t W = (n_items + n_groups - 1) / n_groups;
+        W = W < 1 ? 1 : (W > 64 ? 64 : W);
+        const int cl = lane / lane_replication((int)W);
+        int base = 0;
+        for (int64_t cursor = (cl < W) ? (int64_t)blockIdx.x * W + cl : n_items; cursor < n_items; cursor += n_groups * W) {
+            const int64_t vc = ca.worklist[cursor];
+            const int leg = (int)(vc % a.n_legs);
+            seqik::ChainIO io;
+            chunk_io(a, ca, vc, leg, false, io);
+            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, base);
+            base += (int)(io.n_frames - io.t_begin);
+        }
+    }
 }
 
 // zeroes the control block / statistics of a chunked call (first thing on the stream)
@@ -963,8 +984,8 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
         if (piped) {
-            if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true>), pipe_grid, pipe_blk, 0, stream, a, ca);
-            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SPEC>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SPEC>), pipe_grid, pipe_blk, 0, stream, a, ca);
         } else if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         HIP_TRY(hipGetLastError());
@@ -974,7 +995,11 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         for (int r = 0; r <= ca.n_rounds; ++r) {
             ca.round = r;
             hipLaunchKernelGGL(seqik_chunk_scan_kernel, scan_grid, scan_blk, 0, stream, a, ca);
-            if (r < ca.n_rounds) {
+            if (r < ca.n_rounds && piped) {
+                const dim3 rep_pipe_grid((unsigned)(n_waves < 1024 ? n_waves : 1024));
+                if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_REPAIR>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_REPAIR>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+            } else if (r < ca.n_rounds) {
                 if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
                 else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
             } else {  // serial sweep: one wave per real chain

@@ -58,7 +58,8 @@ class SeqikStream:
 
     def __init__(self, legs: List[_lib.SeqikLegParams], slab_seq: int, n_frames: int, affine=None, layout=None,
                  want_fk: bool = True, n_slots: int = 3, carry: bool = False, generic: bool = False,
-                 device: int = -1, block_size: int = 0):
+                 device: int = -1, block_size: int = 0, frame_chunk: int = 0, frame_halo: int = 0,
+                 chunk_tol: float = 0.0):
         self._lib = _lib.load()
         self.n_legs = len(legs)
         self.slab_seq, self.n_frames = int(slab_seq), int(n_frames)
@@ -67,6 +68,10 @@ class SeqikStream:
         opt = _lib.SeqikOptions()
         opt.device = device
         opt.block_size = block_size
+        # frame chunks inside every slab (SeqikOptions.frame_chunk): with carry=True and ONE long recording per slab
+        # (slab_seq = 1) this is BASELINE config 5 read literally -- a 10 M-frame recording streamed in time slabs, each
+        # slab cut into chunks on the device, its first chunk warm-started from the carried last frame of the slab before
+        opt.frame_chunk, opt.frame_halo, opt.chunk_tol = int(frame_chunk), int(frame_halo), float(chunk_tol)
         rc = self._lib.seqik_stream_open(ctypes.byref(self._handle), self.n_legs,
                                          (_lib.SeqikLegParams * self.n_legs)(*legs),
                                          _lib._affine_array(affine, self.n_legs), self.slab_seq, self.n_frames,
@@ -153,9 +158,11 @@ def solve_streamed(pose: np.ndarray, legs, slab_seq: int, affine=None, want_fk: 
 
 
 def solve_streamed_in_time(pose: np.ndarray, legs, slab_frames: int, affine=None, want_fk: bool = True,
-                           n_slots: int = 3, device: int = -1):
+                           n_slots: int = 3, device: int = -1, frame_chunk: int = 0):
     """``pose (S, L, N, 5, 3)`` pushed through a carried stream in slabs of ``slab_frames`` frames (the S
-    recordings advance in lock step).  Equal to ``_lib.solve_seq(pose, ...)`` bit for bit."""
+    recordings advance in lock step).  Equal to ``_lib.solve_seq(pose, ...)`` bit for bit with ``frame_chunk = 0``;
+    with frame chunks (-1 = automatic) every slab is cut into concurrently solved chunks on the device (a few long
+    recordings then fill the GPU) and the result equals the serial walk to about the chunk tolerance."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     _lib._check_finite(pose)
     S, L, N = pose.shape[:3]
@@ -164,7 +171,8 @@ def solve_streamed_in_time(pose: np.ndarray, legs, slab_frames: int, affine=None
     T = min(slab_frames, N)
     n_full = N // T if T else 0
     if n_full:
-        with SeqikStream(legs, S, T, affine=affine, want_fk=want_fk, n_slots=n_slots, carry=True, device=device) as st:
+        with SeqikStream(legs, S, T, affine=affine, want_fk=want_fk, n_slots=n_slots, carry=True, device=device,
+                         frame_chunk=frame_chunk) as st:
             bufs = []
             for k in range(n_full):
                 sl = slice(k * T, (k + 1) * T)
@@ -180,7 +188,8 @@ def solve_streamed_in_time(pose: np.ndarray, legs, slab_frames: int, affine=None
     t0 = n_full * T
     if t0 < N:  # a shorter last piece: one direct call, continued from the last streamed frame
         rest = _lib.solve_seq(pose[:, :, t0:], legs, want_fk=want_fk, affine=affine, device=device,
-                              init_angles=np.ascontiguousarray(angles[:, :, t0 - 1]) if t0 else None)
+                              init_angles=np.ascontiguousarray(angles[:, :, t0 - 1]) if t0 else None,
+                              frame_chunk=frame_chunk)
         angles[:, :, t0:] = rest["angles"]
         if want_fk:
             fk[:, :, t0:] = rest["fk"]

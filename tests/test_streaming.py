@@ -168,3 +168,24 @@ def test_generic_chains_through_the_stream(lib):
         st.submit(np.ascontiguousarray(seqs[1:]), a1)
         st.wait()
     assert np.array_equal(a0, ref["angles"][:1]) and np.array_equal(a1, ref["angles"][1:])
+
+
+@pytest.mark.gpu
+def test_one_recording_streamed_in_time_slabs_with_frame_chunks(hiplib):
+    """BASELINE config 5 read literally: ONE long recording streamed in time slabs (carried warm start), every slab cut
+    into frame chunks on the device.  Equal to the serial walk to the chunk tolerance's noise floor, and the chunked
+    slabs really are chunked (a slab's first chunk continues bit-identically from the carried state)."""
+    from conftest import load_golden
+    from seqikpy_amd.streaming import solve_streamed_in_time
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]           # (1, 6, 1000, 5, 3)
+    serial = hiplib.solve_seq(pose, params)
+    exact = solve_streamed_in_time(pose, params, slab_frames=256)   # 3 slabs of 256 + a rest of 232: bit-exact
+    assert np.array_equal(exact["angles"], serial["angles"]) and np.array_equal(exact["fk"], serial["fk"])
+    chunked = solve_streamed_in_time(pose, params, slab_frames=256, frame_chunk=-1)
+    assert np.abs(chunked["angles"] - serial["angles"]).max() < 2e-5
+    assert np.abs(chunked["fk"] - serial["fk"]).max() < 2e-5
+    assert np.array_equal(chunked["angles"][:, :, :8], serial["angles"][:, :, :8])        # chunk 0 of slab 0
+    assert not np.array_equal(chunked["angles"], serial["angles"])                         # ... and the rest is chunked
