@@ -1,6 +1,7 @@
 // seqik_head.hip -- head / antenna angle kernel and its C ABI entry points (include/seqik.h).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "seqik_head.hpp"
 #include "seqik_device_scope.hpp"
@@ -45,7 +46,8 @@ int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int
     a.rest_head_pitch = rest_head_pitch; a.rest_antenna_pitch = rest_antenna_pitch;
     a.angles = d_angles; a.n_frames = n_frames; a.compute_ant = compute_ant;
     int64_t blocks = (n_frames + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride beyond 8 blocks per CU
+    static const int per_cu = getenv("SEQIK_HEAD_BLOCKS_PER_CU") ? atoi(getenv("SEQIK_HEAD_BLOCKS_PER_CU")) : 8;
+    if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;  // grid-stride beyond per_cu blocks per CU
     hipLaunchKernelGGL(seqik_head_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
     HTRY(hipGetLastError());
     return SEQIK_OK;

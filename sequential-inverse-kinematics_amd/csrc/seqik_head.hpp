@@ -14,27 +14,97 @@
 
 namespace seqik {
 
+// 1 / sqrt(v) and 1 / q without the IEEE corner-case handling of the compiler's division / square-root expansions (34
+// and 12 instructions): hardware seed + three Newton steps, ~1 ulp, 11 / 7 instructions.  Host builds (tests/harness) use
+// the plain expressions.
+SEQIK_HD double inv_sqrt(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(v);
+    const double h = 0.5 * v;
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);   // the seed is good to ~2^-10: three steps for ~1 ulp
+    return y;
+#else
+    return 1.0 / sqrt(v);
+#endif
+}
+
+SEQIK_HD double inv(double q)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(q);
+    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
+    return r;
+#else
+    return 1.0 / q;
+#endif
+}
+
+// acos for |x| <= 1 (the callers clamp).  The classic fdlibm scheme -- acos(x) = pi/2 - (x + x z R(z)) with z = x^2 for
+// |x| <= 1/2, 2 (s + s z R(z)) with z = (1 - |x|) / 2, s = sqrt(z) otherwise, R = P / Q a (6, 4) rational -- evaluated
+// branch-free: ONE rational for both ranges, selects at the end, without fdlibm's last-bit correction of the square
+// root (<= 2 ulp instead of < 1 ulp; the angles are compared at 1e-9 rad).  57 vector instructions instead of the 93 of
+// the device library's acos, seven times per frame: this kernel is meant to be bound by HBM, not by its arithmetic.
+SEQIK_HD double acos_unit(double x)
+{
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17,
+                 PI = 3.14159265358979311600e+00;
+    const double P0 = 1.66666666666666657415e-01, P1 = -3.25565818622400915405e-01, P2 = 2.01212532134862925881e-01,
+                 P3 = -4.00555345006794114027e-02, P4 = 7.91534994289814532176e-04, P5 = 3.47933107596021167570e-05,
+                 Q1 = -2.40339491173441421878e+00, Q2 = 2.02094576023350569471e+00, Q3 = -6.88283971605453293030e-01,
+                 Q4 = 7.70381505559019352791e-02;
+    const double a = fabs(x);
+    const bool small = a <= 0.5;
+    const double z = small ? x * x : (1.0 - a) * 0.5;
+    const double p = z * (P0 + z * (P1 + z * (P2 + z * (P3 + z * (P4 + z * P5)))));
+    const double q = 1.0 + z * (Q1 + z * (Q2 + z * (Q3 + z * Q4)));
+    const double r = p * inv(q);          // q in [0.6, 1]
+    const double s = z * inv_sqrt(z + 1e-300);  // sqrt(z), z in [0, 1/4] (the tiny offset keeps z = 0 finite)
+    const double w = s + r * s;
+    const double big = (x > 0.0) ? 2.0 * w : PI - 2.0 * (w - PIO2_LO);
+    const double sm = PIO2_HI - (x - (PIO2_LO - x * r));
+    return small ? sm : big;
+}
+
 // angle_between_segments (:163-178): acos of the normalised dot product, signed by
 // det([rot_axis, v1, v2]) = rot_axis . (v1 x v2).  The reference normalises both vectors component by
 // component (6 divisions, 2 square roots); here cos = (v1 . v2) / sqrt(|v1|^2 |v2|^2) -- one division,
-// one square root, the same value up to ~1 ulp -- because this kernel should be bound by HBM, not by
-// FP64 division throughput.
-SEQIK_HD double signed_angle(const double *v1, const double *v2, int rot_axis)
+// one square root, the same value up to ~1 ulp.  Every call of the reference works on vectors PROJECTED on a
+// coordinate plane and rotates about that plane's normal, so the functions below take the two in-plane components
+// (the third one is an exact zero whose products and sums change nothing: same bits as the 3-vector form).
+//   planar_angle(a0, a1, b0, b1): vectors (a0, a1), (b0, b1) in the plane, det = a0 b1 - a1 b0
+SEQIK_HD double planar_angle(double a0, double a1, double b0, double b1)
 {
-    double n1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
-    double n2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
-    double d = (v1[0] * v2[0] + v1[1] * v2[1] + v1[2] * v2[2]) / sqrt(n1 * n2);
-    double det;
-    if (rot_axis == 0) det = v1[1] * v2[2] - v1[2] * v2[1];
-    else if (rot_axis == 1) det = v1[2] * v2[0] - v1[0] * v2[2];
-    else det = v1[0] * v2[1] - v1[1] * v2[0];
+    const double n1 = a0 * a0 + a1 * a1;
+    const double n2 = b0 * b0 + b1 * b1;
+    double d = (a0 * b0 + a1 * b1) * inv_sqrt(n1 * n2);
+    const double det = a0 * b1 - a1 * b0;
     d = fmin(1.0, fmax(-1.0, d));  // guard the last-ulp overshoot of the fused normalisation
-    double a = acos(d);
-    return (det > 0) ? a : -a;
+    const double ang = acos_unit(d);
+    return (det > 0) ? ang : -ang;
+}
+
+//   axis_angle(b_along, b_across): first vector = the unit axis the plane's first coordinate runs along,
+//   second = (b_along, b_across): cos = b_along / |b|, det = b_across.  Also hands back cos / sin of the SIGNED angle
+//   (b_along / |b|, b_across / |b|), which is all the derotation by the head roll needs.
+SEQIK_HD double axis_angle(double b_along, double b_across, double *cos_out = nullptr, double *sin_out = nullptr)
+{
+    const double n2 = b_along * b_along + b_across * b_across;
+    const double rn = inv_sqrt(n2);
+    const double d = fmin(1.0, fmax(-1.0, b_along * rn));
+    if (cos_out) { *cos_out = d; *sin_out = b_across * rn; }
+    const double ang = acos_unit(d);
+    return (b_across > 0) ? ang : -ang;
 }
 
 // derotate_vector (:330-333): scipy Rotation.from_euler("x", -roll).apply(v), i.e. the rotation
-// matrix of the unit quaternion (sin(-roll/2), 0, 0, cos(-roll/2)); m11 / two_xw are computed once per frame
+// matrix of the unit quaternion (sin(-roll/2), 0, 0, cos(-roll/2)): m11 = cos(roll), two_xw = -sin(roll).  The roll is
+// the signed angle between the Y axis and (hor_y, hor_z), so its cosine and sine are hor_y / |.| and hor_z / |.| -- no
+// trigonometric function needed (the reference goes through sin / cos of roll / 2; same values to ~2e-16)
 SEQIK_HD void derotate_x(double m11, double two_xw, const double *v, double *out)
 {
     out[0] = v[0];
@@ -61,25 +131,20 @@ SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
     double hor[3] = {lb[0] - rb[0], lb[1] - rb[1], lb[2] - rb[2]};            // R base -> L base
     double mid[3] = {(rb[0] + lb[0]) * 0.5 - neck[0], (rb[1] + lb[1]) * 0.5 - neck[1],
                      (rb[2] + lb[2]) * 0.5 - neck[2]};                        // neck -> mid antenna base
-    const double X[3] = {1.0, 0.0, 0.0}, Y[3] = {0.0, 1.0, 0.0};
-    double v[3];
-    // head roll (:196-210): Y axis -> horizontal vector projected on the transverse plane, about X
-    v[0] = 0.0; v[1] = hor[1]; v[2] = hor[2];
-    double roll = signed_angle(Y, v, 0);
-    // head pitch (:180-194): X axis -> mid vector projected on the sagittal plane, about Y
-    v[0] = mid[0]; v[1] = 0.0; v[2] = mid[2];
-    double pitch = signed_angle(X, v, 1) + a.rest_head_pitch;
-    // head yaw (:212-226): Y axis -> horizontal vector projected on the frontal plane, about Z
-    v[0] = hor[0]; v[1] = hor[1]; v[2] = 0.0;
-    double yaw = signed_angle(Y, v, 2);
+    // head roll (:196-210): Y axis -> horizontal vector projected on the transverse (y, z) plane, about X:
+    //   det([X, Y, v]) = v_z
+    double cos_roll, sin_roll;
+    const double roll = axis_angle(hor[1], hor[2], &cos_roll, &sin_roll);
+    // head pitch (:180-194): X axis -> mid vector projected on the sagittal (z, x) plane, about Y: det([Y, X, v]) = -v_z
+    const double pitch = axis_angle(mid[0], -mid[2]) + a.rest_head_pitch;
+    // head yaw (:212-226): Y axis -> horizontal vector projected on the frontal (x, y) plane, about Z: det([Z, Y, v]) = -v_x
+    const double yaw = axis_angle(hor[1], -hor[0]);
     const int64_t n = a.n_frames;
     a.angles[t] = roll;
     a.angles[n + t] = pitch;
     a.angles[2 * n + t] = yaw;
     if (!a.compute_ant) return;
-    const double hh = -roll * 0.5;
-    const double qx = sin(hh), qw = cos(hh);
-    const double m11 = qw * qw - qx * qx, two_xw = 2.0 * (qx * qw);
+    const double m11 = cos_roll, two_xw = -sin_roll;
     double hor_d[3];
     derotate_x(m11, two_xw, hor, hor_d);
     for (int side = 0; side < 2; ++side) {  // 0 = L, 1 = R (the reference's dict order)
@@ -89,15 +154,12 @@ SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
         double ant_d[3], head_d[3];
         derotate_x(m11, two_xw, ant, ant_d);
         derotate_x(m11, two_xw, head, head_d);
-        // antenna yaw (:262-291): antenna vs horizontal head vector, both on the transverse plane, about X
-        double a1[3] = {0.0, ant_d[1], ant_d[2]};
-        double h1[3] = {0.0, hor_d[1], hor_d[2]};
-        double ayaw = signed_angle(a1, h1, 0);
+        // antenna yaw (:262-291): antenna vs horizontal head vector, both on the transverse (y, z) plane, about X
+        double ayaw = planar_angle(ant_d[1], ant_d[2], hor_d[1], hor_d[2]);
         if (side == 1) ayaw = PI - ayaw;
-        // antenna pitch (:228-260): head vector vs antenna, both on the sagittal plane, about Y
-        double a2[3] = {ant_d[0], 0.0, ant_d[2]};
-        double h2[3] = {head_d[0], 0.0, head_d[2]};
-        double apitch = signed_angle(h2, a2, 1) - a.rest_antenna_pitch;
+        // antenna pitch (:228-260): head vector vs antenna, both on the sagittal plane, about Y:
+        //   det([Y, h, a]) = h_z a_x - h_x a_z  (plane coordinates (z, x))
+        const double apitch = planar_angle(head_d[2], head_d[0], ant_d[2], ant_d[0]) - a.rest_antenna_pitch;
         a.angles[(3 + 2 * side) * n + t] = ayaw;
         a.angles[(4 + 2 * side) * n + t] = apitch;
     }
