@@ -1,5 +1,8 @@
-"""Frame-parallel solve of LONG recordings ("sharding by frame within one
-sequence").
+"""Frame-parallel solve of LONG recordings, HOST-ORCHESTRATED (round 1).  Superseded by the library's frame chunks
+(``SeqikOptions.frame_chunk``, include/seqik.h: the same speculate / verify / repair scheme entirely on the device, no host
+round trips, 7x faster on the shipped recordings) -- ``LegInvKinSeq.run_ik_and_fk`` and ``frame_sharding`` use those.
+Kept as a reference implementation of the scheme in ~100 lines of numpy ("sharding by frame within
+one sequence").
 
 The reference walks a recording serially because frame t is warm-started from frame t-1
 (``seqikpy/leg_inverse_kinematics.py:272``).  One lane per (recording, leg) therefore leaves a GPU

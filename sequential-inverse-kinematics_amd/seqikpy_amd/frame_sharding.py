@@ -3,11 +3,12 @@
 
 The reference walks a recording serially: frame t is warm-started from frame t-1
 (``seqikpy/leg_inverse_kinematics.py:272``), so contiguous frame slabs on different ranks are coupled through
-one 7-angle state per leg at every slab boundary.  The scheme is the frame-parallel mode's (``frame_parallel.py``)
-one level up:
+one 7-angle state per leg at every slab boundary.  The scheme is the library's frame chunks
+(``SeqikOptions.frame_chunk``, include/seqik.h) one level up:
 
-1. every rank solves its slab ``[a_r, b_r)`` with ``solve_frame_parallel``; ranks > 0 start ``halo`` frames early
-   from the seeds (speculation: on well-posed data the solver forgets its start point within a few frames);
+1. every rank solves its slab ``[a_r, b_r)`` in ONE library call with frame chunks (speculation, verification and
+   repair of the chunks inside the slab happen on its GPU); ranks > 0 start ``halo`` frames early from the seeds
+   (speculation: on well-posed data the solver forgets its start point within a few frames);
 2. the ranks exchange their end states (one tiny all-gather: ``world x S x L x 7`` doubles) and each rank compares
    the state its run-in reached with the true end state of its left neighbour;
 3. a rank whose boundary disagrees by more than ``tol`` re-solves its slab from the true state (``init_angles``,
@@ -23,7 +24,7 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
-from .frame_parallel import solve_frame_parallel
+from . import _lib
 from .sharding import all_gather_rows, partition
 
 
@@ -48,16 +49,22 @@ def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 32, halo: int
     lead = min(halo, a) if rank > 0 else 0
     dev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
+    # chunks inside the slab: the library's frame chunks; tol = 0 asks for exactness there too
+    chunk_kw = dict(frame_chunk=int(chunk), frame_halo=max(int(halo), 1), chunk_tol=float(tol) if tol > 0 else -1.0)
+
     def local_solve(init):
+        """The slab from the seeds with a run-in of ``lead`` frames (init None), or from the true state of the left
+        neighbour.  Returns the slab's results and the state the run-in reached just before frame a."""
         st = {}
         if b <= a:
             return dict(angles=np.zeros((S, L, 0, 7)), fk=np.zeros((S, L, 0, 9, 3)) if want_fk else None), st
-        if init is None:
-            out = solve_frame_parallel(pose[:, :, a - lead:b], legs, chunk, halo, tol, want_fk, affine, device, st, lead=lead)
-        else:
-            out = solve_frame_parallel(pose[:, :, a:b], legs, chunk, halo, tol, want_fk, affine, device, st,
-                                       init_angles=init)
-        return out, st
+        first = a - lead if init is None else a
+        res = _lib.solve_seq(np.ascontiguousarray(pose[:, :, first:b]), legs, want_fk=want_fk, affine=affine, device=device,
+                             init_angles=init, **chunk_kw)
+        off = a - first
+        st["start_state0"] = res["angles"][:, :, off - 1].copy() if off > 0 else None
+        st["chunk_stats"] = res.get("chunk_stats")
+        return dict(angles=res["angles"][:, :, off:], fk=res["fk"][:, :, off:] if want_fk else None), st
 
     out, st = local_solve(None)
     start_state = st.get("start_state0")          # what the run-in reached just before frame a (None on rank 0)
@@ -96,6 +103,6 @@ def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 32, halo: int
     angles = gather(out["angles"], (7,))
     fk = gather(out["fk"], (9, 3)) if want_fk else None
     if stats is not None:
-        stats.update(slab=(a, b), lead=lead, boundary_rounds=rounds, slab_resolved=resolved, **{f"local_{k}": v for k, v in st.items()
-                                                                                               if k != "start_state0"})
+        stats.update(slab=(a, b), lead=lead, boundary_rounds=rounds, slab_resolved=resolved,
+                     local_chunk_stats=st.get("chunk_stats"))
     return dict(angles=angles, fk=fk)

@@ -40,12 +40,20 @@ def main():
         refs = list(ex.map(ref, cases))
     t_cpu = time.perf_counter() - t0
     bad, t_gpu = [], 0.0
+    paths = [0, 0, 0, 0]
     for g0 in range(0, args.cases, 8):       # 8 different legs per launch (the ABI's maximum)
         grp = cases[g0:g0 + 8]
         pose = np.stack([c[0] for c in grp])[None]
         params = [_lib.leg_params_from_arrays(c[1], c[2], c[3]) for c in grp]
+        # every launch path in turn: one launch per stage with diagnostics, the stage pipeline (what the library picks
+        # for a call this small), the fused lane-per-chain kernel, and frame chunks that only accept bit-identical
+        # run-ins (everything is then re-solved from the true state by the repair rounds and the sweep: == serial walk)
+        mode = (g0 // 8) % 4
+        kw = [dict(want_diag=True), dict(pipeline=2), dict(pipeline=1),
+              dict(frame_chunk=8, frame_halo=3, chunk_tol=-1.0, chunk_rounds=2)][mode]
+        paths[mode] += 1
         t0 = time.perf_counter()
-        out = _lib.solve_seq(pose, params, want_fk=True, want_diag=(g0 // 8) % 2 == 0)   # both launch paths
+        out = _lib.solve_seq(pose, params, want_fk=True, **kw)
         t_gpu += time.perf_counter() - t0
         for i in range(len(grp)):
             r = refs[g0 + i]
@@ -57,6 +65,8 @@ def main():
     nf = np.stack([r["nfev"] for r in refs])
     print(json.dumps({"cases": args.cases, "frames_per_case": args.frames, "leg_frames": args.cases * args.frames,
                       "mismatching_cases": len(bad), "first_mismatches": bad[:10],
+                      "launches_by_path": {"one launch per stage + diagnostics": paths[0], "stage pipeline": paths[1],
+                                           "fused lane per chain": paths[2], "frame chunks, exact tolerance": paths[3]},
                       "status_histogram": {int(v): int((np.stack([r["status"] for r in refs]) == v).sum())
                                            for v in range(0, 5)},
                       "max_nfev": int(nf.max()), "cpu_oracle_seconds": t_cpu, "gpu_seconds_incl_transfers": t_gpu}))
