@@ -98,10 +98,17 @@ class SeqikStream:
         for name, a in (("pose", pose), ("angles", angles), ("fk", fk)):
             if a is not None and (a.dtype != np.float64 or not a.flags.c_contiguous):
                 raise ValueError(f"{name} must be a C-contiguous float64 array")
-        n_seq = pose.shape[0]
         per_seq = self.n_legs * self.n_frames
-        if pose.size != n_seq * per_seq * 15 or angles.size != n_seq * per_seq * 7:
-            raise ValueError("pose / angles do not hold n_seq x n_legs x n_frames leg-frames")
+        if self.layout is not None:
+            # custom layout: a slab is the contiguous block of n_seq * n_legs chain strides (include/seqik.h)
+            pc, ac = int(self.layout.pose_chain) * self.n_legs, int(self.layout.ang_chain) * self.n_legs
+            n_seq = pose.size // pc
+            if n_seq * pc != pose.size or angles.size != n_seq * ac:
+                raise ValueError("pose / angles do not hold n_seq x n_legs chain strides of the stream's layout")
+        else:
+            n_seq = pose.shape[0]
+            if pose.size != n_seq * per_seq * 15 or angles.size != n_seq * per_seq * 7:
+                raise ValueError("pose / angles do not hold n_seq x n_legs x n_frames leg-frames")
         if self.want_fk and (fk is None or fk.size != n_seq * per_seq * 27):
             raise ValueError("fk must hold n_seq x n_legs x n_frames x 9 x 3 values")
         rc = self._lib.seqik_stream_submit(self._handle, ctypes.c_void_p(pose.ctypes.data), n_seq,

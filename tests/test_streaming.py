@@ -189,3 +189,34 @@ def test_one_recording_streamed_in_time_slabs_with_frame_chunks(hiplib):
     assert np.abs(chunked["fk"] - serial["fk"]).max() < 2e-5
     assert np.array_equal(chunked["angles"][:, :, :8], serial["angles"][:, :, :8])        # chunk 0 of slab 0
     assert not np.array_equal(chunked["angles"], serial["angles"])                         # ... and the rest is chunked
+
+
+@pytest.mark.gpu
+def test_stream_slots_follow_a_padded_layout_and_bad_layouts_are_rejected(lib):
+    """the device slots of a stream are sized from the caller's layout (chain stride may exceed the dense
+    size), and a layout whose key points / angles would reach outside a chain's stride is refused at open time."""
+    from seqikpy_amd.streaming import SeqikStream
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    params = _params(lib, z, legs)
+    T, S, L = 24, 3, len(legs)
+    pose = _windows(z, legs, "pose", [0, 30, 61], T)                      # (S, L, T, 5, 3)
+    ref = lib.solve_seq(pose, params, want_fk=True)
+    pad_p, pad_a = 15 * T + 40, 7 * T + 24                                # padded chain strides (doubles)
+    lay = lib.SeqikLayout(pad_p, 3 * T, 3, pad_a, T, 1)                   # planar inside a padded chain block
+    hp = np.full((S * L, pad_p), np.nan)
+    hp[:, :15 * T] = pose.transpose(0, 1, 3, 2, 4).reshape(S * L, 15 * T)
+    hp[:, 15 * T:] = 0.0
+    ha = np.full((S * L, pad_a), -7.0)
+    hf = np.empty((S, L, T, 9, 3))
+    with SeqikStream(params, S, T, layout=lay, want_fk=True, n_slots=2) as st:
+        for _ in range(3):                                                # slot reuse with the padded size
+            st.submit(hp, ha, hf)
+        st.wait()
+    got = ha[:, :7 * T].reshape(S, L, 7, T).transpose(0, 1, 3, 2)
+    assert np.array_equal(got, ref["angles"]) and np.array_equal(hf, ref["fk"])
+    for bad in (lib.SeqikLayout(15 * T - 1, 3 * T, 3, 7 * T, T, 1),      # last key point outside the chain stride
+                lib.SeqikLayout(15 * T, 3 * T, 3, 7 * T - 1, T, 1),      # last angle outside
+                lib.SeqikLayout(15 * T, 0, 3, 7 * T, T, 1)):             # zero stride
+        with pytest.raises(ValueError):
+            SeqikStream(params, S, T, layout=bad)
