@@ -28,6 +28,62 @@ from seqikpy_amd import _lib, data, synthetic, utils  # noqa: E402
 from seqikpy_amd.streaming import PinnedArray, SeqikStream  # noqa: E402
 
 
+def one_recording(args):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    L, T = len(legs), args.slab_frames
+    n_slabs = max(1, args.frames // T)
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    rng = np.random.default_rng(5)
+    scales = 1.0 + 0.4 * rng.random(L)
+    fixed = rng.normal(0.0, 2.0, (L, 3))
+    want_fk = not args.no_fk
+    base = np.stack([z[f"{l}_pose"] for l in legs])                                    # (L, 1000, 5, 3) aligned
+    al = np.tile(base, (1, -(-T // base.shape[1]), 1, 1))[:, :T]                        # one slab of T frames
+    tcs = [base[i, 0, 0].copy() for i in range(L)]                                      # the (constant) aligned coxa
+    affs = [_lib.make_affine(fixed[i], scales[i], tcs[i]) for i in range(L)]
+    raw = np.stack([(al[i] - tcs[i]) / scales[i] + fixed[i] for i in range(L)])        # a made-up camera frame
+    layout = _lib.planar_layout(T)
+    p = PinnedArray((1, L, 5, T, 3))
+    p.array[0] = raw.transpose(0, 2, 1, 3)
+    outs = [(PinnedArray((1, L, 7, T)), PinnedArray((1, L, T, 9, 3)) if want_fk else None) for _ in range(args.slots)]
+    with SeqikStream(params, 1, T, affine=affs, layout=layout, want_fk=want_fk, n_slots=args.slots, carry=True,
+                     frame_chunk=-1) as st:
+        for k in range(2):                                                              # warm-up
+            a, f = outs[k % args.slots]
+            st.submit(p.array, a.array, f.array if f else None)
+        st.wait()
+        st.reset_carry()
+        t0 = time.perf_counter()
+        for k in range(n_slabs):
+            a, f = outs[k % args.slots]
+            st.submit(p.array, a.array, f.array if f else None)
+        st.wait()
+        dt = time.perf_counter() - t0
+        st.reset_carry()
+        a, f = outs[0]
+        st.submit(p.array, a.array, f.array if f else None)                             # slab 0 again, from the seeds
+        st.wait()
+    n = min(T, 3000)
+    direct = _lib.solve_seq(np.ascontiguousarray(raw[None, :, :T]), params, want_fk=False, affine=affs, frame_chunk=-1)
+    serial = _lib.solve_seq(np.ascontiguousarray(raw[None, :, :n]), params, want_fk=False, affine=affs)
+    got = a.array[0].transpose(0, 2, 1)                                                 # (L, T, 7)
+    units = n_slabs * L * T
+    bytes_per = 120 + 56 + (216 if want_fk else 0)
+    print(json.dumps({"metric": "leg-IK solves/s, ONE recording streamed from host memory in time slabs (PCIe-inclusive)",
+                      "value": units / dt, "unit": "leg-frame solves/s", "n_gpus": 1, "seconds": dt, "leg_frames": units,
+                      "frames_total": n_slabs * T, "legs": L, "slabs": n_slabs, "slab_frames": T, "slots": args.slots,
+                      "data": "df3d locomotion recording (fixture) repeated, RAW key points through a made-up camera frame, "
+                              "AlignPose.align_leg fused into the kernels",
+                      "mode": "carried stream (frame 0 of a slab warm-started from the last frame of the slab before, on the "
+                              "device), frame chunks inside every slab (automatic parameters)",
+                      "outputs": "7 angles" + (" + 9x3 FK" if want_fk else ""),
+                      "pcie_GBps_total": units * bytes_per / dt / 1e9,
+                      "check": {"streamed_slab_equals_direct_chunked_call_bitwise": bool(np.array_equal(got, direct["angles"][0])),
+                                "max_abs_vs_serial_walk_first_frames": float(np.abs(got[:, :n] - serial["angles"][0]).max()),
+                                "frames_walked_serially": n}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=10_000_000)
@@ -40,7 +96,13 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare one slab with a direct solve on aligned data")
     ap.add_argument("--gpu-stats", action="store_true",
                     help="also time pass 1: AlignPose's whole-recording statistics from the RAW slabs on the GPU")
+    ap.add_argument("--one-recording", action="store_true",
+                    help="config 5 read literally: ONE recording of --frames frames x 6 legs streamed in time slabs "
+                         "(carried warm start), every slab cut into frame chunks on the device; real locomotion poses "
+                         "(the df3d fixture repeated) instead of the synthetic sequences")
     args = ap.parse_args()
+    if args.one_recording:
+        return one_recording(args)
 
     legs = data.LEGS
     L, T = len(legs), args.frames_per_seq
