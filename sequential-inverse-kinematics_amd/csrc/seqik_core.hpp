@@ -1060,9 +1060,20 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     have_pe = true;
                 }
             } else {
-                x[0] = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
-                if constexpr (NA == 2) x[1] = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
-                eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
+                // Stages 2-4: the warm start x is the previous frame's solution and (sa, ca, sb, cb) are still its
+                // sin / cos pairs (set by the trial that was accepted last, or by that solve's start evaluation);
+                // only the prefix frame has changed.  Unless make_strictly_feasible moves x the sin / cos need not be
+                // recomputed: the same function of the same argument gives the same bits.
+                const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+                const double xs1 = (NA == 2) ? strictly_feasible(x[1], lb[1], ub[1], 1e-10) : x[1];
+                if (have_pe && xs0 == x[0] && xs1 == x[1]) {
+                    residual_sc<STAGE>(P, sa, ca, sb, cb, f);
+                } else {
+                    x[0] = xs0;
+                    if constexpr (NA == 2) x[1] = xs1;
+                    eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
+                    have_pe = true;  // (stages 2-4 use the flag for "sa .. cb belong to x")
+                }
             }
             cost = 0.5 * dot3(f, f);
             nfev = 1;
