@@ -107,7 +107,11 @@ typedef struct SeqikOptions {
      * being ~5e-5); inside kinematic-singularity episodes, where the reference itself is chaotic, a
      * 1e-6 difference can pick the other branch.  frame_chunk = 0 keeps the serial walk (bit-exact). */
     int32_t frame_chunk;  /* 0 = serial (default); > 0 = frames per chunk; -1 = automatic (serial for short
-                             recordings, otherwise 8..64 frames so that the chunks fill the GPU) */
+                             recordings, otherwise 8..64 frames so that the chunks fill the GPU).  In automatic mode the
+                             host-buffer entry point also checks the speculation: if more than one chunk in eight
+                             fails its first verification (data with several equivalent leg configurations, where a
+                             run-in does not find the serial trajectory) it returns the SERIAL walk instead and
+                             reports chunk_stats[0] negative */
     int32_t frame_halo;   /* run-in frames of a speculative chunk; 0 = default (8) */
     double chunk_tol;     /* consistency tolerance in rad; 0 = default (1e-6); negative = 0 (a chunk is accepted
                              only if the run-in reproduced the true state bit for bit) */

@@ -1253,7 +1253,10 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     HostCall call;
     if ((rc = acquire_ctx(&call.ctx)) != SEQIK_OK) return rc;
     const bool want_fk = fk && last_stage == 4;
-    const bool want_stats = opt && opt->chunk_stats;
+    // automatic frame chunks keep a check on themselves (below): the statistics are needed even if the caller does
+    // not ask for them
+    const bool auto_chunks = opt && opt->frame_chunk == -1;
+    const bool want_stats = opt && (opt->chunk_stats || auto_chunks);
     const size_t n_ch = (size_t)n_seq * n_legs;
     const size_t need = ArenaCursor::padded(sizeof(double) * 15 * n_lf) + ArenaCursor::padded(sizeof(double) * 7 * n_lf) +
                         (want_fk ? ArenaCursor::padded(sizeof(double) * 27 * n_lf) : 0) +
@@ -1284,11 +1287,30 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     rc = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
                                 d_fk, d_status, d_nfev, d_init, nullptr, affine, opt ? &dev_opt : nullptr, stream);
     if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
+    int32_t h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (want_stats) {
+        TRY_OUT(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, stream));
+        TRY_OUT(hipStreamSynchronize(stream));
+        // AUTOMATIC mode only: speculation is for data on which a run-in finds the serial trajectory (real recordings:
+        // 0-2 % of the chunks fail the first verification).  When more than one chunk in eight fails it -- random poses
+        // with several equivalent leg configurations do that -- the recording has no frame-level parallelism to find and
+        // the chunked result would differ from the serial walk in which of the equivalent configurations it follows; the
+        // call then returns the serial walk (key points and options are still on the device).  chunk_stats[0] comes
+        // back NEGATIVE (minus the number of chunks tried) to say so.
+        if (auto_chunks && h_stats[0] > 0 && (int64_t)h_stats[7] * 8 > (int64_t)h_stats[0]) {
+            dev_opt.frame_chunk = 0;
+            dev_opt.chunk_stats = nullptr;
+            rc = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles, d_fk,
+                                        d_status, d_nfev, d_init, nullptr, affine, &dev_opt, stream);
+            if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
+            h_stats[0] = -h_stats[0];
+        }
+        if (opt->chunk_stats) memcpy(opt->chunk_stats, h_stats, sizeof(h_stats));
+    }
     TRY_OUT(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
     if (want_fk) TRY_OUT(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
     if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
-    if (want_stats) TRY_OUT(hipMemcpyAsync(opt->chunk_stats, d_stats, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipStreamSynchronize(stream));
     return SEQIK_OK;
 }

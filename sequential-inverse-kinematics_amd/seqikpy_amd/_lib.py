@@ -50,7 +50,8 @@ CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_r
 
 
 def chunk_stats_dict(stats):
-    """int32[8] of ``SeqikOptions.chunk_stats`` -> dict (all zero: the call ran serially)."""
+    """int32[8] of ``SeqikOptions.chunk_stats`` -> dict (all zero: the call ran serially; ``chunks`` negative: automatic
+    mode tried that many chunks, found more than one in eight inconsistent and returned the serial walk instead)."""
     return {k: int(v) for k, v in zip(CHUNK_STATS_FIELDS, stats)}
 
 

@@ -273,7 +273,10 @@ class LegInvKinSeq(LegInvKinBase):
           (``SeqikOptions.frame_chunk = -1``, include/seqik.h).  Every frame is still solved by the reference's
           algorithm from a warm start within 1e-6 rad of the serial one; the result equals the serial walk to
           ~1e-5 rad on well-posed frames (the reference's own run-to-run noise is ~5e-5 rad), 10-50x faster for
-          one recording.  Applies to runs of all four stages without diagnostics; others are walked serially.
+          one recording.  Applies to runs of all four stages without diagnostics; others are walked serially.  The
+          library checks the speculation: if more than one chunk in eight fails its first verification (poses with
+          several equivalent leg configurations) it returns the serial walk instead
+          (``frame_chunk_stats["chunks"]`` is then negative).
         * ``False``: the serial walk (bit-identical to the oracle restatement of the reference).
         * ``True`` or a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters.
 

@@ -231,3 +231,27 @@ def test_chunks_on_the_stage_pipeline_equal_model(oracle, hiplib, chunk, halo, r
     ang, fk, stats = _model_all(oracle, z, legs, sl, chunk, halo, rounds=rounds)
     assert np.array_equal(out["angles"][0], ang) and np.array_equal(out["fk"][0], fk)
     assert np.array_equal(np.array([out["chunk_stats"][k] for k in hiplib.CHUNK_STATS_FIELDS]), stats)
+
+
+@pytest.mark.gpu
+def test_automatic_chunks_give_way_to_the_serial_walk_when_speculation_fails(oracle, hiplib):
+    """Random poses that span several equivalent leg configurations: half of the run-ins end in another configuration than
+    the serial walk.  Automatic mode notices (more than one chunk in eight inconsistent at the first verification) and
+    returns the serial walk, bit for bit; explicit chunk parameters are honoured as given."""
+    from seqikpy_amd import data, synthetic, utils
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    pose = synthetic.synthetic_pose(4, 64, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION, variant="iid")
+    rec = np.ascontiguousarray(pose.transpose(1, 0, 2, 3, 4).reshape(6, 256, 5, 3))[None]      # one recording per leg
+    params = [hiplib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
+    serial = hiplib.solve_seq(rec, params)
+    auto = hiplib.solve_seq(rec, params, frame_chunk=-1)
+    assert auto["chunk_stats"]["chunks"] < 0 and auto["chunk_stats"]["inconsistent_at_first_check"] * 8 > -auto["chunk_stats"]["chunks"]
+    assert np.array_equal(auto["angles"], serial["angles"]) and np.array_equal(auto["fk"], serial["fk"])
+    forced = hiplib.solve_seq(rec, params, frame_chunk=8)
+    assert forced["chunk_stats"]["chunks"] == 6 * 32
+    # and on a real recording the automatic mode keeps its chunks
+    z = load_golden("df3d_1000")
+    lg = [str(l) for l in z["legs"]]
+    ok = hiplib.solve_seq(np.stack([z[f"{l}_pose"] for l in lg])[None], _params(hiplib, z, lg), frame_chunk=-1)
+    assert ok["chunk_stats"]["chunks"] == 750
