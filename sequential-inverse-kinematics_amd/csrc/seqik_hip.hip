@@ -303,8 +303,11 @@ __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::Chain
     }
 }
 
+// Register budget: as the lane-per-chain kernels, 168 registers = three waves per SIMD = three workgroups per CU (the
+// kernel would take 184): 46 872 chains 18.8 -> 16.0 ms, 23 436 chains with three launches in flight 9.0 -> 7.9 ms.
 template <bool WANT_FK>
-__global__ void __launch_bounds__(256) seqik_pipe_kernel(KernelArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_pipe_kernel(KernelArgs a)
 {
     __shared__ seqik::LegConst s_legs[kMaxLegs];
     __shared__ PipeShared sh;
@@ -546,7 +549,8 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
 // of chunks.  In a workgroup the stage-1 wave of a chunk runs at most PIPE_DEPTH frames ahead of its stage-2 wave; all
 // four store into the chunk's rows / start_state exactly what the lane-per-chunk kernel stores.
 template <bool WANT_FK, int mode>
-__global__ void __launch_bounds__(256) seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
 {
     static_assert(mode == CHUNK_SPEC || mode == CHUNK_REPAIR, "the sweep stays on the lane-per-chunk kernel");
     __shared__ seqik::LegConst s_legs[kMaxLegs];
