@@ -1,6 +1,11 @@
 """Turns the rocprofv3 CSVs of one bench run (gpurun_out/<tag>_{stats,fetch,write,sq}) into the small
 summaries committed under profiles/ (+ profiles/traffic_rNN.json that bench.py reads)."""
 import glob, json, os, sys
+
+def newest(pattern):
+    """The most recent match (gpurun merges every run's files into the same directories)."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 import pandas as pd
 
 tag, rnd = sys.argv[1], sys.argv[2]           # e.g. r01b r01
@@ -9,13 +14,13 @@ src = os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = pd.read_csv(glob.glob(f"{src}/{tag}_stats/*/*_kernel_stats.csv")[0])
+stats = pd.read_csv(newest(f"{src}/{tag}_stats/*/*_kernel_stats.csv"))
 stats.to_csv(f"{dst}/{rnd}_bench_kernel_stats.csv", index=False)
 bench_line = [l for l in open(f"{src}/{tag}_stats.log") if l.startswith('{"metric"')][0]
 open(f"{dst}/{rnd}_bench_under_rocprof.json", "w").write(bench_line)
 
 def pmc(kind):
-    d = pd.read_csv(glob.glob(f"{src}/{tag}_{kind}/*/*_counter_collection.csv")[0])
+    d = pd.read_csv(newest(f"{src}/{tag}_{kind}/*/*_counter_collection.csv"))
     d = d[d.Kernel_Name.str.contains("seqik_stage_kernel|seqik_fused_kernel")].copy()
     st = d.Kernel_Name.str.extract(r"seqik_stage_kernel<(\d), ")[0]
     d["kernel"] = ("stage" + st).where(st.notna(), "fused")
