@@ -255,3 +255,27 @@ def test_automatic_chunks_give_way_to_the_serial_walk_when_speculation_fails(ora
     lg = [str(l) for l in z["legs"]]
     ok = hiplib.solve_seq(np.stack([z[f"{l}_pose"] for l in lg])[None], _params(hiplib, z, lg), frame_chunk=-1)
     assert ok["chunk_stats"]["chunks"] == 750
+
+
+@pytest.mark.gpu
+def test_chunks_with_fused_alignment_and_several_recordings(hiplib):
+    """Frame chunks of RAW key points with AlignPose.align_leg fused into the kernels == frame chunks of the pre-aligned
+    key points, for several recordings in one call and on both kernels."""
+    from seqikpy_amd import data
+    from seqikpy_amd.alignment import AlignPose
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    raw = {f"{l}_leg": z[f"{l}_raw"] for l in legs}
+    al = AlignPose(raw, legs, body_template=data.TEMPLATE_NMF_LOCOMOTION, log_level="ERROR")
+    affs = [hiplib.make_affine(*al.leg_affine(raw[f"{l}_leg"], l)) for l in legs]
+    params = _params(hiplib, z, legs)
+    cuts = [(0, 300), (350, 650), (690, 990)]
+    pose_raw = np.stack([np.stack([z[f"{l}_raw"][a:b] for l in legs]) for a, b in cuts])
+    pose_al = np.stack([np.stack([z[f"{l}_pose"][a:b] for l in legs]) for a, b in cuts])
+    for pl in (1, 2):
+        fused = hiplib.solve_seq(pose_raw, params, affine=affs, frame_chunk=16, frame_halo=8, pipeline=pl)
+        plain = hiplib.solve_seq(pose_al, params, frame_chunk=16, frame_halo=8, pipeline=pl)
+        assert fused["chunk_stats"]["chunks"] == 3 * 6 * 19
+        assert np.array_equal(fused["angles"], plain["angles"]) and np.array_equal(fused["fk"], plain["fk"])
+    serial = hiplib.solve_seq(pose_al, params)
+    assert np.abs(plain["angles"] - serial["angles"]).max() < 2e-5

@@ -50,10 +50,24 @@ def legs_report(name, against):
     legs = [str(l) for l in z["legs"]]
     pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
     out = _lib.solve_seq(pose, params(z, legs), want_fk=True, want_diag=True)
-    rep = {"frames": int(pose.shape[2]), "against": against, "legs": {}}
+    # the other launch paths of the same call (round 2): stage pipeline and fused lane-per-chain kernel must give the
+    # same bits as the per-stage kernels above; frame chunks (automatic parameters) are compared like the serial walk
+    piped = _lib.solve_seq(pose, params(z, legs), want_fk=True, pipeline=2)
+    fused = _lib.solve_seq(pose, params(z, legs), want_fk=True, pipeline=1)
+    chunked = _lib.solve_seq(pose, params(z, legs), want_fk=True, frame_chunk=-1)
+    rep = {"frames": int(pose.shape[2]), "against": against,
+           "stage_pipeline_and_fused_kernel_equal_the_per_stage_kernels_bit_for_bit":
+               bool(np.array_equal(piped["angles"], out["angles"]) and np.array_equal(piped["fk"], out["fk"]) and
+                    np.array_equal(fused["angles"], out["angles"]) and np.array_equal(fused["fk"], out["fk"])),
+           "frame_chunks": {"chunk_stats": {k: v for k, v in chunked["chunk_stats"].items() if v},
+                            "max_abs_vs_serial_walk": float(np.abs(chunked["angles"] - out["angles"]).max()),
+                            "leg_frames_ge_1e-4_vs_serial_walk": int((np.abs(chunked["angles"] - out["angles"]).max(-1) >= TOL).sum())},
+           "legs": {}}
     for i, leg in enumerate(legs):
         ref = c_oracle.seq_leg(z[f"{leg}_pose"], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"])
         r = compare(out["angles"][0, i], z[f"{leg}_angles"])
+        r["frame_chunks"] = {k: v for k, v in compare(chunked["angles"][0, i], z[f"{leg}_angles"]).items()
+                             if k in ("max_abs", "frames_ge_1e-4", "frames_ge_1e-4_span", "max_abs_outside_those_frames")}
         r["equals_c_oracle_bit_for_bit"] = bool(np.array_equal(out["angles"][0, i], ref["angles"]) and
                                                 np.array_equal(out["fk"][0, i], ref["fk"]) and
                                                 np.array_equal(out["nfev"][0, i], ref["nfev"]) and
@@ -89,8 +103,9 @@ def main():
     if _lib.load().seqik_device_count() < 1:
         raise SystemExit("parity_report.py needs a GPU")
     rep = {"tolerance_rad": TOL,
-           "note": "LF frames ~280-301 of the anipose recording are a kinematic-singularity episode in which the reference "
-                   "itself is not reproducible (DESIGN.md 2); every other frame must be below the tolerance.",
+           "note": "LF frames 284-301 of the anipose recording are a kinematic-singularity episode in which the reference "
+                   "itself is not reproducible (DESIGN.md 2, profiles/r02_perturbation_report.json); every other frame must "
+                   "be below the tolerance.",
            "anipose_6000_vs_shipped_outputs": legs_report("anipose_shipped", "reference's shipped leg_joint_angles.pkl / forward_kinematics.pkl"),
            "anipose_330_vs_reference_source_run": legs_report("anipose_scipy_cut", "reference source over real scipy, build container"),
            "df3d_100_vs_reference_source_run": legs_report("df3d_100", "reference source over real scipy, build container"),
