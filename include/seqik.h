@@ -88,7 +88,10 @@ typedef struct SeqikOptions {
                              running stage k of frame t while wavefront k-1 is already at frame t+1, the prefix frames
                              handed over through LDS: 0 = automatic (runs of all four stages without diagnostics over
                              at most 1024 chains / frame chunks, where the serial path per frame is what counts),
-                             1 = never, 2 = whenever applicable.  None of these changes a result bit. */
+                             1 = never, 2 = whenever applicable, 3 = as 2 but without lane pairs (a wavefront that
+                             carries at most 32 chains runs each on two or more lanes, and neighbouring lanes split
+                             the finite-difference columns and the trial point's sin / cos of a pass between them;
+                             3 is for measurements).  None of these changes a result bit. */
     /* ---- frame chunks (ABI 2): ONE long recording on the whole GPU -------------------------------------------
      * The reference walks a recording serially because frame t is warm-started from frame t-1
      * (seqikpy/leg_inverse_kinematics.py:259-282).  With frame_chunk != 0 a run of all four stages (no status /

@@ -43,11 +43,16 @@ def main():
     cases = [case("config 1 (anipose RF, 100 frames)", za, ["RF"], slice(0, 100)),
              case("config 2 (df3d, 6 legs x 1000 frames)", zd, [str(l) for l in zd["legs"]]),
              case("config 4 legs (anipose RF + LF, 6000 frames)", za, ["RF", "LF"])]
-    variants = [dict(pipeline=1), dict(pipeline=2), dict(), dict(frame_chunk=-1, pipeline=1), dict(frame_chunk=-1, pipeline=2),
-                dict(frame_chunk=-1)]
-    for c, h in ((4, 4), (4, 8), (8, 8), (16, 8), (32, 8)):
-        for pl in (1, 2):
-            variants.append(dict(frame_chunk=c, frame_halo=h, pipeline=pl))
+    # pipeline: 1 = lane-per-chain kernels, 2 = stage pipeline, 3 = stage pipeline without lane pairs, absent = the
+    # library's choice (stage pipeline with lane pairs at these sizes)
+    variants = [dict(pipeline=1), dict(pipeline=3), dict(pipeline=2), dict(), dict(frame_chunk=-1, pipeline=1),
+                dict(frame_chunk=-1, pipeline=3), dict(frame_chunk=-1, pipeline=2), dict(frame_chunk=-1)]
+    if os.environ.get("LATENCY_QUICK"):  # A/B builds: the serial walk and the automatic chunks only
+        variants = [dict(pipeline=3), dict(pipeline=2), dict(frame_chunk=-1)]
+    else:
+        for c, h in ((4, 4), (4, 8), (8, 8), (16, 8), (32, 8)):
+            for pl in (1, 2):
+                variants.append(dict(frame_chunk=c, frame_halo=h, pipeline=pl))
     rows = []
     for name, pose, params, ref, ok in cases:
         serial = None

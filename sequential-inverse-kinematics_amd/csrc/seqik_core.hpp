@@ -822,6 +822,84 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
 }
 
 // ---------------------------------------------------------------------------
+// Lane pairs (SPLIT instantiations of run_stage)
+// ---------------------------------------------------------------------------
+// A thin wave carries every chain on R >= 2 ADJACENT lanes (seqik_hip.hip, chain_of_wave_lane: replication): the
+// replicas hold the same state and take the same branches.  A SPLIT stage uses lanes 2k and 2k + 1 of such a group as a
+// pair: wherever a pass applies the SAME code to the two active joints one after the other -- the two finite-difference
+// columns (perturbed sin / cos + chain product each) and the two sin / cos of the trial point -- the even lane takes
+// joint a, the odd lane joint b, and they swap results with a DPP move (quad_perm [1, 0, 3, 2]: no LDS, no barrier).
+// Each value is computed by the same operations on the same operands as in the unsplit code, so the bits are the same.
+// Work that differs by candidate (select_step's three candidates, the root loop) cannot be split this way: lanes of
+// one wave that run different code run it one after the other.
+SEQIK_HD double pair_swap(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+#else
+    return v;
+#endif
+}
+
+SEQIK_HD bool pair_or(bool v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return v || (__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true) != 0);
+#else
+    return v;
+#endif
+}
+
+SEQIK_HD bool pair_is_odd()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (threadIdx.x & 1) != 0;
+#else
+    return false;
+#endif
+}
+
+// fd_jacobian with one column per lane of a pair (stages with two active joints)
+template <int STAGE>
+SEQIK_HD void fd_jacobian_pair(const StageProblem<STAGE> &P, const double *x, const double *f0, const double *lb,
+                               const double *ub, double sa, double ca, double sb, double cb, bool odd, double J[3][2])
+{
+    static_assert(StageTraits<STAGE>::NA == 2, "one active joint: nothing to split");
+    const double xj = odd ? x[1] : x[0];
+    double h = fd_step(xj, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]);
+    double x1 = xj + h;
+    double dx = x1 - xj;
+    double s1, c1, f1[3];
+    sincos_cw(x1, s1, c1);
+    residual_sc<STAGE>(P, odd ? sa : s1, odd ? ca : c1, odd ? s1 : sb, odd ? c1 : cb, f1);
+    double inv_dx = 1.0 / dx;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double mine = (f1[i] - f0[i]) * inv_dx;
+        const double other = pair_swap(mine);
+        J[i][0] = odd ? other : mine;
+        J[i][1] = odd ? mine : other;
+    }
+}
+
+// eval_residual with one sin / cos per lane of a pair
+template <int STAGE>
+SEQIK_HD void eval_residual_pair(const StageProblem<STAGE> &P, double xa, double xb, bool odd, double *f,
+                                 double &sa, double &ca, double &sb, double &cb, double *pe = nullptr)
+{
+    static_assert(StageTraits<STAGE>::NA == 2, "one active joint: nothing to split");
+    double s1, c1;
+    sincos_cw(odd ? xb : xa, s1, c1);
+    const double s2 = pair_swap(s1), c2 = pair_swap(c1);
+    sa = odd ? s2 : s1; ca = odd ? c2 : c1;
+    sb = odd ? s1 : s2; cb = odd ? c1 : c2;
+    residual_sc<STAGE>(P, sa, ca, sb, cb, f, pe);
+}
+
+// ---------------------------------------------------------------------------
 // Stage driver
 // ---------------------------------------------------------------------------
 // Stage pipeline (PIPED instantiations, seqik_hip.hip "Stage pipeline"): the four stages of a chain run in four
@@ -937,9 +1015,13 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //   CHUNKED   : the lane solves frames [io.t_begin, io.n_frames) of its chain and stores only those from
 //               io.t_store on (ChainIO); false = the whole chain from frame 0, everything stored.
 //   PIPED     : the hand-off goes through the LDS ring of io.pipe (stage pipeline, see PipeLane) instead of io.frames.
-template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false>
+//   SPLIT     : the lane and its neighbour lane ^ 1 carry the same chain and share the work of a pass ("Lane pairs").
+template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false,
+          bool SPLIT = false>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
+    constexpr bool PAIRED = SPLIT && StageTraits<STAGE>::NA == 2;
+    const bool odd = PAIRED && pair_is_odd();
     static_assert(!(PIPED && FROM_ANGLES), "the stage pipeline starts at stage 1");
     static_assert(STAGE > 1 || !FROM_ANGLES, "stage 1 has no prefix");
     static_assert(!(CHUNKED && FROM_ANGLES), "frame chunks start at stage 1 (the run-in has no stored angles)");
@@ -988,6 +1070,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if constexpr (STAGE > 1) stall = pipe_load(io.pipe.produced_in) <= i;
                 if constexpr (HANDOFF) stall = stall || (pipe_load(io.pipe.consumed_out) + PIPE_DEPTH <= i);
             }
+            // a pair starts a frame together (each lane has its own ring and counters, written by its own replica in
+            // the neighbouring waves in the same instruction; this makes the pair independent of how LDS orders them)
+            if constexpr (SPLIT) stall = pair_or(stall);
 #if defined(__HIP_DEVICE_COMPILE__)
             if (__ballot(stall) == __ballot(1)) __builtin_amdgcn_s_sleep(2);  // every lane still in the loop waits
 #endif
@@ -1087,7 +1172,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         if (WANT_DIAG || status == STATUS_NONE) {
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
             double J[3][2], g[2], v[2], dv[2];
-            fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
+            if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
+            else fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], J[0][j] * f[0]));
@@ -1154,7 +1240,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n, pe_n[3] = {0.0, 0.0, 0.0};
                 x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
                 if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);
-                eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
+                if constexpr (PAIRED)
+                    eval_residual_pair<STAGE>(P, x_new[0], x_new[1], odd, f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
+                else
+                    eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
                 nfev += 1;
                 double step_h_norm = norm2v<NA>(step_h);
                 double cost_new = 0.5 * dot3(f_new, f_new);

@@ -87,6 +87,51 @@ SEQIK_HD double diag_form7(const double *a, const double *diag, const double *b)
 }
 
 // ---------------------------------------------------------------------------
+// Lane groups (GROUPED instantiation of run_generic): a thin wave carries every chain on a multiple of 8 adjacent
+// lanes that hold the same state (seqik_hip.hip, lane_replication).  Lanes 0..6 of a group of 8 each take ONE of the
+// seven joints wherever a pass runs the same code once per joint -- the seven finite-difference columns (a perturbed
+// sin / cos and the whole 7-link chain product each: half of a pass) and the seven sin / cos of the trial point -- and
+// the group exchanges the results with ds_swizzle broadcasts (the LDS crossbar, no memory, no barrier).  Every value
+// is produced by the same operations on the same operands as in the one-lane code: same bits.  Lane 7 repeats joint 6.
+// ---------------------------------------------------------------------------
+template <int C>
+SEQIK_HD double group8_bcast(double v)  // the value lane C of this lane's group of 8 holds
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, (C << 5) | 0x18);  // bit mode: source lane = (lane & 0x18) | C
+    hi = __builtin_amdgcn_ds_swizzle(hi, (C << 5) | 0x18);
+    return __hiloint2double(hi, lo);
+#else
+    return v;
+#endif
+}
+
+SEQIK_HD void group8_gather(double v, double *out /* [GN] */)
+{
+    out[0] = group8_bcast<0>(v); out[1] = group8_bcast<1>(v); out[2] = group8_bcast<2>(v); out[3] = group8_bcast<3>(v);
+    out[4] = group8_bcast<4>(v); out[5] = group8_bcast<5>(v); out[6] = group8_bcast<6>(v);
+}
+
+SEQIK_HD int group8_joint()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int l = threadIdx.x & 7;
+    return l < GN ? l : GN - 1;
+#else
+    return 0;
+#endif
+}
+
+SEQIK_HD double pick7(const double *a, int j)  // a[j] without indexing a register array by a lane-dependent value
+{
+    double r = a[0];
+#pragma unroll
+    for (int i = 1; i < GN; ++i) r = (j == i) ? a[i] : r;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
 // Trust-region step without an SVD (mirrors oracle solve_tr_woodbury operation for operation).
 //
 // scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] (10 x 7).  All it needs from
@@ -137,13 +182,18 @@ SEQIK_HD void woodbury_solve(const double Jh[3][GN], const double *W, const doub
 }
 
 // pp = (B + J_h^T J_h)^-1 J_h^T f (the un-negated step), and -- when WANT_PHI -- phi and the Newton ratio phi / phi'
+// jm >= 0: lane group, this lane divides for joint jm only (the seven quotients are the same code on different data)
 template <bool WANT_PHI>
 SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const double *rhs, double alpha, double Delta,
-                           double *pp, double &phi, double &ratio)
+                           double *pp, double &phi, double &ratio, int jm = -1)
 {
     double W[GN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6];
+    if (jm >= 0) {
+        group8_gather(1.0 / (pick7(diag_h, jm) + alpha), W);
+    } else {
 #pragma unroll
-    for (int c = 0; c < GN; ++c) W[c] = 1.0 / (diag_h[c] + alpha);
+        for (int c = 0; c < GN; ++c) W[c] = 1.0 / (diag_h[c] + alpha);
+    }
 #pragma unroll
     for (int c = 0; c < GN; ++c) {
         double w0 = W[c] * Jh[0][c], w1 = W[c] * Jh[1][c], w2 = W[c] * Jh[2][c];
@@ -164,7 +214,7 @@ SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const d
 
 // solve_lsq_trust_region with m = 3 < n = 7 (never full rank), SVD-free
 SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, const double *f, double Delta,
-                                double &alpha_io, double *p)
+                                double &alpha_io, double *p, int jm = -1)
 {
     double rhs[GN], pp[GN];
 #pragma unroll
@@ -186,7 +236,7 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
             if (it < 9) a_k = -1.0;
         }
         double phi, ratio;
-        woodbury_phi<true>(Jh, diag_h, rhs, a_k, Delta, pp, phi, ratio);
+        woodbury_phi<true>(Jh, diag_h, rhs, a_k, Delta, pp, phi, ratio, jm);
         if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
             alpha = a_k - (phi + Delta) * ratio * inv_Delta;
             shortcut = true;
@@ -196,14 +246,14 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         double phi, ratio;
-        woodbury_phi<true>(Jh, diag_h, rhs, alpha, Delta, pp, phi, ratio);
+        woodbury_phi<true>(Jh, diag_h, rhs, alpha, Delta, pp, phi, ratio, jm);
         if (phi < 0) alpha_upper = alpha;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
     double unused_phi, unused_ratio;
-    woodbury_phi<false>(Jh, diag_h, rhs, alpha, Delta, pp, unused_phi, unused_ratio);
+    woodbury_phi<false>(Jh, diag_h, rhs, alpha, Delta, pp, unused_phi, unused_ratio, jm);
     double scale = Delta / vnorm7(pp);
 #pragma unroll
     for (int c = 0; c < GN; ++c) p[c] = -(pp[c] * scale);
@@ -359,10 +409,12 @@ SEQIK_HD int generic_link_dof(int link)
     return link == 0 ? 2 : (link == 1 ? 0 : (link == 2 ? 1 : link));
 }
 
-template <bool WANT_DIAG>
+// gc must live in addressable memory (LDS): the GROUPED code reads gc.lb[j] / gc.ub[j] with a lane-dependent j
+template <bool WANT_DIAG, bool GROUPED = false>
 SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const GenericIO &io)
 {
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
+    const int jm = GROUPED ? group8_joint() : 0;  // the joint this lane takes in grouped sections
     double x[GN], f[3] = {0.0, 0.0, 0.0}, sn[GN], cs[GN], target[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < GN; ++i) {
         x[i] = io.init ? io.init[generic_link_dof(i)] : gc.seed[i];
@@ -385,9 +437,16 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             } else {
                 for (int a = 0; a < 3; ++a) target[a] = kp[a] - org[a];
             }
-            for (int i = 0; i < GN; ++i) {
-                x[i] = strictly_feasible(x[i], gc.lb[i], gc.ub[i], 1e-10);
-                sincos_cw(x[i], sn[i], cs[i]);
+            if constexpr (GROUPED) {
+                const double xj = strictly_feasible(pick7(x, jm), gc.lb[jm], gc.ub[jm], 1e-10);
+                double s1, c1;
+                sincos_cw(xj, s1, c1);
+                group8_gather(xj, x); group8_gather(s1, sn); group8_gather(c1, cs);
+            } else {
+                for (int i = 0; i < GN; ++i) {
+                    x[i] = strictly_feasible(x[i], gc.lb[i], gc.ub[i], 1e-10);
+                    sincos_cw(x[i], sn[i], cs[i]);
+                }
             }
             generic_residual(gc, sn, cs, target, f);
             cost = 0.5 * dot3(f, f);
@@ -402,16 +461,31 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
         if (WANT_DIAG || status == STATUS_NONE) {
             // ---- 2-point finite-difference Jacobian: column j perturbs joint j only ---------------
             double J[3][GN], g[GN], v[GN], dv[GN];
-            for (int j = 0; j < GN; ++j) {
-                double h = fd_step(x[j], gc.lb[j], gc.ub[j]);
-                double x1 = x[j] + h;
-                double dx = x1 - x[j];
-                double s_keep = sn[j], c_keep = cs[j], f1[3];
-                sincos_cw(x1, sn[j], cs[j]);
-                generic_residual(gc, sn, cs, target, f1);
-                sn[j] = s_keep; cs[j] = c_keep;
+            if constexpr (GROUPED) {  // one column per lane of the group
+                const double xj = pick7(x, jm);
+                double h = fd_step(xj, gc.lb[jm], gc.ub[jm]);
+                double x1 = xj + h;
+                double dx = x1 - xj;
+                double s1, c1, sp[GN], cp[GN], f1[3];
+                sincos_cw(x1, s1, c1);
+#pragma unroll
+                for (int i = 0; i < GN; ++i) { sp[i] = (i == jm) ? s1 : sn[i]; cp[i] = (i == jm) ? c1 : cs[i]; }
+                generic_residual(gc, sp, cp, target, f1);
                 double inv_dx = 1.0 / dx;
-                for (int k = 0; k < 3; ++k) J[k][j] = (f1[k] - f[k]) * inv_dx;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) group8_gather((f1[k] - f[k]) * inv_dx, J[k]);
+            } else {
+                for (int j = 0; j < GN; ++j) {
+                    double h = fd_step(x[j], gc.lb[j], gc.ub[j]);
+                    double x1 = x[j] + h;
+                    double dx = x1 - x[j];
+                    double s_keep = sn[j], c_keep = cs[j], f1[3];
+                    sincos_cw(x1, sn[j], cs[j]);
+                    generic_residual(gc, sn, cs, target, f1);
+                    sn[j] = s_keep; cs[j] = c_keep;
+                    double inv_dx = 1.0 / dx;
+                    for (int k = 0; k < 3; ++k) J[k][j] = (f1[k] - f[k]) * inv_dx;
+                }
             }
             for (int j = 0; j < GN; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
@@ -433,8 +507,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 finished = true;
             } else {
                 double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
+                if constexpr (GROUPED) group8_gather(sqrt(pick7(v, jm)) * 1.0, d);
                 for (int j = 0; j < GN; ++j) {
-                    d[j] = sqrt(v[j]) * 1.0;
+                    if constexpr (!GROUPED) d[j] = sqrt(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
                 }
@@ -443,13 +518,20 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double theta = fmax(0.995, 1 - g_norm);
 
                 double p_h[GN], p[GN], step[GN], step_h[GN];
-                solve_tr_woodbury(Jh, diag_h, f, Delta, alpha, p_h);
+                solve_tr_woodbury(Jh, diag_h, f, Delta, alpha, p_h, GROUPED ? jm : -1);
                 for (int j = 0; j < GN; ++j) p[j] = d[j] * p_h[j];
                 double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h);
                 double x_new[GN], sn_n[GN], cs_n[GN], f_new[3];
-                for (int j = 0; j < GN; ++j) {
-                    x_new[j] = strictly_feasible(x[j] + step[j], gc.lb[j], gc.ub[j], 0.0);
-                    sincos_cw(x_new[j], sn_n[j], cs_n[j]);
+                if constexpr (GROUPED) {
+                    const double xj = strictly_feasible(pick7(x, jm) + pick7(step, jm), gc.lb[jm], gc.ub[jm], 0.0);
+                    double s1, c1;
+                    sincos_cw(xj, s1, c1);
+                    group8_gather(xj, x_new); group8_gather(s1, sn_n); group8_gather(c1, cs_n);
+                } else {
+                    for (int j = 0; j < GN; ++j) {
+                        x_new[j] = strictly_feasible(x[j] + step[j], gc.lb[j], gc.ub[j], 0.0);
+                        sincos_cw(x_new[j], sn_n[j], cs_n[j]);
+                    }
                 }
                 generic_residual(gc, sn_n, cs_n, target, f_new);
                 nfev += 1;

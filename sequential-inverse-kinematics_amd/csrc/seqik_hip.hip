@@ -65,6 +65,7 @@ struct KernelArgs {
     int32_t n_legs;
     int32_t lanes_per_wave;       // W: chains a wavefront carries (1..64), see chain_of_lane()
     LegOrder leg_order;           // dispatch order of the legs
+    int32_t lane_pairs;           // stage pipeline: thin waves split a pass over lane pairs (0 = off, for measurements)
     // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
@@ -92,9 +93,15 @@ struct KernelArgs {
 //     into a mode in which its vector instructions issue ~4.6x slower once it shares its CU with other waves (measured:
 //     scripts/microbench/exec_density.hip, exec_mode.hip, profiles/r02_sparse_exec_microbench.jsonl; the threshold is
 //     the number of ACTIVE lanes, wherever they sit, exited or masked alike).  So a wave that carries W < 16 chains
-//     runs every chain on R = 64 / W lanes: the replicas load the same operands, take the same branches and store the
+//     runs every chain on R ~ 64 / W lanes: the replicas load the same operands, take the same branches and store the
 //     same values to the same addresses -- no additional instruction is issued, and the wave stays in the fast mode.
-__device__ __forceinline__ int lane_replication(int W) { return W < 16 ? 64 / W : 1; }
+//     R is even, and at least 2 up to W = 32: two adjacent replicas form a lane PAIR that shares the work of a pass on the
+//     stage pipeline (seqik_core.hpp "Lane pairs"; lane_pairs() below).
+//     Up to W = 8 it is a multiple of 8: the generic-chain kernel splits a pass over groups of 8 adjacent replicas
+//     (seqik_generic.hpp "Lane groups"; lane_groups() below).
+__device__ __forceinline__ int lane_replication(int W) { return W <= 8 ? ((64 / W) & ~7) : (W <= 32 ? ((64 / W) & ~1) : 1); }
+__device__ __forceinline__ bool lane_pairs(int W) { return W <= 32; }
+__device__ __forceinline__ bool lane_groups(int W) { return W <= 8; }
 
 __device__ __forceinline__ bool chain_of_wave_lane(int64_t wave, int lane, int64_t n_seq, int32_t n_legs, int32_t W,
                                                    const LegOrder &order, int64_t &c, int &leg)
@@ -113,6 +120,11 @@ __device__ __forceinline__ bool chain_of_wave_lane(int64_t wave, int lane, int64
     const int64_t seq = (wave - slot * n_grp) * W + lane;
     c = seq * n_legs + leg;
     return lane < W && seq < n_seq;
+}
+
+__device__ __forceinline__ bool use_pairs(const KernelArgs &a)
+{
+    return a.lane_pairs != 0 && lane_pairs(a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave);
 }
 
 __device__ __forceinline__ bool chain_of_lane(int64_t n_seq, int32_t n_legs, int32_t W, const LegOrder &order,
@@ -282,9 +294,11 @@ struct PipeShared {
     int consumed[3][64];
 };
 
+// pairs (wave-uniform): the wave carries every chain on an even number of adjacent lanes, lanes 2k / 2k + 1 split the
+// passes of the stages with two active joints between them
 template <bool WANT_FK, bool CHUNK_SPEC_MODE>
 __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane,
-                                         int base = 0)
+                                         bool pairs, int base = 0)
 {
     seqik::PipeLane &pl = io.pipe;
     pl.lane_stride = 64;
@@ -295,11 +309,14 @@ __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::Chain
     pl.ring_out = stage_wave < 3 ? &sh.ring[stage_wave][0][0][lane] : nullptr;
     pl.produced_out = stage_wave < 3 ? &sh.produced[stage_wave][lane] : nullptr;
     pl.consumed_out = stage_wave < 3 ? &sh.consumed[stage_wave][lane] : nullptr;
-    switch (stage_wave) {  // wave-uniform
+    switch (stage_wave + (pairs && stage_wave < 3 ? 4 : 0)) {  // wave-uniform
     case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
     case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
     case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
-    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true>(lc, io); break;
+    case 4: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
+    case 5: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
+    case 6: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
+    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true>(lc, io); break;  // one joint
     }
 }
 
@@ -336,7 +353,7 @@ seqik_pipe_kernel(KernelArgs a)
     io.init = a.init ? a.init + c * 7 : nullptr;
     io.frames = nullptr;
     io.n_frames = a.n_frames;
-    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane);
+    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -571,7 +588,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
         seqik::ChainIO io;
         chunk_io(a, ca, vc, leg, true, io);
         // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
-        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane);
+        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a));
     } else {
         // the work list of round ca.round, spread over the workgroups as thinly as possible; the four stage waves of a
         // workgroup walk the same entries in the same order (the ring counters of a lane keep counting across entries)
@@ -585,7 +602,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
             const int leg = (int)(vc % a.n_legs);
             seqik::ChainIO io;
             chunk_io(a, ca, vc, leg, false, io);
-            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, base);
+            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), base);
             base += (int)(io.n_frames - io.t_begin);
         }
     }
@@ -645,6 +662,7 @@ struct GenericKernelArgs {
     int64_t n_chains, n_seq, n_frames;
     int32_t n_legs, lanes_per_wave;
     LegOrder leg_order;
+    int32_t lane_groups;  // thin waves split a pass over groups of 8 lanes (0 = off, for measurements)
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
 };
@@ -676,7 +694,9 @@ seqik_generic_kernel(GenericKernelArgs a)
     io.nfev = a.nfev ? a.nfev + c * a.n_frames : nullptr;
     io.init = a.init ? a.init + c * 7 : nullptr;
     io.n_frames = a.n_frames;
-    seqik::run_generic<WANT_DIAG>(s_legs[leg].gc, s_legs[leg].aff, io);
+    const int W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
+    if (a.lane_groups != 0 && lane_groups(W)) seqik::run_generic<WANT_DIAG, true>(s_legs[leg].gc, s_legs[leg].aff, io);  // wave-uniform
+    else seqik::run_generic<WANT_DIAG, false>(s_legs[leg].gc, s_legs[leg].aff, io);
 }
 
 // Device copies of the per-leg constant tables.  Callers almost always pass the same legs on every call, so the
@@ -948,7 +968,8 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     // serial path per frame is what counts), 1 = never, 2 = whenever applicable
     const int pipe_opt = opt ? opt->reserved[3] : 0;
     const bool piped = first_stage == 1 && last_stage == 4 && !diag &&
-                       (pipe_opt == 2 || (pipe_opt == 0 && n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
+                       (pipe_opt >= 2 || (pipe_opt == 0 && n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
+    a.lane_pairs = pipe_opt == 3 ? 0 : 1;  // 3 = as 2, thin waves without lane pairs (measurements)
     a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked || piped);
     int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
     if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
@@ -1177,6 +1198,7 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     a.n_seq = n_seq;
     a.leg_order = make_leg_order(legs, n_legs);
     a.lanes_per_wave = pick_lanes_per_wave(a.n_chains, opt);
+    a.lane_groups = (opt && opt->reserved[3] == 3) ? 0 : 1;  // 3: thin waves without lane groups (measurements)
     int64_t n_waves = ((n_seq + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;
     if (opt && opt->reserved[2] == 1) {
         n_waves = (a.n_chains + a.lanes_per_wave - 1) / a.lanes_per_wave;

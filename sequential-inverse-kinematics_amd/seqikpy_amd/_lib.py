@@ -364,7 +364,7 @@ def device_attributes(device=0):
 
 
 def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_size=0, affine=None, init_angles=None,
-                  lanes_per_wave=0):
+                  lanes_per_wave=0, lane_groups=True):
     """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
     fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None)."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
@@ -386,6 +386,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_si
     opt.device = device
     opt.block_size = block_size
     opt.reserved[0] = lanes_per_wave
+    opt.reserved[3] = 0 if lane_groups else 3  # measurements: thin waves without the split over groups of 8 lanes
     rc = load().seqik_solve_generic(pose.ctypes.data_as(_dp), S, L, N, (SeqikLegParams * L)(*legs),
                                     angles.ctypes.data_as(_dp), fk.ctypes.data_as(_dp) if fk is not None else None,
                                     status.ctypes.data_as(_ip) if status is not None else None,

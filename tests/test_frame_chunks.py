@@ -180,10 +180,12 @@ def test_python_api_default_is_chunked_and_within_parity_of_shipped_golden(hipli
 # Stage pipeline (SeqikOptions.reserved[3]): four wavefronts per group of chains, hand-off through LDS
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes", [0, 1, 3, 64])
+@pytest.mark.parametrize("lanes", [0, 1, 3, 5, 7, 12, 20, 32, 33, 64])
 def test_stage_pipeline_equals_oracle_bit_for_bit(oracle, hiplib, lanes):
     """Serial walk on the stage pipeline == lane-per-chain kernel == C oracle, whatever the number of chains per
-    workgroup (every lane has its own ring slots and counters)."""
+    workgroup (every lane has its own ring slots and counters).  Up to 32 chains per wavefront every chain runs on
+    two or more lanes and neighbouring lanes split the passes between them (lane pairs): same bits, also against the
+    pipeline without pairs (pipeline = 3)."""
     z = load_golden("df3d_1000")
     legs = [str(l) for l in z["legs"]]
     params = _params(hiplib, z, legs)
@@ -191,6 +193,8 @@ def test_stage_pipeline_equals_oracle_bit_for_bit(oracle, hiplib, lanes):
     piped = hiplib.solve_seq(pose, params, pipeline=2, lanes_per_wave=lanes)
     plain = hiplib.solve_seq(pose, params, pipeline=1)
     assert np.array_equal(piped["angles"], plain["angles"]) and np.array_equal(piped["fk"], plain["fk"])
+    unpaired = hiplib.solve_seq(pose, params, pipeline=3, lanes_per_wave=lanes)
+    assert np.array_equal(piped["angles"], unpaired["angles"]) and np.array_equal(piped["fk"], unpaired["fk"])
     for s, o in enumerate((0, 200, 411, 640, 900)):
         for li, l in enumerate(legs):
             ref = oracle.seq_leg(z[f"{l}_pose"][o:o + 90], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"])

@@ -280,7 +280,7 @@ def test_random_legs_and_nasty_targets_bit_for_bit(lib, oracle):
             assert (out["angles"][0, i] >= b[:, 0]).all() and (out["angles"][0, i] <= b[:, 1]).all()
 
 
-@pytest.mark.parametrize("lanes", [1, 5, 64])
+@pytest.mark.parametrize("lanes", [1, 3, 5, 8, 9, 64])
 def test_lanes_per_wave_does_not_change_results(lib, lanes):
     """The lane -> chain mapping (SeqikOptions.reserved[0]) only decides where a chain runs: 23 sequences x 6
     legs (ragged against 5 and 64 lanes per wave) give the same bits as the automatic choice."""
@@ -299,6 +299,11 @@ def test_lanes_per_wave_does_not_change_results(lib, lanes):
     gen_auto = lib.solve_generic(gpose, gp)
     gen = lib.solve_generic(gpose, gp, lanes_per_wave=lanes)
     assert np.array_equal(gen["angles"], gen_auto["angles"]) and np.array_equal(gen["fk"], gen_auto["fk"])
+    # up to 8 chains per wavefront the generic kernel splits a pass over groups of 8 lanes: same bits without
+    one_lane = lib.solve_generic(gpose, gp, lanes_per_wave=lanes, lane_groups=False, want_diag=True)
+    grouped = lib.solve_generic(gpose, gp, lanes_per_wave=lanes, want_diag=True)
+    for k in ("angles", "fk", "status", "nfev"):
+        assert np.array_equal(one_lane[k], grouped[k]), k
 
 
 def test_single_launch_equals_one_launch_per_stage(lib):
