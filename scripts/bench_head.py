@@ -18,14 +18,19 @@ def run():
     rc = lib.seqik_head_angles_device(r.data_ptr(), l.data_ptr(), n, neck.data_ptr(), 0, float(z["rest_head_pitch"][0]),
                                       float(z["rest_antenna_pitch"][0]), 1, out.data_ptr(), st)
     assert rc == 0
-for _ in range(3): run()
-ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
+for _ in range(15): run()  # the first launches after the fill kernels run ~10 % slower
+K = 40
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
 ev[0].record()
-for i in range(10):
+for i in range(K):
     run(); ev[i + 1].record()
 torch.cuda.synchronize()
-ms = np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(10)])
+each = np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(K)])
+ms = float(each.mean())
 bytes_per_frame = 96 + 56
-print(json.dumps({"kernel": "seqik_head_kernel", "frames": n, "ms": ms, "frames_per_s": n / ms * 1e3,
-                  "algorithmic_GBps": bytes_per_frame * n / ms / 1e6, "hbm_peak_GBps": 8000,
-                  "frac": bytes_per_frame * n / ms / 1e6 / 8000}))
+rate = lambda t: bytes_per_frame * n / t / 1e6
+print(json.dumps({"kernel": "seqik_head_kernel", "frames": n, "launches": K, "ms": ms, "ms_min": float(each.min()),
+                  "ms_median": float(np.median(each)), "ms_max": float(each.max()), "frames_per_s": n / ms * 1e3,
+                  "algorithmic_GBps": rate(ms), "algorithmic_GBps_best_launch": rate(float(each.min())),
+                  "hbm_peak_GBps": 8000, "frac": rate(ms) / 8000, "frac_best_launch": rate(float(each.min())) / 8000,
+                  "ms_each": [round(float(v), 3) for v in each]}))

@@ -1,0 +1,181 @@
+// Microbenchmark: where does the head / antenna kernel's time go?  Same frames, same launch shape as
+// seqik_head_kernel (256 threads, grid-stride), variants:
+//   0 full        per-lane AoS loads (48 B per lane and array, stride 48 B), arithmetic, 7 SoA stores
+//   1 copy        the same loads and stores, no arithmetic (memory side alone)
+//   2 math        the arithmetic on frames that stay in cache (arithmetic side alone)
+//   3 staged      the two AoS inputs come in as 16-byte fully coalesced loads staged through LDS per wavefront
+//   4 staged copy
+//   5 staged, non-temporal loads and stores            6 the same, copy only
+//   7 per-lane AoS loads as 0, non-temporal loads (16 B) and stores
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o head_split head_split.hip && ./head_split [n_frames]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../sequential-inverse-kinematics_amd/csrc/seqik_head.hpp"
+
+using seqik::HeadArgs;
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) head_variant(HeadArgs a)
+{
+    constexpr bool STAGED = MODE >= 3 && MODE <= 6, COPY = (MODE == 1 || MODE == 4 || MODE == 6), NT = MODE >= 5;
+    __shared__ d2 s_stage[STAGED ? 4 * 384 : 1];  // per wave: 2 arrays x 3072 B = 384 x 16 B
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = a.n_frames;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < n; t0 += stride) {
+        const int64_t t = t0 + threadIdx.x;
+        double out[7];
+        bool have = false;
+        if (MODE == 2) {
+            const int64_t tt = t & 4095;
+            seqik::head_angles_compute(a.r_head + tt * 6, a.l_head + tt * 6, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+            if (out[0] + out[1] + out[2] + out[3] + out[4] + out[5] + out[6] == 123.456) a.angles[tt] = 1.0;  // never
+            continue;
+        }
+        if (!STAGED) {
+            if (t < n) {
+                const double *rb = a.r_head + t * 6, *lb = a.l_head + t * 6;
+                double rr[6], ll[6];
+                if (NT) {
+                    const d2 *r2 = reinterpret_cast<const d2 *>(rb), *l2 = reinterpret_cast<const d2 *>(lb);
+                    for (int j = 0; j < 3; ++j) {
+                        const d2 x = __builtin_nontemporal_load(r2 + j), y = __builtin_nontemporal_load(l2 + j);
+                        rr[2 * j] = x.x; rr[2 * j + 1] = x.y; ll[2 * j] = y.x; ll[2 * j + 1] = y.y;
+                    }
+                    rb = rr; lb = ll;
+                }
+                if (COPY) { for (int j = 0; j < 6; ++j) out[j] = rb[j] + lb[j]; out[6] = rb[0] - lb[5]; }
+                else seqik::head_angles_compute(rb, lb, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+                have = true;
+            }
+        } else {
+            d2 *st = s_stage + wave * 384;
+            const int64_t w0 = t0 + wave * 64;  // first frame of this wave
+            if (w0 + 64 <= n) {
+                // 16-byte chunks: 192 per array, lane takes chunks lane, 64 + lane, 128 + lane (1 KiB contiguous per load)
+                const d2 *gr = reinterpret_cast<const d2 *>(a.r_head + w0 * 6);
+                const d2 *gl = reinterpret_cast<const d2 *>(a.l_head + w0 * 6);
+                d2 r0, r1, r2, l0, l1, l2;
+                if (NT) {
+                    r0 = __builtin_nontemporal_load(gr + lane); r1 = __builtin_nontemporal_load(gr + 64 + lane);
+                    r2 = __builtin_nontemporal_load(gr + 128 + lane);
+                    l0 = __builtin_nontemporal_load(gl + lane); l1 = __builtin_nontemporal_load(gl + 64 + lane);
+                    l2 = __builtin_nontemporal_load(gl + 128 + lane);
+                } else {
+                    r0 = gr[lane]; r1 = gr[64 + lane]; r2 = gr[128 + lane];
+                    l0 = gl[lane]; l1 = gl[64 + lane]; l2 = gl[128 + lane];
+                }
+                st[lane] = r0; st[64 + lane] = r1; st[128 + lane] = r2;
+                st[192 + lane] = l0; st[256 + lane] = l1; st[320 + lane] = l2;
+                wave_lds_fence();
+                const double *sr = reinterpret_cast<const double *>(st) + lane * 6;
+                const double *sl = reinterpret_cast<const double *>(st + 192) + lane * 6;
+                if (COPY) { for (int j = 0; j < 6; ++j) out[j] = sr[j] + sl[j]; out[6] = sr[0] - sl[5]; }
+                else seqik::head_angles_compute(sr, sl, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+                have = true;
+                wave_lds_fence();  // the next iteration's writes stay behind these reads
+            } else if (t < n) {
+                seqik::head_angles_compute(a.r_head + t * 6, a.l_head + t * 6, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+                have = true;
+            }
+        }
+        if (have) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                if (NT) __builtin_nontemporal_store(out[j], a.angles + j * n + t);
+                else a.angles[j * n + t] = out[j];
+            }
+        }
+    }
+}
+
+static int g_per_cu = 8;
+
+template <int MODE>
+static float run(const HeadArgs &a, int reps)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    int64_t blocks = (a.n_frames + 255) / 256;
+    if (blocks > 256 * g_per_cu) blocks = 256 * g_per_cu;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(head_variant<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(head_variant<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / reps;
+}
+
+int main(int argc, char **argv)
+{
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 64000000;
+    if (getenv("BLOCKS_PER_CU")) g_per_cu = atoi(getenv("BLOCKS_PER_CU"));
+    double *r, *l, *neck, *out;
+    (void)hipMalloc(&r, n * 48); (void)hipMalloc(&l, n * 48); (void)hipMalloc(&neck, 24); (void)hipMalloc(&out, n * 56);
+    {   // plausible key points: a 6000-frame pattern repeated
+        double *h = (double *)malloc(6000 * 48 * 2);
+        for (int i = 0; i < 6000; ++i) {
+            const double ph = i * 0.01;
+            double *rb = h + i * 6, *lb = h + 6000 * 6 + i * 6;
+            rb[0] = 0.3 + 0.01 * sin(ph); rb[1] = -0.12 + 0.01 * cos(ph); rb[2] = 0.35 + 0.005 * sin(2 * ph);
+            rb[3] = 0.45 + 0.02 * sin(ph + 1); rb[4] = -0.2 + 0.02 * cos(ph + 2); rb[5] = 0.3 + 0.02 * sin(ph + 3);
+            lb[0] = 0.3 + 0.01 * cos(ph); lb[1] = 0.12 + 0.01 * sin(ph); lb[2] = 0.35 + 0.005 * cos(2 * ph);
+            lb[3] = 0.45 + 0.02 * cos(ph + 1); lb[4] = 0.2 + 0.02 * sin(ph + 2); lb[5] = 0.3 + 0.02 * cos(ph + 3);
+        }
+        for (int64_t o = 0; o < n; o += 6000) {
+            const int64_t m = (n - o) < 6000 ? (n - o) : 6000;
+            (void)hipMemcpy(r + o * 6, h, m * 48, hipMemcpyHostToDevice);
+            (void)hipMemcpy(l + o * 6, h + 6000 * 6, m * 48, hipMemcpyHostToDevice);
+        }
+        const double nk[3] = {0.0, 0.0, 0.2};
+        (void)hipMemcpy(neck, nk, 24, hipMemcpyHostToDevice);
+        free(h);
+    }
+    HeadArgs a;
+    a.r_head = r; a.l_head = l; a.neck = neck; a.neck_stride = 0; a.rest_head_pitch = 0.1; a.rest_antenna_pitch = 0.2;
+    a.angles = out; a.n_frames = n; a.compute_ant = 1;
+    // accuracy of the device arithmetic (hardware seeds + Newton steps) against the same formulas evaluated on the host
+    // with IEEE division and square root: first 6000 frames, staged variant
+    double max_diff = 0.0;
+    {
+        hipLaunchKernelGGL(head_variant<5>, dim3(2048), dim3(256), 0, 0, a);
+        (void)hipDeviceSynchronize();
+        const int m = 6000;
+        double *hr = (double *)malloc(m * 48), *hl = (double *)malloc(m * 48), *ho = (double *)malloc(sizeof(double) * 7 * m),
+               *dev = (double *)malloc(sizeof(double) * 7 * m);
+        (void)hipMemcpy(hr, r, m * 48, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hl, l, m * 48, hipMemcpyDeviceToHost);
+        for (int j = 0; j < 7; ++j) (void)hipMemcpy(dev + j * m, out + j * n, m * 8, hipMemcpyDeviceToHost);
+        const double nk[3] = {0.0, 0.0, 0.2};
+        HeadArgs h = a;
+        h.r_head = hr; h.l_head = hl; h.neck = nk; h.angles = ho; h.n_frames = m;
+        for (int t = 0; t < m; ++t) seqik::head_angles_frame(h, t);
+        for (int i = 0; i < 7 * m; ++i) { const double d = fabs(ho[i] - dev[i]); if (d > max_diff) max_diff = d; }
+    }
+    const double gb = 152.0 * n / 1e9;
+    // best of 6 rounds of 10 launches each, variants interleaved (back-to-back runs of one variant differ by ~10 %)
+    float t[8] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
+    for (int round = 0; round < 6; ++round) {
+        t[0] = fminf(t[0], run<0>(a, 10)); t[1] = fminf(t[1], run<1>(a, 10)); t[2] = fminf(t[2], run<2>(a, 10));
+        t[3] = fminf(t[3], run<3>(a, 10)); t[4] = fminf(t[4], run<4>(a, 10)); t[5] = fminf(t[5], run<5>(a, 10));
+        t[6] = fminf(t[6], run<6>(a, 10)); t[7] = fminf(t[7], run<7>(a, 10));
+    }
+    printf("{\"frames\": %lld, \"blocks_per_cu\": %d, \"newton_steps\": %d, \"max_abs_diff_device_vs_host_formulas\": %.3e, "
+           "\"full_ms\": %.3f, \"copy_ms\": %.3f, \"math_only_ms\": %.3f, \"staged_ms\": %.3f, \"staged_copy_ms\": %.3f, "
+           "\"staged_nt_ms\": %.3f, \"staged_nt_copy_ms\": %.3f, \"full_nt_ms\": %.3f, \"TBps\": {\"full\": %.2f, \"copy\": %.2f, \"staged\": %.2f, "
+           "\"staged_copy\": %.2f, \"staged_nt\": %.2f, \"staged_nt_copy\": %.2f}}\n",
+           (long long)n, g_per_cu, SEQIK_HEAD_NEWTON, max_diff, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
+           gb / t[0], gb / t[1], gb / t[3], gb / t[4], gb / t[5], gb / t[6]);
+    return 0;
+}

@@ -1,5 +1,6 @@
 // seqik_head.hip -- head / antenna angle kernel and its C ABI entry points (include/seqik.h).
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -11,11 +12,65 @@ extern "C" void seqik_set_error(int code, const char *msg);
 
 namespace {
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// orders a wavefront's LDS writes before its reads of what OTHER lanes wrote (the hardware completes a wave's LDS
+// operations in order; this is for the compiler)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One frame per lane, grid-stride.  Per frame 96 B in (two AoS records of 48 B) and 56 B out (seven SoA rows): the
+// kernel is meant to run at the rate of a copy.  What that took (scripts/microbench/head_split.hip):
+//   * every load of a frame is issued before its first store (the seven angles go to registers first): input and
+//     output may alias as far as the compiler knows, so a store in the middle held the later loads back -- two memory
+//     round trips per frame, 2.2 -> 1.75 ms for 64 M frames;
+//   * STAGED: a wavefront's 64 records are one contiguous 3 KiB block per array; it comes in as three fully coalesced
+//     16-byte-per-lane loads (1 KiB each, non-temporal: read once) into LDS and the lanes pick their records from
+//     there; the outputs leave as non-temporal stores.  1.75 -> 1.67 ms; a copy with the same traffic takes 1.58 ms.
+//     (Non-temporal loads WITHOUT the staging are a loss, 2.1 ms: the three strided loads of a lane then miss each
+//     other's lines.)  Needs 16-byte aligned inputs and whole wavefronts; everything else takes the per-lane loads.
+template <bool STAGED>
 __global__ void __launch_bounds__(256) seqik_head_kernel(seqik::HeadArgs a)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.n_frames; t += stride)
-        seqik::head_angles_frame(a, t);
+    __shared__ d2 s_stage[STAGED ? 4 * 384 : 1];  // per wavefront: 2 arrays x 3072 B = 384 x 16 B
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n = a.n_frames;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool ant = a.compute_ant != 0;
+    const int n_out = ant ? 7 : 3;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 < n; t0 += stride) {
+        const int64_t t = t0 + threadIdx.x;
+        const int64_t w0 = t0 + wave * 64;  // first frame of this wavefront
+        double out[7];
+        if (STAGED && w0 + 64 <= n) {
+            d2 *st = s_stage + wave * 384;
+            const d2 *gr = reinterpret_cast<const d2 *>(a.r_head + w0 * 6);
+            const d2 *gl = reinterpret_cast<const d2 *>(a.l_head + w0 * 6);
+            const d2 r0 = __builtin_nontemporal_load(gr + lane), r1 = __builtin_nontemporal_load(gr + 64 + lane),
+                     r2 = __builtin_nontemporal_load(gr + 128 + lane);
+            const d2 l0 = __builtin_nontemporal_load(gl + lane), l1 = __builtin_nontemporal_load(gl + 64 + lane),
+                     l2 = __builtin_nontemporal_load(gl + 128 + lane);
+            st[lane] = r0; st[64 + lane] = r1; st[128 + lane] = r2;
+            st[192 + lane] = l0; st[256 + lane] = l1; st[320 + lane] = l2;
+            wave_lds_fence();
+            seqik::head_angles_compute(reinterpret_cast<const double *>(st) + lane * 6,
+                                       reinterpret_cast<const double *>(st + 192) + lane * 6, a.neck + t * a.neck_stride,
+                                       a.rest_head_pitch, a.rest_antenna_pitch, ant, out);
+            wave_lds_fence();  // the next iteration's LDS writes stay behind these reads
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < n_out) __builtin_nontemporal_store(out[j], a.angles + j * n + t);
+        } else if (t < n) {
+            seqik::head_angles_compute(a.r_head + t * 6, a.l_head + t * 6, a.neck + t * a.neck_stride, a.rest_head_pitch,
+                                       a.rest_antenna_pitch, ant, out);
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (j < n_out) a.angles[j * n + t] = out[j];
+        }
+    }
 }
 
 int hip_fail(hipError_t e, const char *what)
@@ -48,7 +103,10 @@ int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int
     int64_t blocks = (n_frames + 255) / 256;
     static const int per_cu = getenv("SEQIK_HEAD_BLOCKS_PER_CU") ? atoi(getenv("SEQIK_HEAD_BLOCKS_PER_CU")) : 8;
     if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;  // grid-stride beyond per_cu blocks per CU
-    hipLaunchKernelGGL(seqik_head_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+    // staged loads need 16-byte aligned records and read the antenna tips too (only worth it when they are used)
+    const bool staged = compute_ant && ((reinterpret_cast<uintptr_t>(d_r_head) | reinterpret_cast<uintptr_t>(d_l_head)) & 15) == 0;
+    if (staged) hipLaunchKernelGGL(seqik_head_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
+    else hipLaunchKernelGGL(seqik_head_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), a);
     HTRY(hipGetLastError());
     return SEQIK_OK;
 }

@@ -14,17 +14,26 @@
 
 namespace seqik {
 
+// This file is built with -ffp-contract=off like the solver (one flag set for the library), but nothing here is pinned
+// bit for bit to an oracle (the angles are compared with the reference at a tolerance), so products feeding sums are
+// written as explicit fused multiply-adds: a third fewer vector instructions than the separate multiply + add.
+SEQIK_HD double hfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // 1 / sqrt(v) and 1 / q without the IEEE corner-case handling of the compiler's division / square-root expansions (34
-// and 12 instructions): hardware seed + three Newton steps, ~1 ulp, 11 / 7 instructions.  Host builds (tests/harness) use
-// the plain expressions.
+// and 12 instructions): hardware seed (v_rcp_f64 / v_rsq_f64) + two / three Newton steps (measured against the host
+// formulas on 6000 frames, scripts/microbench/head_split.hip: 2 + 3 steps 4e-12 rad, 2 + 2 steps 1.5e-11; the seeds are
+// good to ~2^-23 and the reciprocal's argument is in [0.6, 1], the square root's feeds an acos).  Host builds
+// (tests/harness) use the plain expressions.
+#ifndef SEQIK_HEAD_NEWTON
+#define SEQIK_HEAD_NEWTON 2
+#endif
 SEQIK_HD double inv_sqrt(double v)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rsq(v);
     const double h = 0.5 * v;
-    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
-    y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);   // the seed is good to ~2^-10: three steps for ~1 ulp
+#pragma unroll
+    for (int i = 0; i < SEQIK_HEAD_NEWTON + 1; ++i) y = hfma(y, hfma(-(h * y), y, 0.5), y);
     return y;
 #else
     return 1.0 / sqrt(v);
@@ -35,9 +44,8 @@ SEQIK_HD double inv(double q)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rcp(q);
-    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-q, r, 1.0), r);
+#pragma unroll
+    for (int i = 0; i < SEQIK_HEAD_NEWTON; ++i) r = hfma(r, hfma(-q, r, 1.0), r);
     return r;
 #else
     return 1.0 / q;
@@ -59,14 +67,14 @@ SEQIK_HD double acos_unit(double x)
                  Q4 = 7.70381505559019352791e-02;
     const double a = fabs(x);
     const bool small = a <= 0.5;
-    const double z = small ? x * x : (1.0 - a) * 0.5;
-    const double p = z * (P0 + z * (P1 + z * (P2 + z * (P3 + z * (P4 + z * P5)))));
-    const double q = 1.0 + z * (Q1 + z * (Q2 + z * (Q3 + z * Q4)));
+    const double z = small ? x * x : hfma(a, -0.5, 0.5);
+    const double p = z * hfma(z, hfma(z, hfma(z, hfma(z, hfma(z, P5, P4), P3), P2), P1), P0);
+    const double q = hfma(z, hfma(z, hfma(z, hfma(z, Q4, Q3), Q2), Q1), 1.0);
     const double r = p * inv(q);          // q in [0.6, 1]
     const double s = z * inv_sqrt(z + 1e-300);  // sqrt(z), z in [0, 1/4] (the tiny offset keeps z = 0 finite)
-    const double w = s + r * s;
-    const double big = (x > 0.0) ? 2.0 * w : PI - 2.0 * (w - PIO2_LO);
-    const double sm = PIO2_HI - (x - (PIO2_LO - x * r));
+    const double w = hfma(r, s, s);
+    const double big = (x > 0.0) ? 2.0 * w : hfma(-2.0, w - PIO2_LO, PI);
+    const double sm = PIO2_HI - (x - hfma(-x, r, PIO2_LO));
     return small ? sm : big;
 }
 
@@ -79,10 +87,10 @@ SEQIK_HD double acos_unit(double x)
 //   planar_angle(a0, a1, b0, b1): vectors (a0, a1), (b0, b1) in the plane, det = a0 b1 - a1 b0
 SEQIK_HD double planar_angle(double a0, double a1, double b0, double b1)
 {
-    const double n1 = a0 * a0 + a1 * a1;
-    const double n2 = b0 * b0 + b1 * b1;
-    double d = (a0 * b0 + a1 * b1) * inv_sqrt(n1 * n2);
-    const double det = a0 * b1 - a1 * b0;
+    const double n1 = hfma(a0, a0, a1 * a1);
+    const double n2 = hfma(b0, b0, b1 * b1);
+    double d = hfma(a0, b0, a1 * b1) * inv_sqrt(n1 * n2);
+    const double det = hfma(a0, b1, -(a1 * b0));
     d = fmin(1.0, fmax(-1.0, d));  // guard the last-ulp overshoot of the fused normalisation
     const double ang = acos_unit(d);
     return (det > 0) ? ang : -ang;
@@ -93,7 +101,7 @@ SEQIK_HD double planar_angle(double a0, double a1, double b0, double b1)
 //   (b_along / |b|, b_across / |b|), which is all the derotation by the head roll needs.
 SEQIK_HD double axis_angle(double b_along, double b_across, double *cos_out = nullptr, double *sin_out = nullptr)
 {
-    const double n2 = b_along * b_along + b_across * b_across;
+    const double n2 = hfma(b_along, b_along, b_across * b_across);
     const double rn = inv_sqrt(n2);
     const double d = fmin(1.0, fmax(-1.0, b_along * rn));
     if (cos_out) { *cos_out = d; *sin_out = b_across * rn; }
@@ -108,8 +116,8 @@ SEQIK_HD double axis_angle(double b_along, double b_across, double *cos_out = nu
 SEQIK_HD void derotate_x(double m11, double two_xw, const double *v, double *out)
 {
     out[0] = v[0];
-    out[1] = m11 * v[1] - two_xw * v[2];
-    out[2] = two_xw * v[1] + m11 * v[2];
+    out[1] = hfma(m11, v[1], -(two_xw * v[2]));
+    out[2] = hfma(two_xw, v[1], m11 * v[2]);
 }
 
 struct HeadArgs {
@@ -123,30 +131,28 @@ struct HeadArgs {
     int32_t compute_ant;
 };
 
-SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
+// The seven angles of one frame from its key points: rb / lb = antenna base + tip (right / left, 6 doubles each),
+// neck (3).  out: head roll, pitch, yaw, antenna yaw L, pitch L, yaw R, pitch R (the last four only with compute_ant).
+SEQIK_HD void head_angles_compute(const double *rb, const double *lb, const double *neck, double rest_head_pitch,
+                                  double rest_antenna_pitch, bool compute_ant, double *out)
 {
     const double PI = 3.141592653589793;
-    const double *rb = a.r_head + t * 6, *lb = a.l_head + t * 6;
-    const double *neck = a.neck + t * a.neck_stride;
     double hor[3] = {lb[0] - rb[0], lb[1] - rb[1], lb[2] - rb[2]};            // R base -> L base
-    double mid[3] = {(rb[0] + lb[0]) * 0.5 - neck[0], (rb[1] + lb[1]) * 0.5 - neck[1],
-                     (rb[2] + lb[2]) * 0.5 - neck[2]};                        // neck -> mid antenna base
+    double mid[3] = {hfma(rb[0] + lb[0], 0.5, -neck[0]), hfma(rb[1] + lb[1], 0.5, -neck[1]),
+                     hfma(rb[2] + lb[2], 0.5, -neck[2])};                     // neck -> mid antenna base
     // head roll (:196-210): Y axis -> horizontal vector projected on the transverse (y, z) plane, about X:
     //   det([X, Y, v]) = v_z
     double cos_roll, sin_roll;
-    const double roll = axis_angle(hor[1], hor[2], &cos_roll, &sin_roll);
+    out[0] = axis_angle(hor[1], hor[2], &cos_roll, &sin_roll);
     // head pitch (:180-194): X axis -> mid vector projected on the sagittal (z, x) plane, about Y: det([Y, X, v]) = -v_z
-    const double pitch = axis_angle(mid[0], -mid[2]) + a.rest_head_pitch;
+    out[1] = axis_angle(mid[0], -mid[2]) + rest_head_pitch;
     // head yaw (:212-226): Y axis -> horizontal vector projected on the frontal (x, y) plane, about Z: det([Z, Y, v]) = -v_x
-    const double yaw = axis_angle(hor[1], -hor[0]);
-    const int64_t n = a.n_frames;
-    a.angles[t] = roll;
-    a.angles[n + t] = pitch;
-    a.angles[2 * n + t] = yaw;
-    if (!a.compute_ant) return;
+    out[2] = axis_angle(hor[1], -hor[0]);
+    if (!compute_ant) return;
     const double m11 = cos_roll, two_xw = -sin_roll;
     double hor_d[3];
     derotate_x(m11, two_xw, hor, hor_d);
+#pragma unroll
     for (int side = 0; side < 2; ++side) {  // 0 = L, 1 = R (the reference's dict order)
         const double *base = side == 0 ? lb : rb;
         double ant[3] = {base[3] - base[0], base[4] - base[1], base[5] - base[2]};
@@ -159,10 +165,19 @@ SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
         if (side == 1) ayaw = PI - ayaw;
         // antenna pitch (:228-260): head vector vs antenna, both on the sagittal plane, about Y:
         //   det([Y, h, a]) = h_z a_x - h_x a_z  (plane coordinates (z, x))
-        const double apitch = planar_angle(head_d[2], head_d[0], ant_d[2], ant_d[0]) - a.rest_antenna_pitch;
-        a.angles[(3 + 2 * side) * n + t] = ayaw;
-        a.angles[(4 + 2 * side) * n + t] = apitch;
+        out[3 + 2 * side] = ayaw;
+        out[4 + 2 * side] = planar_angle(head_d[2], head_d[0], ant_d[2], ant_d[0]) - rest_antenna_pitch;
     }
+}
+
+// one frame straight from / to the caller's arrays (partial wavefronts at the end of a launch; tests/harness)
+SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
+{
+    double out[7];
+    head_angles_compute(a.r_head + t * 6, a.l_head + t * 6, a.neck + t * a.neck_stride, a.rest_head_pitch,
+                        a.rest_antenna_pitch, a.compute_ant != 0, out);
+    const int n_out = a.compute_ant ? 7 : 3;
+    for (int j = 0; j < n_out; ++j) a.angles[j * a.n_frames + t] = out[j];
 }
 
 }  // namespace seqik

@@ -88,3 +88,25 @@ def test_head_kernel_streaming_rate_and_linearity(z, hiplib):
     small = hiplib.head_angles(z["R_head"], z["L_head"], z["Neck"][:, 0], z["rest_head_pitch"][0],
                                z["rest_antenna_pitch"][0])
     assert np.array_equal(out.cpu().numpy().reshape(7, reps, 6000), np.broadcast_to(small[:, None], (7, reps, 6000)))
+    # records that are only 8-byte aligned take the per-lane loads instead of the staged 16-byte ones: same bits;
+    # so does a run without the antenna angles (three rows written, the others untouched)
+    m = 100_003
+    r_off = torch.zeros(m * 6 + 1, dtype=torch.float64, device="cuda")
+    l_off = torch.zeros(m * 6 + 1, dtype=torch.float64, device="cuda")
+    r_off[1:] = r[:m].reshape(-1)
+    l_off[1:] = l[:m].reshape(-1)
+    out2 = torch.full((7, m), 7.0, dtype=torch.float64, device="cuda")
+    assert (r_off.data_ptr() + 8) % 16 == 8
+    rc = lib.seqik_head_angles_device(r_off.data_ptr() + 8, l_off.data_ptr() + 8, m, neck.data_ptr(), 0,
+                                      float(z["rest_head_pitch"][0]), float(z["rest_antenna_pitch"][0]), 1,
+                                      out2.data_ptr(), stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out[:, :m])
+    out3 = torch.full((7, m), 7.0, dtype=torch.float64, device="cuda")
+    rc = lib.seqik_head_angles_device(r.data_ptr(), l.data_ptr(), m, neck.data_ptr(), 0,
+                                      float(z["rest_head_pitch"][0]), float(z["rest_antenna_pitch"][0]), 0,
+                                      out3.data_ptr(), stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out3[:3], out[:3, :m]) and bool((out3[3:] == 7.0).all())
