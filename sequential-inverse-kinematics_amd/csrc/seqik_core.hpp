@@ -1058,6 +1058,12 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
     bool have_pe = false;
 
+    // (Tried and dropped: loading the NEXT frame's inputs (key point, origin, prefix frame: 18 doubles) into staging
+    // registers at the top of every pass and moving them into place when a lane finishes its frame, so that no lane
+    // waits for the memory round trip of a frame start -- every pass has a few lanes starting one.  The generated code
+    // did what was intended (loads at the top, `s_waitcnt vmcnt(8)` behind the finished frame's stores), needs 36 more
+    // registers, i.e. two waves per SIMD: 15.1 ms per benchmark step against 15.2 without it at two waves, 13.7 at the
+    // usual three (20.8 with the staging registers spilled at three).  The frame-start loads are not what waves wait for.)
     // (Tried and dropped: keeping finished lanes in the loop and letting all 64 lanes execute a burst of dummy
     // multiply-adds per pass while fewer than 16 lanes are still working, to keep the wave out of the slow sparse-EXEC
     // mode of scripts/microbench/exec_*.hip during the end-of-stage tail: 14.2 -> 15.0 ms per benchmark step.)
@@ -1318,7 +1324,11 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     for (int i = 0; i < 3; ++i) w[9 + i] = after.t[i];
                 }
                 if (WANT_FK && STAGE >= 2 && stored) {
-                    const double *origin = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
+                    // (the origin is read into registers BEFORE the first store: pose and fk may alias as far as the
+                    // compiler knows, and re-reading origin[a] after every store made each of the up to 21 stores below
+                    // wait for a memory round trip of its own: 14.1 -> 13.7 ms per benchmark step)
+                    const double *origin_p = lc.aff.enabled ? lc.aff.template_coxa : io.pose + t * io.pose_frame;
+                    const double origin[3] = {origin_p[0], origin_p[1], origin_p[2]};
                     double *fk = io.fk + t * 27;
                     if constexpr (STAGE == 2) {
                         for (int a = 0; a < 3; ++a) { fk[12 + a] = after.t[a] + origin[a]; fk[15 + a] = after.t[a] + origin[a]; }

@@ -578,7 +578,8 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 if (io.nfev) io.nfev[t] = nfev;
             }
             if (io.fk) {
-                const double *origin = aff.enabled ? aff.template_coxa : io.pose + t * io.pose_frame;
+                const double *origin_p = aff.enabled ? aff.template_coxa : io.pose + t * io.pose_frame;
+                const double origin[3] = {origin_p[0], origin_p[1], origin_p[2]};  // read before the first store (run_stage)
                 double *fk = io.fk + t * 27;
                 Frame e;
                 double coxa_end[3], femur_end[3];
