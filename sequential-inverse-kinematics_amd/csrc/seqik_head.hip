@@ -6,6 +6,7 @@
 
 #include "seqik_head.hpp"
 #include "seqik_device_scope.hpp"
+#include "seqik_hostctx.hpp"
 #include "../../include/seqik.h"
 
 extern "C" void seqik_set_error(int code, const char *msg);
@@ -125,26 +126,29 @@ int seqik_head_angles(const double *r_head, const double *l_head, int64_t n_fram
     const int n_out = compute_ant ? 7 : 3;
     const size_t in_bytes = sizeof(double) * 6 * n_frames;
     const size_t neck_bytes = sizeof(double) * (neck_stride ? 3 * n_frames : 3);
-    double *d_r = nullptr, *d_l = nullptr, *d_n = nullptr, *d_a = nullptr;
-    int rc = SEQIK_OK;
-    do {
-#define HB(expr) { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = hip_fail(e_, #expr); break; } }
-        HB(hipMalloc(reinterpret_cast<void **>(&d_r), in_bytes));
-        HB(hipMalloc(reinterpret_cast<void **>(&d_l), in_bytes));
-        HB(hipMalloc(reinterpret_cast<void **>(&d_n), neck_bytes));
-        HB(hipMalloc(reinterpret_cast<void **>(&d_a), sizeof(double) * 7 * n_frames));
-        HB(hipMemcpy(d_r, r_head, in_bytes, hipMemcpyHostToDevice));
-        HB(hipMemcpy(d_l, l_head, in_bytes, hipMemcpyHostToDevice));
-        HB(hipMemcpy(d_n, neck, neck_bytes, hipMemcpyHostToDevice));
-        rc = seqik_head_angles_device(d_r, d_l, n_frames, d_n, neck_stride, rest_head_pitch, rest_antenna_pitch,
-                                      compute_ant, d_a, nullptr);
-        if (rc != SEQIK_OK) break;
-        HB(hipDeviceSynchronize());
-        HB(hipMemcpy(angles, d_a, sizeof(double) * n_out * n_frames, hipMemcpyDeviceToHost));
-#undef HB
-    } while (0);
-    (void)hipFree(d_r); (void)hipFree(d_l); (void)hipFree(d_n); (void)hipFree(d_a);
-    return rc;
+    const size_t out_bytes = sizeof(double) * 7 * n_frames;
+    // a pooled context (stream + device arena) as the other host-buffer entry points: no hipMalloc / hipFree per call
+    seqik::HostLeaseGuard g;
+    int rc = seqik::host_lease_acquire(&g.lease);
+    if (rc != SEQIK_OK) return rc;
+    rc = seqik::host_lease_reserve(&g.lease, 2 * seqik::arena_padded(in_bytes) + seqik::arena_padded(neck_bytes) +
+                                                 seqik::arena_padded(out_bytes));
+    if (rc != SEQIK_OK) return rc;
+    hipStream_t stream = g.lease.stream;
+    char *p = g.lease.arena;
+    double *d_r = reinterpret_cast<double *>(p); p += seqik::arena_padded(in_bytes);
+    double *d_l = reinterpret_cast<double *>(p); p += seqik::arena_padded(in_bytes);
+    double *d_n = reinterpret_cast<double *>(p); p += seqik::arena_padded(neck_bytes);
+    double *d_a = reinterpret_cast<double *>(p);
+    HTRY(hipMemcpyAsync(d_r, r_head, in_bytes, hipMemcpyHostToDevice, stream));
+    HTRY(hipMemcpyAsync(d_l, l_head, in_bytes, hipMemcpyHostToDevice, stream));
+    HTRY(hipMemcpyAsync(d_n, neck, neck_bytes, hipMemcpyHostToDevice, stream));
+    rc = seqik_head_angles_device(d_r, d_l, n_frames, d_n, neck_stride, rest_head_pitch, rest_antenna_pitch, compute_ant,
+                                  d_a, stream);
+    if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
+    HTRY(hipMemcpyAsync(angles, d_a, sizeof(double) * n_out * n_frames, hipMemcpyDeviceToHost, stream));
+    HTRY(hipStreamSynchronize(stream));
+    return SEQIK_OK;
 }
 
 }  // extern "C"

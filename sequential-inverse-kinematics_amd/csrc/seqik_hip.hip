@@ -10,6 +10,7 @@
 #include "seqik_core.hpp"
 #include "seqik_consts.hpp"
 #include "seqik_device_scope.hpp"
+#include "seqik_hostctx.hpp"
 
 namespace {
 
@@ -1067,6 +1068,36 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
 }
 
 }  // namespace
+
+// the pooled context for the other translation units (seqik_hostctx.hpp)
+namespace seqik {
+
+int host_lease_acquire(HostLease *lease)
+{
+    HostCtx *c = nullptr;
+    const int rc = acquire_ctx(&c);
+    if (rc != SEQIK_OK) return rc;
+    lease->ctx = c;
+    lease->stream = c->stream;
+    lease->arena = c->arena;
+    return SEQIK_OK;
+}
+
+int host_lease_reserve(HostLease *lease, size_t bytes)
+{
+    HostCtx *c = static_cast<HostCtx *>(lease->ctx);
+    const int rc = ctx_reserve(c, bytes);
+    lease->arena = c->arena;
+    return rc;
+}
+
+void host_lease_release(HostLease *lease)
+{
+    if (lease->ctx) release_ctx(static_cast<HostCtx *>(lease->ctx));
+    lease->ctx = nullptr;
+}
+
+}  // namespace seqik
 
 extern "C" {
 

@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
 SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip", "seqik_core.hpp",
-           "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp", "seqik_device_scope.hpp"]
+           "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp", "seqik_device_scope.hpp", "seqik_hostctx.hpp"]
 COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
 

@@ -478,6 +478,12 @@ def test_host_calls_do_not_strand_device_memory(lib):
     for i in range(40):
         out = lib.solve_seq(pose[: 512 - (i % 3)], params)
     assert np.array_equal(out["angles"][:2], ref["angles"])
+    # the head / antenna entry point borrows the same pooled context (no hipMalloc / hipFree per call)
+    zh = load_golden("anipose_head")
+    head0 = lib.head_angles(zh["R_head"], zh["L_head"], zh["Neck"][:, 0], 0.1, 0.2)
+    for i in range(20):
+        head = lib.head_angles(zh["R_head"], zh["L_head"], zh["Neck"][:, 0], 0.1, 0.2)
+    assert np.array_equal(head, head0)
     used = free0 - torch.cuda.mem_get_info()[0]
     assert used < 1.6 * per_call, (used, per_call)      # one context, not one workspace per call
     # concurrent callers get their own contexts and the same bits
