@@ -481,8 +481,8 @@ __device__ __forceinline__ void chunk_io(const KernelArgs &a, const ChunkArgs &c
 // Solves chunks: the four stage bodies back to back, as seqik_fused_kernel, over the frames of one chunk per lane.
 //   CHUNK_SPEC    lane -> virtual chain by chain_of_lane() (leg-pure waves), run-in from the seeds
 //   CHUNK_REPAIR  lanes take the entries of the work list of round ca.round (grid-stride), start from the true state
-//   CHUNK_SWEEP   wave w = real chain w: verify 64 chunks at a time, the lane of the first inconsistent one re-solves
-//                 it, continue behind it (the verification then sees the new last frame)
+//   CHUNK_SWEEP   wave w = real chain w: verify 64 chunks at a time, re-solve the first inconsistent one (on all 64
+//                 lanes, as replicas), continue behind it (the verification then sees the new last frame)
 template <bool WANT_FK, int mode>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
 seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
@@ -539,8 +539,10 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
                 const bool inc = kk < K && chunk_inconsistent(a, ca, wave, v, kk);
                 const unsigned long long m = __ballot(inc);
                 if (m) {
+                    // every lane re-solves the first inconsistent chunk (replicas: same loads, same stores) -- a
+                    // wavefront with one active lane would run in the slow sparse-EXEC mode (chain_of_wave_lane)
                     const int first = __ffsll((long long)m) - 1;
-                    if (lane == first) vc = v;
+                    vc = (seq * K + cursor + first) * a.n_legs + leg;
                     cursor += first + 1;
                     found = true;
                     break;
@@ -552,7 +554,7 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
         if (vc >= 0) {
             seqik::ChainIO io;
             chunk_io(a, ca, vc, leg, mode == CHUNK_SPEC, io);
-            if (mode == CHUNK_SWEEP && ca.stats) atomicAdd(&ca.stats[6], 1);
+            if (mode == CHUNK_SWEEP && ca.stats && lane == 0) atomicAdd(&ca.stats[6], 1);
             const seqik::LegConst &lc = s_legs[leg];
             seqik::run_stage<1, false, false, false, true, true>(lc, io);
             seqik::run_stage<2, WANT_FK, false, false, true, true>(lc, io);
