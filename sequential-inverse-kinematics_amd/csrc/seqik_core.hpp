@@ -1063,7 +1063,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // waits for the memory round trip of a frame start -- every pass has a few lanes starting one.  The generated code
     // did what was intended (loads at the top, `s_waitcnt vmcnt(8)` behind the finished frame's stores), needs 36 more
     // registers, i.e. two waves per SIMD: 15.1 ms per benchmark step against 15.2 without it at two waves, 13.7 at the
-    // usual three (20.8 with the staging registers spilled at three).  The frame-start loads are not what waves wait for.)
+    // usual three (20.8 with the staging registers spilled at three).  The frame-start loads are not what waves wait for.
+    // The same for the key point and origin alone (six doubles) on the stage pipeline's thin wavefronts: serial walk of
+    // the shipped 6000-frame recording 144 -> 174 ms -- vector memory returns in order, so the spill reloads of every
+    // pass then wait for that pass's look-ahead loads instead of one round trip per frame.)
     // (Tried and dropped: keeping finished lanes in the loop and letting all 64 lanes execute a burst of dummy
     // multiply-adds per pass while fewer than 16 lanes are still working, to keep the wave out of the slow sparse-EXEC
     // mode of scripts/microbench/exec_*.hip during the end-of-stage tail: 14.2 -> 15.0 ms per benchmark step.)
