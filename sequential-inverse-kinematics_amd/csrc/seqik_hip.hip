@@ -323,8 +323,11 @@ __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::Chain
 
 // Register budget: as the lane-per-chain kernels, 168 registers = three waves per SIMD = three workgroups per CU (the
 // kernel would take 184): 46 872 chains 18.8 -> 16.0 ms, 23 436 chains with three launches in flight 9.0 -> 7.9 ms.
-template <bool WANT_FK>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+// WPE: waves per SIMD the kernel is compiled for.  3 (168 registers) for grids that put three workgroups on a CU; 2
+// (256 registers, nothing spilled) for the small grids of the latency regime, where a SIMD never holds more than two
+// of these waves anyway: serial walk of the shipped 6000-frame recording 144 -> 139 ms.
+template <bool WANT_FK, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 seqik_pipe_kernel(KernelArgs a)
 {
     __shared__ seqik::LegConst s_legs[kMaxLegs];
@@ -568,8 +571,8 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
 // The speculative pass of a chunked call on the stage pipeline (seqik_pipe_kernel): a workgroup of four waves per group
 // of chunks.  In a workgroup the stage-1 wave of a chunk runs at most PIPE_DEPTH frames ahead of its stage-2 wave; all
 // four store into the chunk's rows / start_state exactly what the lane-per-chunk kernel stores.
-template <bool WANT_FK, int mode>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+template <bool WANT_FK, int mode, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
 {
     static_assert(mode == CHUNK_SPEC || mode == CHUNK_REPAIR, "the sweep stays on the lane-per-chunk kernel");
@@ -983,6 +986,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (grid64 > 0x7fffffffLL || n_waves > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
     const dim3 pipe_grid((unsigned)n_waves), pipe_blk(256);  // one workgroup (4 stage waves) per group of W chains
+    const bool roomy = n_waves <= 2 * 256;  // at most two workgroups per CU: the 256-register build of the pipeline kernels
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
     static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
@@ -1012,8 +1016,11 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
         if (piped) {
-            if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SPEC>), pipe_grid, pipe_blk, 0, stream, a, ca);
-            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SPEC>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            if (roomy) {
+                if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SPEC, 2>), pipe_grid, pipe_blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SPEC, 2>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            } else if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SPEC, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a, ca);
+            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SPEC, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a, ca);
         } else if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         HIP_TRY(hipGetLastError());
@@ -1025,8 +1032,11 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
             hipLaunchKernelGGL(seqik_chunk_scan_kernel, scan_grid, scan_blk, 0, stream, a, ca);
             if (r < ca.n_rounds && piped) {
                 const dim3 rep_pipe_grid((unsigned)(n_waves < 1024 ? n_waves : 1024));
-                if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_REPAIR>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
-                else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_REPAIR>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+                if (roomy) {
+                    if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_REPAIR, 2>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+                    else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_REPAIR, 2>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+                } else if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_REPAIR, SEQIK_WAVES_PER_EU>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_REPAIR, SEQIK_WAVES_PER_EU>), rep_pipe_grid, pipe_blk, 0, stream, a, ca);
             } else if (r < ca.n_rounds) {
                 if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
                 else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_REPAIR>), rep_grid, blk, 0, stream, a, ca);
@@ -1044,8 +1054,11 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (fused) {
         if (opt && opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         if (piped) {
-            if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true>), pipe_grid, pipe_blk, 0, stream, a);
-            else hipLaunchKernelGGL((seqik_pipe_kernel<false>), pipe_grid, pipe_blk, 0, stream, a);
+            if (roomy) {
+                if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true, 2>), pipe_grid, pipe_blk, 0, stream, a);
+                else hipLaunchKernelGGL((seqik_pipe_kernel<false, 2>), pipe_grid, pipe_blk, 0, stream, a);
+            } else if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
+            else hipLaunchKernelGGL((seqik_pipe_kernel<false, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
         } else if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
         else hipLaunchKernelGGL((seqik_fused_kernel<false>), grid, blk, 0, stream, a);
         HIP_TRY(hipGetLastError());
