@@ -304,6 +304,8 @@ def test_lanes_per_wave_does_not_change_results(lib, lanes):
     grouped = lib.solve_generic(gpose, gp, lanes_per_wave=lanes, want_diag=True)
     for k in ("angles", "fk", "status", "nfev"):
         assert np.array_equal(one_lane[k], grouped[k]), k
+    wide = lib.solve_generic(gpose, gp, lanes_per_wave=lanes, block_size=256)  # four wavefronts per workgroup
+    assert np.array_equal(wide["angles"], gen_auto["angles"]) and np.array_equal(wide["fk"], gen_auto["fk"])
 
 
 def test_single_launch_equals_one_launch_per_stage(lib):
