@@ -1067,6 +1067,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // The same for the key point and origin alone (six doubles) on the stage pipeline's thin wavefronts: serial walk of
     // the shipped 6000-frame recording 144 -> 174 ms -- vector memory returns in order, so the spill reloads of every
     // pass then wait for that pass's look-ahead loads instead of one round trip per frame.)
+    // (Tried and dropped: letting finished lanes wait until 4 / 8 / 16 of them have gathered, so that the wavefront goes
+    // through the end-of-frame and start-of-frame blocks -- ~150-250 instructions that it otherwise executes in almost
+    // every pass for two or three lanes -- less often: 14.05 / 13.79 / 13.90 ms per benchmark step against 13.83; what
+    // the blocks save is spent on the additional passes of the waiting lanes.)
     // (Tried and dropped: keeping finished lanes in the loop and letting all 64 lanes execute a burst of dummy
     // multiply-adds per pass while fewer than 16 lanes are still working, to keep the wave out of the slow sparse-EXEC
     // mode of scripts/microbench/exec_*.hip during the end-of-stage tail: 14.2 -> 15.0 ms per benchmark step.)
