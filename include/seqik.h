@@ -110,7 +110,8 @@ typedef struct SeqikOptions {
      * being ~5e-5); inside kinematic-singularity episodes, where the reference itself is chaotic, a
      * 1e-6 difference can pick the other branch.  frame_chunk = 0 keeps the serial walk (bit-exact). */
     int32_t frame_chunk;  /* 0 = serial (default); > 0 = frames per chunk; -1 = automatic (serial for short
-                             recordings, otherwise 8..64 frames so that the chunks fill the GPU).  In automatic mode the
+                             recordings, otherwise 8..64 frames so that the chunks fill the GPU; 4 frames after a run-in of 4 for calls of
+                             at most 1024 chunks of 8).  In automatic mode the
                              host-buffer entry point also checks the speculation: if more than one chunk in eight
                              fails its first verification (data with several equivalent leg configurations, where a
                              run-in does not find the serial trajectory) it returns the SERIAL walk instead and

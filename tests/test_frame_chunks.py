@@ -143,7 +143,11 @@ def test_hip_exact_tolerance_and_automatic_mode(oracle, hiplib):
     assert np.array_equal(exact["angles"], serial["angles"][:, :, :160])  # bit for bit the serial walk
     auto = hiplib.solve_seq(pose, params, frame_chunk=-1)
     st = auto["chunk_stats"]
-    assert st["chunks"] == 6 * 125 and st["frames_per_chunk"] == 8 and st["run_in_frames"] == 8
+    # a call this small (750 chunks of 8 would leave most SIMDs idle) is cut into chunks of 4 after a run-in of 4
+    assert st["chunks"] == 6 * 250 and st["frames_per_chunk"] == 4 and st["run_in_frames"] == 4
+    big = hiplib.solve_seq(np.ascontiguousarray(np.broadcast_to(pose, (2,) + pose.shape[1:])), params, frame_chunk=-1)
+    assert big["chunk_stats"]["chunks"] == 2 * 6 * 125 and big["chunk_stats"]["frames_per_chunk"] == 8   # 1500 chunks of 8
+    assert np.array_equal(big["angles"][0], big["angles"][1])
     assert np.abs(auto["angles"] - serial["angles"]).max() < 2e-5
     assert np.abs(auto["fk"] - serial["fk"]).max() < 2e-5
     short = hiplib.solve_seq(pose[:, :, :40], params, frame_chunk=-1)  # too short: serial
@@ -258,7 +262,7 @@ def test_automatic_chunks_give_way_to_the_serial_walk_when_speculation_fails(ora
     z = load_golden("df3d_1000")
     lg = [str(l) for l in z["legs"]]
     ok = hiplib.solve_seq(np.stack([z[f"{l}_pose"] for l in lg])[None], _params(hiplib, z, lg), frame_chunk=-1)
-    assert ok["chunk_stats"]["chunks"] == 750
+    assert ok["chunk_stats"]["chunks"] == 1500
 
 
 @pytest.mark.gpu

@@ -46,7 +46,7 @@ def test_entire_pipeline(tmp_path, oracle, hiplib, monkeypatch, frame_parallel):
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES, NMF_TEMPLATE
     from seqikpy_amd.utils import calculate_body_size
     body_size = calculate_body_size(NMF_TEMPLATE, ["RF", "LF"])
-    tol = 0.0 if not frame_parallel else 1e-5
+    tol = 0.0 if not frame_parallel else 2e-5  # chunks start within 1e-6 rad of the serial state (tests/test_frame_chunks.py)
     for leg in ("RF", "LF"):
         seg, b, seeds = oracle.leg_params(leg, BOUNDS, body_size, INITIAL_ANGLES)
         ref = oracle.seq_leg(z[f"aligned_{leg}_leg"], seg, b, seeds)
