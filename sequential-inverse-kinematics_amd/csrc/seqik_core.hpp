@@ -1066,7 +1066,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // usual three (20.8 with the staging registers spilled at three).  The frame-start loads are not what waves wait for.
     // The same for the key point and origin alone (six doubles) on the stage pipeline's thin wavefronts: serial walk of
     // the shipped 6000-frame recording 144 -> 174 ms -- vector memory returns in order, so the spill reloads of every
-    // pass then wait for that pass's look-ahead loads instead of one round trip per frame.)
+    // pass then wait for that pass's look-ahead loads instead of one round trip per frame; on the 256-register build, which
+    // has no spills, still 140 -> 144 ms: six loads and their wait in every pass cost more than one round trip per frame.)
     // (Tried and dropped: letting finished lanes wait until 4 / 8 / 16 of them have gathered, so that the wavefront goes
     // through the end-of-frame and start-of-frame blocks -- ~150-250 instructions that it otherwise executes in almost
     // every pass for two or three lanes -- less often: 14.05 / 13.79 / 13.90 ms per benchmark step against 13.83; what
