@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the sequential leg-IK hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]   (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
+
+N > 1: either started by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank per GPU),
+or plainly as `python bench.py --gpus N ...`, in which case this process only LAUNCHES that command as a child, relays
+rank 0's JSON line and exits with the child's code (launch_ranks_if_needed below; it never touches the GPU).
 
 Metric (BASELINE.json): leg-IK solves/s, one solve = one (frame, leg) = 4 stage sub-solves ->
 7 joint angles (+ the stage-4 forward kinematics); and max |d theta| vs the reference (`parity`).
@@ -27,6 +31,10 @@ HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figure
   parity             HIP vs the committed reference fixtures (shipped anipose outputs, df3d reference-source run):
                      max |d theta|, leg-frames over 1e-4 rad and where, for the serial walk and for frame chunks
   cpu_baseline       the C oracle on the host cores, bounded sample of the same workload (+ Python/scipy pool)
+and, at N > 1, `multi_gpu`:
+  ranks_seen, rank_ms_per_step   who took part (rank, host, device from the process group) and how even the ranks were
+  gather_compare     the same batch with the angle gather as peer writes, as grouped RCCL point-to-point, and without
+  strong | weak      the other scaling mode, a short run beside the headline (strong = config 3 literally)
 """
 import argparse
 import json
@@ -40,8 +48,65 @@ from concurrent.futures import ThreadPoolExecutor
 # 4.13e8 -> 3.0e8 solves/s as soon as a process group exists (same as GPU_MAX_HW_QUEUES=2 without one); with 8
 # queues both cases run at 4.13e8.  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and hipIpc handles across processes need it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch_ranks_if_needed(argv):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process becomes the LAUNCHER.  It starts
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a child (one rank per GPU; the
+    shape of the reference's own parallel script, which builds its pool and merges the results itself:
+    examples/example_leg_inv_kinematics_parallel.py:163-198), relays rank 0's single JSON line and exits with the
+    child's code -- non-zero when any rank failed, 124 on time-out, 3 when no JSON line came back.  It runs BEFORE torch
+    is imported and never touches the GPU or the HIP library (a process that has initialised the GPU must not be
+    replaced or forked into ranks)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+        return  # already a rank of a torch.distributed.run job
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as sock:  # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    limit = float(os.environ.get("SEQIK_BENCH_TIMEOUT", "1500"))
+    sys.stderr.write("bench.py launcher: " + " ".join(cmd) + "\n")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = child.communicate(timeout=limit)
+        rc = child.returncode
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)  # the child's own session: torchrun and every rank
+        except ProcessLookupError:
+            pass
+        out, _ = child.communicate()
+        sys.stderr.write(f"bench.py launcher: no result after {limit:.0f} s, ranks killed\n")
+        rc = 124
+    lines = [l for l in (out or "").splitlines() if l.startswith('{"metric"')]
+    for l in (out or "").splitlines():
+        if not l.startswith('{"metric"'):
+            sys.stderr.write(l + "\n")
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        rc = 3
+    sys.exit(rc)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed(sys.argv[1:])
+
 for p in (os.path.join(ROOT, "sequential-inverse-kinematics_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -309,22 +374,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N "
-                             "--master-addr 127.0.0.1 bench.py --gpus N ...")
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher starts one rank per GPU)")
     n_dev = torch.cuda.device_count()
-    device_index = local_rank % max(n_dev, 1)  # (more ranks than GPUs only happens in the gloo dry run)
+    device_index = local_rank % max(n_dev, 1)  # (more ranks than GPUs only happens in the one-GPU rehearsal)
     torch.cuda.set_device(device_index)
     dist = None
     # SEQIK_BENCH_FORCE_DIST=1: run the process-group + gather path with a single rank too (rehearsal of the RCCL
     # code path on a one-GPU box; the gather is then a device-to-device copy)
     use_dist = world > 1 or os.environ.get("SEQIK_BENCH_FORCE_DIST") == "1"
+    backend = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("SEQIK_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo": dry runs
+        # "nccl" = RCCL over xGMI, one GPU per rank.  Ranks that have to share a GPU (rehearsal on a one-GPU box: RCCL
+        # refuses two ranks on one device) talk over gloo; the solver, the peer-write gather and the timing are the same.
+        backend = os.environ.get("SEQIK_BENCH_BACKEND") or ("nccl" if n_dev >= world else "gloo")
         if backend == "nccl":
             # the solver keeps every CU busy for the whole step: give RCCL's stream priority so that the gather's
             # few workgroups are dispatched as soon as a slot frees up instead of behind the queued solver waves
@@ -333,22 +399,29 @@ def main():
                                     pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     T = args.frames_per_seq
     S_total = args.frames // T
-    lo, hi, S_job = sharding.rank_share(S_total, world, rank, args.scaling)
-    if args.scaling == "strong":
-        # the fixed problem: S_total sequences, generated identically on every rank, rank r solves its slice
-        legs, body, pose_all, params = make_workload(S_total, T, args.variant, synthetic.SEED_BASE)
-        pose = pose_all[lo:hi]
-        del pose_all
-    else:
-        legs, body, pose, params = make_workload(S_total, T, args.variant, synthetic.SEED_BASE + 1000 * rank)
+    n_streams = args.streams
+
+    def workload_for(scaling):
+        """(pose of this rank, legs, body, params, leg-frames per step over all ranks)"""
+        lo, hi, S_job = sharding.rank_share(S_total, world, rank, scaling)
+        if scaling == "strong":
+            # the fixed problem: S_total sequences, generated identically on every rank, rank r solves its slice
+            legs_, body_, pose_all, params_ = make_workload(S_total, T, args.variant, synthetic.SEED_BASE)
+            pose_ = pose_all[lo:hi]
+            del pose_all
+        else:
+            legs_, body_, pose_, params_ = make_workload(S_total, T, args.variant, synthetic.SEED_BASE + 1000 * rank)
+        return pose_, legs_, body_, params_, S_job * len(legs_) * T
+
+    pose, legs, body, params, units_all = workload_for(args.scaling)
     S = pose.shape[0]
     L = len(legs)
-    batch = Batch(pose, params, args, args.streams)
+    batch = Batch(pose, params, args, n_streams)
     units_per_step = batch.units  # leg-frames per step on this rank
-    units_all = S_job * L * T  # leg-frames per step over all ranks
     streams = batch.streams
     main_stream = batch.main
     # angle buffers: one per batch in flight + two spare, so that a gather that is still draining (it only gets
@@ -362,42 +435,51 @@ def main():
     gather, gather_how = (peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=8.0)
                           if use_dist else (None, None))
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
-    for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
-        for e in row:
-            e.record(main_stream)
-
-    def step(i, events=None):
-        b = i % n_buf
-        with torch.cuda.stream(streams[i % len(streams)]):
-            if gather:
-                gather.wait_buffer(b)  # the gather that last read this buffer has completed
-            batch.launch(i, d_ang[b], events)
-            if gather:
-                gather.submit(b, d_ang[b])
-
     def sync_all():
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    if gather:
-        gather.drain()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, ev[i])
-    if gather:
-        gather.drain()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def timed_region(bt, bufs, g, steps, warmup, events=None):
+        """W untimed + K timed steps of batch `bt` (round-robin over its streams, gather `g` per step when there is
+        one), bracketed by barrier + synchronize.  Returns (max over ranks, this rank's) seconds."""
+        nb = len(bufs)
+
+        def step(i, evs=None):
+            b = i % nb
+            with torch.cuda.stream(bt.streams[i % len(bt.streams)]):
+                if g:
+                    g.wait_buffer(b)  # the gather that last read this buffer has completed
+                bt.launch(i, bufs[b], evs)
+                if g:
+                    g.submit(b, bufs[b])
+
+        for i in range(warmup):
+            step(i)
+        if g:
+            g.drain()
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i, events[i] if events else None)
+        if g:
+            g.drain()
+        sync_all()
+        mine = time.perf_counter() - t0
+        tmax = mine
+        if dist:
+            t = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tmax = float(t.item())
+        return tmax, mine
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
+        for e in row:
+            e.record(main_stream)
+
+    elapsed, elapsed_mine = timed_region(batch, d_ang, gather, args.steps, args.warmup, ev)
 
     # Outside the timed region: every buffer the overlapped launches wrote must hold, bit for bit, what one launch
     # made alone writes (all steps solve the same batch) -- a measurement of launches that disturbed each other
@@ -484,6 +566,48 @@ def main():
         roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
         roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
 
+    # ---- N > 1: who took part, how even the ranks were, both gathers, and the other scaling mode -- in the same run ----
+    multi = None
+    if dist and world > 1:
+        import socket
+        seen = [None] * world
+        dist.all_gather_object(seen, {"rank": rank, "host": socket.gethostname(), "device": device_index,
+                                      "pid": os.getpid(), "ms_per_step": elapsed_mine / args.steps * 1e3})
+        multi = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a GPU: rehearsal)"),
+                 "ranks_seen": [{k: r[k] for k in ("rank", "host", "device")} for r in seen],
+                 "rank_ms_per_step": {"min": min(r["ms_per_step"] for r in seen), "max": max(r["ms_per_step"] for r in seen),
+                                      "by_rank": [r["ms_per_step"] for r in seen]}}
+        if not args.no_extras:
+            k_cmp = max(4, min(20, args.steps))
+            # the final joint-angle gather, both ways, same batch, same process group: copy-engine peer writes into
+            # rank 0's exported buffers vs grouped RCCL point-to-point (the north star's "RCCL over xGMI")
+            cmp_ = {"steps": k_cmp}
+            for how in ("peer", "rccl"):
+                g2, desc = peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, prefer=how)
+                tm, _ = timed_region(batch, d_ang, g2, k_cmp, min(2, args.warmup))
+                cmp_[how] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm, "ran_as": desc}
+                if hasattr(g2, "close"):
+                    g2.close()
+                del g2
+            tm, _ = timed_region(batch, d_ang, None, k_cmp, min(2, args.warmup))
+            cmp_["no_gather"] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm}
+            multi["gather_compare"] = cmp_
+            # the other scaling mode beside the headline: strong = config 3 literally (the fixed 1M-frame problem split
+            # over the ranks), weak = 1M frames per GPU
+            other_scaling = "strong" if args.scaling == "weak" else "weak"
+            pose2, _, _, _, units_all2 = workload_for(other_scaling)
+            b2 = Batch(pose2, params, args, n_streams)
+            bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
+            g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0)
+            k2 = max(4, min(40, args.steps))
+            tm, _ = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
+            multi[other_scaling] = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
+                                    "steps": k2, "scaling": other_scaling, "sequences_per_gpu": int(pose2.shape[0]),
+                                    "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc}
+            if hasattr(g2, "close"):
+                g2.close()
+            del g2, b2, bufs2, pose2
+
     if rank == 0:
         out = {
             "metric": "leg-IK solves/s (frames x 6 legs); max |d theta| vs reference in `parity`",
@@ -508,6 +632,8 @@ def main():
             "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
                         "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
         }
+        if multi:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_extras:
             # ---- one launch at a time --------------------------------------------------------------------------
             n1 = max(4, min(16, args.steps // 6))

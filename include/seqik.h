@@ -81,7 +81,8 @@ typedef struct SeqikOptions {
                              1024 chains, 64 from there on);
                              [1]: 0 = a run of all four stages without diagnostics is ONE launch (every wave takes its
                              chains through stages 1, 2, 3, 4 in turn; stage_events[0] is then recorded in front of that
-                             kernel and [1]..[4] behind it), 1 = always one launch per stage;
+                             kernel and [1]..[4] behind it), 1 = always one launch per stage (this also switches the
+                             AUTOMATIC stage pipeline of [3] off; an explicit [3] >= 2 and frame chunks still use it);
                              [2]: 0 = all lanes of a wavefront carry the same leg, 1 = consecutive chains (legs
                              interleaved);
                              [3]: stage pipeline -- a workgroup of four wavefronts per group of chains, wavefront k

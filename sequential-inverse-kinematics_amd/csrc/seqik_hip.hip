@@ -980,8 +980,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     // with at most kPipeMaxChains chains / chunks: too few for the lane-per-chain kernels to fill the GPU, so the
     // serial path per frame is what counts), 1 = never, 2 = whenever applicable
     const int pipe_opt = opt ? opt->reserved[3] : 0;
+    const bool staged = opt && opt->reserved[1] == 1;  // "always one launch per stage" rules out the AUTOMATIC pipeline
     const bool piped = first_stage == 1 && last_stage == 4 && !diag &&
-                       (pipe_opt >= 2 || (pipe_opt == 0 && n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
+                       (pipe_opt >= 2 || (pipe_opt == 0 && !(staged && !chunked) &&
+                                          n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
     a.lane_pairs = pipe_opt == 3 ? 0 : 1;  // 3 = as 2, thin waves without lane pairs (measurements)
     a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked || piped);
     int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
@@ -1006,7 +1008,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         if (pool_workspace) HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&a.frames), ws_bytes, stream));
         else if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     }
-    const bool fused = (piped || !(opt && opt->reserved[1] == 1)) && first_stage == 1 && last_stage == 4 && !diag;
+    const bool fused = (piped || !staged) && first_stage == 1 && last_stage == 4 && !diag;
     if (chunked) {
         ChunkArgs ca;
         ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo;

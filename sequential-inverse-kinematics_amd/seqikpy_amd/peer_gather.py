@@ -163,10 +163,12 @@ def make_gather(dist, world: int, rank: int, like, n_buffers: int, dst: int = 0,
                 prefer: Optional[str] = None):
     """The gather pipeline for this process group: ``PeerWriteGather`` when it works on every rank (and each link
     delivers at least ``min_gbps``), else ``GatherPipeline``.  ``prefer``: "peer" / "rccl" / None = the environment
-    variable SEQIK_GATHER or "auto" (peer writes on RCCL process groups, RCCL point-to-point otherwise).
+    variable SEQIK_GATHER or "auto" (peer writes for device buffers, point-to-point of the process group otherwise).
     Returns (pipeline, description)."""
     prefer = prefer or os.environ.get("SEQIK_GATHER", "auto")
-    want_peer = prefer == "peer" or (prefer == "auto" and dist.get_backend() == "nccl" and like.is_cuda)
+    # (gloo process groups over device buffers are the one-GPU rehearsal: the peer path works there too -- the flags
+    # then travel over gloo -- and RCCL's stand-in would stage every block through the host)
+    want_peer = prefer == "peer" or (prefer == "auto" and like.is_cuda)
     if want_peer and world > 1:
         pg = PeerWriteGather(dist, world, rank, like, dst=dst, n_buffers=n_buffers)
         if pg.ok:

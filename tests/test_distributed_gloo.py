@@ -344,3 +344,45 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     assert b["scaling"] == "strong" and b["n_gpus"] == 2
     assert b["config"]["sequences_per_gpu"] == 64 and b["config"]["frames_per_gpu"] == 4096
     assert abs(b["value"] - 8192 * 6 * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) < 1e-6 * b["value"]
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_propagates_rank_failure(tmp_path):
+    """`python bench.py --gpus 2` without a rank environment becomes the launcher (bench.launch_ranks_if_needed): it
+    starts torch.distributed.run as a child and exits with the child's code.  Here there is no GPU, so every rank
+    fails: the launcher must come back non-zero and print no JSON line (never a half result)."""
+    import subprocess
+    if __import__("torch").cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_launches_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SEQIK_BENCH_TIMEOUT"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--frames", "128",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "torch.distributed.run" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks(tmp_path):
+    """The driver's command form, `python3 bench.py --gpus 2 ...` (no torchrun): the process launches its two ranks
+    itself (sharing the box's one GPU, so the process group falls back to gloo), relays ONE JSON line, rc 0; the line
+    carries the N > 1 extras: ranks seen, per-rank step times, both gathers, the strong leg."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--frames", "8192"], env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["roofline"]["frac"] > 0
+    m = b["multi_gpu"]
+    assert sorted(r_["rank"] for r_ in m["ranks_seen"]) == [0, 1]
+    assert m["rank_ms_per_step"]["min"] <= m["rank_ms_per_step"]["max"]
+    assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"])
+    assert "peer writes" in m["gather_compare"]["peer"]["ran_as"]
+    assert m["strong"]["sequences_per_gpu"] == 64 and m["strong"]["leg_frames_per_step_all_ranks"] == 8192 * 6
+    assert abs(b["value"] - 2 * 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]

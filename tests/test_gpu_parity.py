@@ -316,9 +316,11 @@ def test_single_launch_equals_one_launch_per_stage(lib):
     params = _params(lib, z, legs)
     base = np.stack([z[f"{l}_pose"] for l in legs])
     pose = np.stack([base[:, o:o + 40] for o in [(41 * i) % 950 for i in range(200)]])
+    # staged=1 rules out the automatic stage pipeline (1200 chains would otherwise get it): the four stage kernels run
     staged = lib.solve_seq(pose, params, want_fk=True, staged=1)
-    for kw in (dict(), dict(lanes_per_wave=64), dict(lanes_per_wave=3), dict(block_size=256), dict(interleave_legs=1),
-               dict(interleave_legs=1, lanes_per_wave=7)):
+    for kw in (dict(), dict(pipeline=1), dict(pipeline=2), dict(pipeline=1, lanes_per_wave=64), dict(lanes_per_wave=64),
+               dict(lanes_per_wave=3), dict(pipeline=1, lanes_per_wave=3), dict(block_size=256), dict(pipeline=1, block_size=256),
+               dict(interleave_legs=1), dict(pipeline=1, interleave_legs=1), dict(interleave_legs=1, lanes_per_wave=7)):
         one = lib.solve_seq(pose, params, want_fk=True, **kw)
         assert np.array_equal(one["angles"], staged["angles"]) and np.array_equal(one["fk"], staged["fk"]), kw
     assert np.array_equal(lib.solve_seq(pose, params, want_fk=False)["angles"], staged["angles"])
