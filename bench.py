@@ -291,7 +291,7 @@ def single_recording(n_frames=1_000_000, steps=4):
     d_pose = torch.from_numpy(rec).cuda()
     d_ang = torch.zeros((1, L, 7, N), dtype=torch.float64, device="cuda")
     d_fk = torch.zeros((1, L, N, 9, 3), dtype=torch.float64, device="cuda")
-    d_stats = torch.zeros(8, dtype=torch.int32, device="cuda")
+    d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
     layout = _lib.planar_layout(N)
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 2
+#define SEQIK_ABI_VERSION 3
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -88,7 +88,7 @@ typedef struct SeqikOptions {
                              [3]: stage pipeline -- a workgroup of four wavefronts per group of chains, wavefront k
                              running stage k of frame t while wavefront k-1 is already at frame t+1, the prefix frames
                              handed over through LDS: 0 = automatic (runs of all four stages without diagnostics over
-                             at most 1024 chains / frame chunks, where the serial path per frame is what counts),
+                             at most 40 000 chains / frame chunks, where the serial path per frame is what counts),
                              1 = never, 2 = whenever applicable, 3 = as 2 but without lane pairs (a wavefront that
                              carries at most 32 chains runs each on two or more lanes, and neighbouring lanes split
                              the finite-difference columns and the trial point's sin / cos of a pass between them;
@@ -110,22 +110,42 @@ typedef struct SeqikOptions {
      * (measured: <= 1.1e-5 rad on the shipped recordings with the defaults, the reference's own run-to-run noise
      * being ~5e-5); inside kinematic-singularity episodes, where the reference itself is chaotic, a
      * 1e-6 difference can pick the other branch.  frame_chunk = 0 keeps the serial walk (bit-exact). */
-    int32_t frame_chunk;  /* 0 = serial (default); > 0 = frames per chunk; -1 = automatic (serial for short
-                             recordings, otherwise 8..64 frames so that the chunks fill the GPU; 4 frames after a run-in of 4 for calls of
-                             at most 1024 chunks of 8).  In automatic mode the
-                             host-buffer entry point also checks the speculation: if more than one chunk in eight
-                             fails its first verification (data with several equivalent leg configurations, where a
-                             run-in does not find the serial trajectory) it returns the SERIAL walk instead and
-                             reports chunk_stats[0] negative */
+    int32_t frame_chunk;  /* 0 = serial (default: the reference's walk, bit-exact); > 0 = frames per chunk;
+                             -1 = automatic: a function of n_frames ALONE (seqik_frame_chunk_plan), so a recording gets
+                             the same chunks -- hence the same bits -- alone, beside other recordings in one call, or in a
+                             longer batch: serial below 48 frames, 4 frames after a run-in of 4 up to 1365 frames, then
+                             8..64 frames after a run-in of 8.  The automatic mode also guards itself PER CHAIN, on the
+                             device: a chain of which more than one chunk in eight fails the first verification (data
+                             with several equivalent leg configurations, where a run-in does not find the serial
+                             trajectory) is walked serially instead -- the reference's result bit for bit for that
+                             chain; chunk_stats[8] counts such chains, chunk_flags marks their chunks */
     int32_t frame_halo;   /* run-in frames of a speculative chunk; 0 = default (8) */
     double chunk_tol;     /* consistency tolerance in rad; 0 = default (1e-6); negative = 0 (a chunk is accepted
                              only if the run-in reproduced the true state bit for bit) */
     int32_t chunk_rounds; /* parallel repair rounds before the serial sweep; 0 = default (3) */
-    int32_t pad_;
-    int32_t *chunk_stats; /* nullable int32[8], HOST memory for the host-buffer entry points, DEVICE memory for the
+    int32_t frame_lead;   /* ABI 3.  > 0: the call is a SLAB of a longer recording (frame-sharding over GPUs): its first
+                             frame_lead frames are the run-in of chunk 0 (solved from the seeds, not stored), chunk k
+                             stores frames [frame_lead + k C, frame_lead + (k + 1) C).  Chunk 0 is then speculative like
+                             the others; it is verified / repaired against d_init_angles (the true state of the frame in
+                             front of frame_lead) when that is given -- typically in a second, chunk_resume call */
+    int32_t *chunk_stats; /* nullable int32[16], HOST memory for the host-buffer entry points, DEVICE memory for the
                              _device ones: [0] chunks, [1] frames per chunk, [2] run-in frames, [3..5] chunks
                              re-solved in repair rounds 1..3 (later rounds are added to [5]), [6] chunks re-solved
-                             by the serial sweep, [7] chunks found inconsistent by the first verification */
+                             by the serial sweep, [7] chunks found inconsistent by the first verification, [8] chains
+                             the automatic mode walked serially instead, [9] their chunks, [10..15] zero */
+    /* ---- ABI 3 ---------------------------------------------------------------------------------------------------- */
+    uint8_t *chunk_flags; /* nullable [n_seq][n_legs][K] (K from seqik_frame_chunk_plan; host / device memory as
+                             chunk_stats): per chunk, bit 0 = failed the first verification, bit 1 = re-solved in a
+                             repair round, bit 2 = re-solved by the sweep, bit 3 = its chain was walked serially.
+                             Lets a caller see WHERE a recording is chaotic (kinematic-singularity episodes) */
+    double *chunk_states; /* nullable [n_seq][n_legs][K][7], DEVICE entry point only, in/out: the warm start the stored
+                             frames of every chunk were computed from.  Kept by the caller between a call and the
+                             chunk_resume call that continues it */
+    int32_t chunk_resume; /* 1: no speculative pass -- d_angles / d_fk / chunk_states hold the result of an earlier call
+                             with the same geometry, d_init_angles the TRUE state in front of chunk 0; only
+                             verification, repair rounds and sweep run (chunk 0 included).  Needs an explicit
+                             frame_chunk > 0 and chunk_states */
+    int32_t pad2_;
 } SeqikOptions;
 
 /* Element (double) strides of the device buffers of seqik_solve_seq_device.  Chain c = seq * n_legs + leg.
@@ -203,6 +223,11 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
  * above); d_fk is always [chain][frame][9][3], d_status / d_nfev [chain][frame][4].
  * This is the entry point the benchmark times.
  */
+/* The frame chunks a call over recordings of n_frames frames would use with these options (frame_chunk / frame_halo /
+ * frame_lead): frames per chunk, run-in frames, chunks per chain K -- all 0 when the call would be walked serially.
+ * A function of n_frames and the options alone (not of the number of recordings or legs).  No GPU needed. */
+int seqik_frame_chunk_plan(int64_t n_frames, const SeqikOptions *opt, int32_t *chunk, int32_t *halo, int64_t *n_chunks);
+
 int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames,
                            const SeqikLegParams *legs, int32_t first_stage, int32_t last_stage,
                            double *d_angles, double *d_fk, int32_t *d_status, int32_t *d_nfev,

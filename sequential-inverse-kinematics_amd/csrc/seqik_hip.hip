@@ -176,34 +176,41 @@ int pick_lanes_per_wave(int64_t n_chains, const SeqikOptions *opt, bool chunked 
     return (int)((n_chains + 255) / 256 < 1 ? 1 : (n_chains + 255) / 256);  // <= 256 thin waves of 1-4 lanes
 }
 
-// Frame chunks of a call (SeqikOptions.frame_chunk / frame_halo): false = serial walk.
-// Automatic choice: recordings shorter than 48 frames stay serial; otherwise the chunk length is the one that cuts
-// the call into ~196 608 pieces (three full waves on each of the 1024 SIMDs), rounded up to a multiple of 8 and kept
-// within 8..64 frames: the run-in (8 frames by default) is extra work, so chunks are not made shorter than it, and a
-// chunk longer than 64 frames gains nothing (BENCH sequence-length sweep).  Small calls: see below.
-bool pick_frame_chunks(const SeqikOptions *opt, int64_t n_chains, int64_t n_frames, int32_t &chunk, int32_t &halo,
-                       int64_t &n_chunks)
+// Frame chunks of a call (SeqikOptions.frame_chunk / frame_halo / frame_lead): false = serial walk.
+// Automatic choice (frame_chunk = -1): a function of the recording's LENGTH ALONE, so that a recording gets the same
+// chunks -- and therefore the same result, bit for bit -- whether it is solved alone, beside other recordings in one
+// call, or on another day (round-2 review: it used to depend on n_chains x n_frames).  Recordings shorter than 48 frames
+// stay serial; otherwise the chunk length is the one that would cut a SIX-legged recording of that length into ~196 608
+// pieces (three full waves on each of the 1024 SIMDs), rounded up to a multiple of 8 and kept within 8..64 frames: the
+// run-in (8 frames by default) is extra work, so chunks are not made shorter than it, and a chunk longer than 64 frames
+// gains nothing (BENCH sequence-length sweep).  A recording so short that chunks of 8 would leave most of the GPU
+// idle (six legs x N / 8 <= 1024, i.e. up to 1365 frames) is cut finer still -- 4 frames after a run-in of 4: the
+// additional run-in work lands on idle SIMDs and the longest serial piece halves (shipped recordings: RF x 100 frames
+// 0.88 -> 0.53 ms, six legs x 1000 1.06 -> 0.89).  The price of determinism: a call with MANY short recordings pays that
+// doubled run-in work although it would fill the GPU anyway; such callers pass frame_chunk = 0 or explicit values.
+// For the BASELINE configs this reproduces the round-2 choices (config 1 / 2: 4 + 4, config 4: 8 + 8, 1M frames: 32 + 8).
+bool pick_frame_chunks(const SeqikOptions *opt, int64_t n_frames, int32_t &chunk, int32_t &halo, int32_t &lead, int64_t &n_chunks)
 {
     if (!opt || opt->frame_chunk == 0) return false;
+    lead = opt->frame_lead > 0 ? opt->frame_lead : 0;
+    if (lead >= n_frames) return false;
+    const int64_t n = n_frames - lead;  // frames that are stored
     halo = opt->frame_halo > 0 ? opt->frame_halo : 8;
     int64_t c = opt->frame_chunk;
     if (c < 0) {
-        if (n_frames < 48) return false;
-        c = ((n_chains * n_frames / 196608 + 7) / 8) * 8;
+        if (n < 48) return false;
+        c = ((6 * n / 196608 + 7) / 8) * 8;
         c = c < 8 ? 8 : (c > 64 ? 64 : c);
-        // a call that leaves most of the GPU idle even in chunks of 8 (at most 1024 of them: one per SIMD) is cut finer
-        // still -- 4 frames after a run-in of 4: the additional run-in work lands on idle SIMDs and the longest serial
-        // piece of the call halves (shipped recordings: RF x 100 frames 0.88 -> 0.53 ms, six legs x 1000 1.06 -> 0.89)
-        if (c == 8 && n_chains * ((n_frames + 7) / 8) <= 1024) {
+        if (c == 8 && 6 * ((n + 7) / 8) <= 1024) {
             c = 4;
             if (opt->frame_halo <= 0) halo = 4;
         }
     }
-    if (c >= n_frames) return false;
+    if (c >= n && lead == 0 && !opt->chunk_resume) return false;
     if (c > (1 << 20)) c = 1 << 20;
     if (halo > (1 << 20)) halo = 1 << 20;
     chunk = (int32_t)c;
-    n_chunks = (n_frames + c - 1) / c;
+    n_chunks = (n + c - 1) / c;
     return true;
 }
 
@@ -374,12 +381,15 @@ seqik_pipe_kernel(KernelArgs a)
 // of real chain c = seq * n_legs + leg.  Launch sequence on the caller's stream, no host round trip:
 //     chunk kernel  (SPEC)     every virtual chain: chunk 0 from the seeds / init at frame 0, chunk k >= 1 from the
 //                              seeds at frame k C - h; the h run-in frames leave only start_state[vc] (7 angles)
+//     verify kernel            first verification, one wave per real chain: per-chunk report, statistics, and in
+//                              automatic mode the per-chain decision "speculation failed here: walk this chain serially"
 //     R x { scan kernel        which chunks are inconsistent (|start_state - true last frame of chunk k-1| > tol in
 //                              some joint)?  those whose predecessor is consistent go on the work list
 //           chunk kernel (REPAIR)  re-solves the listed chunks from the true state (init = the stored angles of frame
 //                              k C - 1; bit-identical to the serial continuation), start_state[vc] = that state }
 //     scan kernel + chunk kernel (SWEEP)   one wave per real chain walks its chunks left to right and re-solves what is
 //                              still inconsistent: terminates after at most K steps with every chunk consistent
+//     pipe kernel (SERIAL)     automatic mode: the chains the verify kernel gave up on, frame by frame from their seeds
 // Every kernel after a scan that found nothing returns at once (ChunkCtrl), so on well-posed data the tail costs a
 // few empty launches.  Within a round no two adjacent chunks are rewritten, and a chunk is only ever read (its last
 // frame, as warm start) while nobody writes it.
@@ -389,31 +399,82 @@ struct ChunkCtrl {
     int32_t pending;  // chunks this round's scan found inconsistent (listed or not)
 };
 constexpr int kMaxChunkRounds = 8;
+constexpr int kCtrlSerial = kMaxChunkRounds + 1;  // ctrl entry whose `count` is the length of the serial list
+
+// per-chunk report bits (SeqikOptions.chunk_flags)
+enum : uint8_t { CHUNK_FLAG_FAILED_FIRST = 1, CHUNK_FLAG_REPAIRED = 2, CHUNK_FLAG_SWEPT = 4, CHUNK_FLAG_SERIAL = 8 };
 
 struct ChunkArgs {
     int64_t n_chunks;      // K, chunks per chain
     int64_t n_vseq;        // n_seq * K
     int32_t chunk, halo;   // C, h
+    int32_t lead;          // run-in frames in front of chunk 0 (SeqikOptions.frame_lead); chunk k stores [lead + k C, ...)
+    int32_t k_first;       // first chunk that is verified: 1 normally; 0 when chunk 0 is speculative too (lead > 0 /
+                           // resume) AND the true state in front of it is known (KernelArgs::init)
     double tol;
-    double *start_state;   // [n_vchains][7]: the warm start the stored frames of a chunk were computed from
+    double *start_state;   // [n_chains][K][7]: the warm start the stored frames of a chunk were computed from
     int32_t *worklist;     // [n_vchains]
-    ChunkCtrl *ctrl;       // [kMaxChunkRounds + 1]
-    int32_t *stats;        // nullable device int32[8] (SeqikOptions.chunk_stats)
+    ChunkCtrl *ctrl;       // [kMaxChunkRounds + 2]
+    int32_t *stats;        // nullable device int32[16] (SeqikOptions.chunk_stats)
+    uint8_t *flags;        // nullable device [n_chains][K] (SeqikOptions.chunk_flags)
+    int32_t *chain_serial; // [n_chains]: 1 = the automatic mode's guard hands this chain to the serial walk
+    int32_t *serial_list;  // [n_chains]
+    int32_t guard;         // automatic mode: chains with more than one chunk in eight inconsistent are walked serially
+    int32_t resume;        // chunk_resume call: the per-chunk report of the call it continues is kept (bits are added)
     int32_t round;         // entry of ctrl this launch writes (scan) / reads (repair, sweep)
     int32_t n_rounds;      // R
 };
 
-enum : int { CHUNK_SPEC = 0, CHUNK_REPAIR = 1, CHUNK_SWEEP = 2 };
+enum : int { CHUNK_SPEC = 0, CHUNK_REPAIR = 1, CHUNK_SWEEP = 2, CHUNK_SERIAL = 3 };
 
-// does the warm start chunk k of real chain c was computed from differ from the stored last frame of chunk k - 1?
-__device__ __forceinline__ bool chunk_inconsistent(const KernelArgs &a, const ChunkArgs &ca, int64_t c, int64_t vc, int64_t k)
+// does the warm start chunk k of real chain c was computed from differ from the stored last frame of chunk k - 1
+// (chunk 0: from the caller's true state in front of the call, KernelArgs::init)?
+__device__ __forceinline__ bool chunk_inconsistent(const KernelArgs &a, const ChunkArgs &ca, int64_t c, int64_t k)
 {
-    const double *ss = ca.start_state + vc * 7;
-    const double *ang = a.angles + c * a.ang_chain + (k * ca.chunk - 1) * a.ang_frame;
+    const double *ss = ca.start_state + (c * ca.n_chunks + k) * 7;
     bool bad = false;
+    if (k == 0) {
+        const double *init = a.init + c * 7;
 #pragma unroll
-    for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - ang[d * a.ang_dof]) <= ca.tol);  // NaN counts as a mismatch
+        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - init[d]) <= ca.tol);
+    } else {
+        const double *ang = a.angles + c * a.ang_chain + (ca.lead + k * ca.chunk - 1) * a.ang_frame;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - ang[d * a.ang_dof]) <= ca.tol);  // NaN counts as a mismatch
+    }
     return bad;
+}
+
+// First verification, one wavefront per real chain: which chunks start from a state that is not the true one?  Fills the
+// per-chunk report, counts, and -- automatic mode -- decides PER CHAIN whether speculation is worth keeping: a chain with
+// more than one chunk in eight inconsistent (random poses with several equivalent leg configurations do that: a run-in
+// then lands in another configuration than the serial walk about half of the time) is put on the serial list; the scan /
+// repair / sweep kernels leave it alone and seqik_chunk_pipe_kernel<CHUNK_SERIAL> walks it frame by frame from its seeds,
+// which is the reference's result bit for bit.  Per chain, so the decision for a recording does not depend on what else
+// is in the call.
+__global__ void __launch_bounds__(64) seqik_chunk_verify_kernel(KernelArgs a, ChunkArgs ca)
+{
+    const int64_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t K = ca.n_chunks;
+    int fails = 0;
+    for (int64_t k0 = 0; k0 < K; k0 += 64) {
+        const int64_t k = k0 + lane;
+        const bool inc = k < K && k >= ca.k_first && chunk_inconsistent(a, ca, c, k);
+        if (ca.flags && k < K) ca.flags[c * K + k] = (ca.resume ? ca.flags[c * K + k] : 0) | (inc ? CHUNK_FLAG_FAILED_FIRST : 0);
+        fails += __popcll(__ballot(inc));
+    }
+    const bool serial = ca.guard && (int64_t)fails * 8 > K;
+    if (lane == 0) {
+        if (ca.stats && fails) atomicAdd(&ca.stats[7], fails);
+        if (serial) {
+            ca.chain_serial[c] = 1;
+            ca.serial_list[atomicAdd(&ca.ctrl[kCtrlSerial].count, 1)] = (int32_t)c;
+            if (ca.stats) { atomicAdd(&ca.stats[8], 1); atomicAdd(&ca.stats[9], (int32_t)K); }
+        }
+    }
+    if (serial && ca.flags)
+        for (int64_t k = lane; k < K; k += 64) ca.flags[c * K + k] |= CHUNK_FLAG_SERIAL;
 }
 
 __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, ChunkArgs ca)
@@ -428,11 +489,11 @@ __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, Chu
         const int64_t vseq = vc / a.n_legs;
         const int leg = (int)(vc - vseq * a.n_legs);
         const int64_t seq = vseq / ca.n_chunks, k = vseq - seq * ca.n_chunks;
-        if (k > 0) {
-            const int64_t c = seq * a.n_legs + leg;
-            inc = chunk_inconsistent(a, ca, c, vc, k);
+        const int64_t c = seq * a.n_legs + leg;
+        if (k >= ca.k_first && !ca.chain_serial[c]) {
+            inc = chunk_inconsistent(a, ca, c, k);
             // repaired now only if the chunk in front of it is not about to change
-            if (inc) ready = !(k > 1 && chunk_inconsistent(a, ca, c, vc - a.n_legs, k - 1));
+            if (inc) ready = !(k > ca.k_first && chunk_inconsistent(a, ca, c, k - 1));
         }
     }
     int mine = -1;
@@ -442,21 +503,19 @@ __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, Chu
     if (threadIdx.x == 0) {  // one device atomic per workgroup
         if (s_count) s_base = atomicAdd(&ca.ctrl[ca.round].count, s_count);
         if (s_pending) atomicAdd(&ca.ctrl[ca.round].pending, s_pending);
-        if (ca.stats) {
-            if (ca.round == 0 && s_pending) atomicAdd(&ca.stats[7], s_pending);
-            if (ca.round < ca.n_rounds && s_count) atomicAdd(&ca.stats[3 + (ca.round < 2 ? ca.round : 2)], s_count);
-        }
+        if (ca.stats && ca.round < ca.n_rounds && s_count) atomicAdd(&ca.stats[3 + (ca.round < 2 ? ca.round : 2)], s_count);
     }
     __syncthreads();
     if (ready) ca.worklist[s_base + mine] = (int32_t)vc;
 }
 
 // ChainIO of virtual chain vc (chunk k of real chain c): speculative (run-in from the seeds / the caller's init) or
-// repair (from the stored last frame of chunk k - 1, which also becomes the chunk's recorded start state)
+// repair (from the stored last frame of chunk k - 1 -- chunk 0: from the caller's true state --, which also becomes the
+// chunk's recorded start state)
 __device__ __forceinline__ void chunk_io(const KernelArgs &a, const ChunkArgs &ca, int64_t vc, int leg, bool spec,
-                                         seqik::ChainIO &io)
+                                         seqik::ChainIO &io, uint8_t flag = 0)
 {
-    const int64_t K = ca.n_chunks, C = ca.chunk, N = a.n_frames;
+    const int64_t K = ca.n_chunks, C = ca.chunk, N = a.n_frames, lead = ca.lead;
     const int64_t vseq = vc / a.n_legs;
     const int64_t seq = vseq / K, k = vseq - seq * K;
     const int64_t c = seq * a.n_legs + leg;
@@ -469,23 +528,47 @@ __device__ __forceinline__ void chunk_io(const KernelArgs &a, const ChunkArgs &c
     io.fk = a.fk ? a.fk + c * N * 27 : nullptr;
     io.status = nullptr;
     io.nfev = nullptr;
-    io.frames = a.frames + vc * (C + ca.halo) * 12;
-    io.t_store = k * C;
-    io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
-    double *ss = ca.start_state + vc * 7;
+    const int64_t ws_frames = C + (ca.halo > lead ? ca.halo : lead);
+    io.frames = a.frames + vc * ws_frames * 12;
+    io.t_store = lead + k * C;
+    io.n_frames = lead + (k + 1) * C < N ? lead + (k + 1) * C : N;
+    double *ss = ca.start_state + (c * K + k) * 7;
     if (spec) {
-        io.t_begin = (k * C > ca.halo) ? k * C - ca.halo : 0;
-        io.init = (k == 0 && a.init) ? a.init + c * 7 : nullptr;
+        const bool run_in = k > 0 || lead > 0;  // chunk 0 of a call with a lead is speculative like the others
+        io.t_begin = (k > 0 && io.t_store > ca.halo) ? io.t_store - ca.halo : 0;
+        io.init = (!run_in && a.init) ? a.init + c * 7 : nullptr;
         io.init_stride = 1;
-        io.start_state = (k > 0) ? ss : nullptr;
+        io.start_state = run_in ? ss : nullptr;
     } else {
         io.t_begin = io.t_store;
-        io.init = io.angles + (io.t_store - 1) * a.ang_frame;
-        io.init_stride = a.ang_dof;
+        if (k == 0) { io.init = a.init + c * 7; io.init_stride = 1; }
+        else { io.init = io.angles + (io.t_store - 1) * a.ang_frame; io.init_stride = a.ang_dof; }
         io.start_state = nullptr;
 #pragma unroll
-        for (int d = 0; d < 7; ++d) ss[d] = io.init[d * a.ang_dof];
+        for (int d = 0; d < 7; ++d) ss[d] = io.init[d * io.init_stride];
+        if (ca.flags && flag) ca.flags[c * K + k] |= flag;  // (replicas write the same byte)
     }
+}
+
+// ChainIO of real chain c walked serially from frame 0 (the guard's fallback): the whole call, everything stored
+__device__ __forceinline__ void serial_io(const KernelArgs &a, int64_t c, seqik::ChainIO &io)
+{
+    io.pose = a.pose + c * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c * a.n_frames * 27 : nullptr;
+    io.status = nullptr;
+    io.nfev = nullptr;
+    io.frames = nullptr;
+    io.t_begin = 0;
+    io.t_store = 0;
+    io.n_frames = a.n_frames;
+    io.init = a.init ? a.init + c * 7 : nullptr;
+    io.init_stride = 1;
+    io.start_state = nullptr;
 }
 
 // Solves chunks: the four stage bodies back to back, as seqik_fused_kernel, over the frames of one chunk per lane.
@@ -523,8 +606,8 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
         const int cl = lane / lane_replication((int)W);  // thin waves: every item on 64 / W lanes (see chain_of_wave_lane)
         cursor = (cl < W) ? wave * W + cl : n_items;
     } else if (mode == CHUNK_SWEEP) {
-        if (ca.ctrl[ca.round].pending == 0 || wave >= a.n_chains) return;
-        cursor = 1;  // wave-uniform: next chunk of real chain `wave` to verify
+        if (ca.ctrl[ca.round].pending == 0 || wave >= a.n_chains || ca.chain_serial[wave]) return;
+        cursor = ca.k_first;  // wave-uniform: next chunk of real chain `wave` to verify
     }
     for (;;) {
         int64_t vc = -1;
@@ -545,8 +628,7 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
             bool found = false;
             while (cursor < K) {
                 const int64_t kk = cursor + lane;
-                const int64_t v = (seq * K + kk) * a.n_legs + leg;
-                const bool inc = kk < K && chunk_inconsistent(a, ca, wave, v, kk);
+                const bool inc = kk < K && chunk_inconsistent(a, ca, wave, kk);
                 const unsigned long long m = __ballot(inc);
                 if (m) {
                     // every lane re-solves the first inconsistent chunk (replicas: same loads, same stores) -- a
@@ -563,7 +645,7 @@ seqik_chunk_kernel(KernelArgs a, ChunkArgs ca)
         }
         if (vc >= 0) {
             seqik::ChainIO io;
-            chunk_io(a, ca, vc, leg, mode == CHUNK_SPEC, io);
+            chunk_io(a, ca, vc, leg, mode == CHUNK_SPEC, io, mode == CHUNK_SWEEP ? CHUNK_FLAG_SWEPT : CHUNK_FLAG_REPAIRED);
             if (mode == CHUNK_SWEEP && ca.stats && lane == 0) atomicAdd(&ca.stats[6], 1);
             const seqik::LegConst &lc = s_legs[leg];
             seqik::run_stage<1, false, false, false, true, true>(lc, io);
@@ -582,7 +664,7 @@ template <bool WANT_FK, int mode, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
 {
-    static_assert(mode == CHUNK_SPEC || mode == CHUNK_REPAIR, "the sweep stays on the lane-per-chunk kernel");
+    static_assert(mode == CHUNK_SPEC || mode == CHUNK_REPAIR || mode == CHUNK_SERIAL, "the sweep stays on the lane-per-chunk kernel");
     __shared__ seqik::LegConst s_legs[kMaxLegs];
     __shared__ PipeShared sh;
     {
@@ -603,18 +685,26 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
         // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
         pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a));
     } else {
-        // the work list of round ca.round, spread over the workgroups as thinly as possible; the four stage waves of a
-        // workgroup walk the same entries in the same order (the ring counters of a lane keep counting across entries)
-        const int64_t n_items = ca.ctrl[ca.round].count, n_groups = gridDim.x;
+        // the work list of round ca.round (SERIAL: the serial list), spread over the workgroups as thinly as possible; the
+        // four stage waves of a workgroup walk the same entries in the same order (the ring counters of a lane keep
+        // counting across entries)
+        const int64_t n_items = (mode == CHUNK_SERIAL) ? ca.ctrl[kCtrlSerial].count : ca.ctrl[ca.round].count, n_groups = gridDim.x;
         int64_t W = (n_items + n_groups - 1) / n_groups;
         W = W < 1 ? 1 : (W > 64 ? 64 : W);
         const int cl = lane / lane_replication((int)W);
         int base = 0;
         for (int64_t cursor = (cl < W) ? (int64_t)blockIdx.x * W + cl : n_items; cursor < n_items; cursor += n_groups * W) {
-            const int64_t vc = ca.worklist[cursor];
-            const int leg = (int)(vc % a.n_legs);
             seqik::ChainIO io;
-            chunk_io(a, ca, vc, leg, false, io);
+            int leg;
+            if (mode == CHUNK_SERIAL) {
+                const int64_t c = ca.serial_list[cursor];
+                leg = (int)(c % a.n_legs);
+                serial_io(a, c, io);
+            } else {
+                const int64_t vc = ca.worklist[cursor];
+                leg = (int)(vc % a.n_legs);
+                chunk_io(a, ca, vc, leg, false, io, CHUNK_FLAG_REPAIRED);
+            }
             pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), base);
             base += (int)(io.n_frames - io.t_begin);
         }
@@ -625,8 +715,8 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
 __global__ void seqik_chunk_reset_kernel(ChunkArgs ca, int32_t n_chunks_total)
 {
     const int i = threadIdx.x;
-    if (i <= kMaxChunkRounds) { ca.ctrl[i].count = 0; ca.ctrl[i].pending = 0; }
-    if (ca.stats && i < 8) ca.stats[i] = (i == 0) ? n_chunks_total : (i == 1) ? ca.chunk : (i == 2) ? ca.halo : 0;
+    if (i <= kCtrlSerial) { ca.ctrl[i].count = 0; ca.ctrl[i].pending = 0; }
+    if (ca.stats && i < 16) ca.stats[i] = (i == 0) ? n_chunks_total : (i == 1) ? ca.chunk : (i == 2) ? ca.halo : 0;
 }
 
 // from_angles: first stage of a run that starts after stage 1; handoff: a later stage follows
@@ -744,10 +834,12 @@ struct TableCache {
             size_t lru = 0;
             for (size_t i = 1; i < entries.size(); ++i)
                 if (entries[i].last_use < entries[lru].last_use) lru = i;
-            HIP_TRY(hipSetDevice(entries[lru].device));
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(entries[lru].d));
-            HIP_TRY(hipSetDevice(dev));
+            {
+                seqik::DeviceScope evict;  // restores the caller's device on every path out of this block
+                HIP_TRY(evict.enter(entries[lru].device));
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(entries[lru].d));
+            }
             entries.erase(entries.begin() + lru);
         }
         Entry e;
@@ -970,10 +1062,12 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     const bool fk = d_fk && last_stage == 4;  // FK is the stage-4 chain's (leg_inverse_kinematics.py:279-282)
     if (!fk) a.fk = nullptr;
     // frame chunks (SeqikOptions.frame_chunk): runs of all four stages without diagnostics only
-    int32_t chunk = 0, halo = 0;
+    int32_t chunk = 0, halo = 0, lead = 0;
     int64_t n_chunks = 1;
     const bool chunked = first_stage == 1 && last_stage == 4 && !diag &&
-                         pick_frame_chunks(opt, a.n_chains, n_frames, chunk, halo, n_chunks);
+                         pick_frame_chunks(opt, n_frames, chunk, halo, lead, n_chunks);
+    if (!chunked && opt && (opt->frame_lead > 0 || opt->chunk_resume))
+        return fail(SEQIK_ERR_BAD_ARG, "frame_lead / chunk_resume need frame chunks (frame_chunk != 0, all four stages, no diagnostics)%s");
     const int64_t n_vchains = a.n_chains * n_chunks;  // virtual chains = chunks (= chains when not chunked)
     if (n_vchains > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many frame chunks for one launch%s");
     // stage pipeline (four waves per group of chains, seqik_pipe_kernel): SeqikOptions.reserved[3] = 0 automatic (calls
@@ -999,9 +1093,10 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
     static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
+    const size_t ws_frames = chunked ? (size_t)chunk + (size_t)(halo > lead ? halo : lead) : 0;  // hand-off frames per chunk
     if (chunked) {
-        const size_t ws_bytes = sizeof(double) * (12 * (size_t)(chunk + halo) + 7) * n_vchains + 128 +
-                                sizeof(int32_t) * (size_t)n_vchains;
+        const size_t ws_bytes = sizeof(double) * (12 * ws_frames + 7) * n_vchains + 128 +
+                                sizeof(int32_t) * ((size_t)n_vchains + 2 * (size_t)a.n_chains);
         if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     } else if (last_stage > first_stage && !piped) {
         const size_t ws_bytes = sizeof(double) * 12 * a.n_chains * n_frames;
@@ -1011,20 +1106,38 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     const bool fused = (piped || !staged) && first_stage == 1 && last_stage == 4 && !diag;
     if (chunked) {
         ChunkArgs ca;
-        ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo;
+        ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo; ca.lead = lead;
         ca.tol = (opt->chunk_tol > 0) ? opt->chunk_tol : (opt->chunk_tol < 0 ? 0.0 : 1e-6);
         ca.n_rounds = (opt->chunk_rounds > 0) ? (opt->chunk_rounds < kMaxChunkRounds ? opt->chunk_rounds : kMaxChunkRounds) : 3;
         ca.stats = opt->chunk_stats;
+        ca.flags = opt->chunk_flags;
         ca.round = 0;
-        // carve the workspace: hand-off frames | start states | control block | work list
+        const bool resume = opt->chunk_resume != 0;
+        ca.resume = resume ? 1 : 0;
+        if (resume && !opt->chunk_states)
+            return fail(SEQIK_ERR_BAD_ARG, "chunk_resume needs the chunk_states of the call it resumes%s");
+        // chunk 0 is verified (and repaired) like the others when it started from a run-in and the caller says what the
+        // true state in front of it is
+        ca.k_first = ((lead > 0 || resume) && d_init) ? 0 : 1;
+        // the guard against failed speculation belongs to the automatic mode of a whole recording
+        ca.guard = (opt->frame_chunk == -1 && lead == 0 && !resume) ? 1 : 0;
+        // carve the workspace: [hand-off frames] | start states (unless the caller keeps them) | control block |
+        // work list | serial flags | serial list.  (The stage pipeline hands frames over through LDS, but the sweep at the
+        // end of a piped call runs on the lane-per-chunk kernel and uses the hand-off frames.)
         char *base = reinterpret_cast<char *>(a.frames);
-        size_t off = sizeof(double) * 12 * (size_t)n_vchains * (chunk + halo);
+        size_t off = sizeof(double) * 12 * (size_t)n_vchains * ws_frames;
         ca.start_state = reinterpret_cast<double *>(base + off); off += sizeof(double) * 7 * (size_t)n_vchains;
+        if (opt->chunk_states) ca.start_state = opt->chunk_states;
         ca.ctrl = reinterpret_cast<ChunkCtrl *>(base + off); off += 128;
-        ca.worklist = reinterpret_cast<int32_t *>(base + off);
+        ca.worklist = reinterpret_cast<int32_t *>(base + off); off += sizeof(int32_t) * (size_t)n_vchains;
+        ca.chain_serial = reinterpret_cast<int32_t *>(base + off); off += sizeof(int32_t) * (size_t)a.n_chains;
+        ca.serial_list = reinterpret_cast<int32_t *>(base + off);
         if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
-        if (piped) {
+        HIP_TRY(hipMemsetAsync(ca.chain_serial, 0, sizeof(int32_t) * (size_t)a.n_chains, stream));
+        if (resume) {
+            // nothing is solved speculatively: angles / chunk_states are a previous call's, d_init the true state
+        } else if (piped) {
             if (roomy) {
                 if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SPEC, 2>), pipe_grid, pipe_blk, 0, stream, a, ca);
                 else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SPEC, 2>), pipe_grid, pipe_blk, 0, stream, a, ca);
@@ -1033,6 +1146,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         } else if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(seqik_chunk_verify_kernel, dim3((unsigned)a.n_chains), dim3(64), 0, stream, a, ca);
         const dim3 scan_grid((unsigned)((n_vchains + 255) / 256)), scan_blk(256);
         const int64_t rep_waves = n_waves < 4096 ? n_waves : 4096;  // the work list is walked grid-stride
         const dim3 rep_grid((unsigned)((rep_waves * 64 + block - 1) / block));
@@ -1054,6 +1168,15 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
                 if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SWEEP>), sweep_grid, sweep_blk, 0, stream, a, ca);
                 else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SWEEP>), sweep_grid, sweep_blk, 0, stream, a, ca);
             }
+            HIP_TRY(hipGetLastError());
+        }
+        if (ca.guard) {  // the chains the first verification gave up on: the serial walk, on the stage pipeline
+            const dim3 ser_grid((unsigned)(a.n_chains < 1024 ? a.n_chains : 1024));
+            if (a.n_chains <= 2 * 256) {
+                if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SERIAL, 2>), ser_grid, pipe_blk, 0, stream, a, ca);
+                else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SERIAL, 2>), ser_grid, pipe_blk, 0, stream, a, ca);
+            } else if (fk) hipLaunchKernelGGL((seqik_chunk_pipe_kernel<true, CHUNK_SERIAL, SEQIK_WAVES_PER_EU>), ser_grid, pipe_blk, 0, stream, a, ca);
+            else hipLaunchKernelGGL((seqik_chunk_pipe_kernel<false, CHUNK_SERIAL, SEQIK_WAVES_PER_EU>), ser_grid, pipe_blk, 0, stream, a, ca);
             HIP_TRY(hipGetLastError());
         }
         if (opt->stage_events)
@@ -1117,7 +1240,11 @@ int host_lease_reserve(HostLease *lease, size_t bytes)
 
 void host_lease_release(HostLease *lease)
 {
-    if (lease->ctx) release_ctx(static_cast<HostCtx *>(lease->ctx));
+    if (lease->ctx) {
+        // also on a failing path: work queued so far may still use the arena / the caller's buffers
+        (void)hipStreamSynchronize(static_cast<HostCtx *>(lease->ctx)->stream);
+        release_ctx(static_cast<HostCtx *>(lease->ctx));
+    }
     lease->ctx = nullptr;
 }
 
@@ -1149,11 +1276,12 @@ int seqik_release_workspaces(void)
         w.d = nullptr;
     }
     g_ws.clear();
+    bool any_busy = false;
     {
         std::lock_guard<std::mutex> ctx_lock(g_ctx_mutex);
         for (size_t i = 0; i < g_ctx.size();) {
             HostCtx *c = g_ctx[i];
-            if (c->busy) { ++i; continue; }  // a call is running on another thread
+            if (c->busy) { any_busy = true; ++i; continue; }  // a call is running on another thread
             HIP_TRY(hipSetDevice(c->device));
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->arena) HIP_TRY(hipFree(c->arena));
@@ -1163,6 +1291,9 @@ int seqik_release_workspaces(void)
         }
     }
     HIP_TRY(hipSetDevice(prev));
+    // the cached leg tables stay while a host-buffer call is running on another thread: it may have fetched its table
+    // pointer already and not launched yet (they are freed by the next release that finds every context idle)
+    if (any_busy) return SEQIK_OK;
     if (int rc = g_leg_tables.release()) return rc;
     if (int rc = g_generic_tables.release()) return rc;
     return SEQIK_OK;
@@ -1270,7 +1401,15 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
 // device buffers of one host-buffer call, carved from a pooled context's arena
 struct HostCall {
     HostCtx *ctx = nullptr;
-    ~HostCall() { if (ctx) release_ctx(ctx); }
+    hipStream_t stream = nullptr;
+    // (on every exit path, also the failing ones: copies and kernels queued so far may still be writing into the arena
+    // or the caller's buffers; the context goes back to the pool only once its stream is idle)
+    ~HostCall()
+    {
+        if (!ctx) return;
+        if (stream) (void)hipStreamSynchronize(stream);
+        release_ctx(ctx);
+    }
 };
 
 #define TRY_OUT(expr)                                                                            \
@@ -1302,6 +1441,7 @@ int seqik_solve_generic(const double *pose, int64_t n_seq, int32_t n_legs, int64
                         (init_angles ? ArenaCursor::padded(sizeof(double) * 7 * n_ch) : 0);
     if ((rc = ctx_reserve(call.ctx, need)) != SEQIK_OK) return rc;
     hipStream_t stream = call.ctx->stream;
+    call.stream = stream;
     ArenaCursor cur{call.ctx->arena};
     double *d_pose = cur.take<double>(15 * n_lf), *d_angles = cur.take<double>(7 * n_lf);
     double *d_fk = fk ? cur.take<double>(27 * n_lf) : nullptr;
@@ -1334,24 +1474,32 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     HostCall call;
     if ((rc = acquire_ctx(&call.ctx)) != SEQIK_OK) return rc;
     const bool want_fk = fk && last_stage == 4;
-    // automatic frame chunks keep a check on themselves (below): the statistics are needed even if the caller does
-    // not ask for them
-    const bool auto_chunks = opt && opt->frame_chunk == -1;
-    const bool want_stats = opt && (opt->chunk_stats || auto_chunks);
+    // frame chunks: statistics and the per-chunk report are produced on the device and copied back
+    int32_t pl_chunk = 0, pl_halo = 0, pl_lead = 0;
+    int64_t pl_k = 0;
+    const bool diag = status || nfev;
+    const bool chunked = first_stage == 1 && last_stage == 4 && !diag && pick_frame_chunks(opt, n_frames, pl_chunk, pl_halo, pl_lead, pl_k);
+    if (opt && (opt->chunk_states || opt->chunk_resume))
+        return fail(SEQIK_ERR_BAD_ARG, "chunk_states / chunk_resume: device entry point only (seqik_solve_seq_device)%s");
+    const bool want_stats = opt && opt->chunk_stats;
+    const bool want_flags = opt && opt->chunk_flags && chunked;
     const size_t n_ch = (size_t)n_seq * n_legs;
+    const size_t n_flags = want_flags ? n_ch * (size_t)pl_k : 0;
     const size_t need = ArenaCursor::padded(sizeof(double) * 15 * n_lf) + ArenaCursor::padded(sizeof(double) * 7 * n_lf) +
                         (want_fk ? ArenaCursor::padded(sizeof(double) * 27 * n_lf) : 0) +
                         (status ? ArenaCursor::padded(sizeof(int32_t) * 4 * n_lf) : 0) +
                         (nfev ? ArenaCursor::padded(sizeof(int32_t) * 4 * n_lf) : 0) +
-                        (init_angles ? ArenaCursor::padded(sizeof(double) * 7 * n_ch) : 0) + 256;
+                        (init_angles ? ArenaCursor::padded(sizeof(double) * 7 * n_ch) : 0) + 256 + ArenaCursor::padded(n_flags);
     if ((rc = ctx_reserve(call.ctx, need)) != SEQIK_OK) return rc;
     hipStream_t stream = call.ctx->stream;
+    call.stream = stream;
     ArenaCursor cur{call.ctx->arena};
     double *d_pose = cur.take<double>(15 * n_lf), *d_angles = cur.take<double>(7 * n_lf);
     double *d_fk = want_fk ? cur.take<double>(27 * n_lf) : nullptr;
     int32_t *d_status = status ? cur.take<int32_t>(4 * n_lf) : nullptr, *d_nfev = nfev ? cur.take<int32_t>(4 * n_lf) : nullptr;
     double *d_init = init_angles ? cur.take<double>(7 * n_ch) : nullptr;
-    int32_t *d_stats = cur.take<int32_t>(8);
+    int32_t *d_stats = cur.take<int32_t>(16);
+    uint8_t *d_flags = want_flags ? cur.take<uint8_t>(n_flags) : nullptr;
     if (d_init) TRY_OUT(hipMemcpyAsync(d_init, init_angles, sizeof(double) * 7 * n_ch, hipMemcpyHostToDevice, stream));
     TRY_OUT(hipMemcpyAsync(d_pose, pose, sizeof(double) * 15 * n_lf, hipMemcpyHostToDevice, stream));
     // angles is in/out: columns of stages that do not run are inputs (earlier stages) or stay as they are
@@ -1361,38 +1509,32 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     if (d_nfev) TRY_OUT(hipMemsetAsync(d_nfev, 0, sizeof(int32_t) * 4 * n_lf, stream));
     SeqikOptions dev_opt;
     if (opt) dev_opt = *opt; else memset(&dev_opt, 0, sizeof(dev_opt));
+    dev_opt.chunk_flags = d_flags;
     if (want_stats) {
-        TRY_OUT(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 8, stream));  // stays zero when the call is not chunked
+        TRY_OUT(hipMemsetAsync(d_stats, 0, sizeof(int32_t) * 16, stream));  // stays zero when the call is not chunked
         dev_opt.chunk_stats = d_stats;
     }
     rc = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles,
                                 d_fk, d_status, d_nfev, d_init, nullptr, affine, opt ? &dev_opt : nullptr, stream);
     if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
-    int32_t h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (want_stats) {
-        TRY_OUT(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, stream));
-        TRY_OUT(hipStreamSynchronize(stream));
-        // AUTOMATIC mode only: speculation is for data on which a run-in finds the serial trajectory (real recordings:
-        // 0-2 % of the chunks fail the first verification).  When more than one chunk in eight fails it -- random poses
-        // with several equivalent leg configurations do that -- the recording has no frame-level parallelism to find and
-        // the chunked result would differ from the serial walk in which of the equivalent configurations it follows; the
-        // call then returns the serial walk (key points and options are still on the device).  chunk_stats[0] comes
-        // back NEGATIVE (minus the number of chunks tried) to say so.
-        if (auto_chunks && h_stats[0] > 0 && (int64_t)h_stats[7] * 8 > (int64_t)h_stats[0]) {
-            dev_opt.frame_chunk = 0;
-            dev_opt.chunk_stats = nullptr;
-            rc = seqik_solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_angles, d_fk,
-                                        d_status, d_nfev, d_init, nullptr, affine, &dev_opt, stream);
-            if (rc != SEQIK_OK) { (void)hipStreamSynchronize(stream); return rc; }
-            h_stats[0] = -h_stats[0];
-        }
-        if (opt->chunk_stats) memcpy(opt->chunk_stats, h_stats, sizeof(h_stats));
-    }
+    if (want_stats) TRY_OUT(hipMemcpyAsync(opt->chunk_stats, d_stats, sizeof(int32_t) * 16, hipMemcpyDeviceToHost, stream));
+    if (want_flags) TRY_OUT(hipMemcpyAsync(opt->chunk_flags, d_flags, n_flags, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipMemcpyAsync(angles, d_angles, sizeof(double) * 7 * n_lf, hipMemcpyDeviceToHost, stream));
     if (want_fk) TRY_OUT(hipMemcpyAsync(fk, d_fk, sizeof(double) * 27 * n_lf, hipMemcpyDeviceToHost, stream));
     if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipStreamSynchronize(stream));
+    return SEQIK_OK;
+}
+
+int seqik_frame_chunk_plan(int64_t n_frames, const SeqikOptions *opt, int32_t *chunk, int32_t *halo, int64_t *n_chunks)
+{
+    int32_t c = 0, h = 0, lead = 0;
+    int64_t k = 0;
+    const bool chunked = n_frames > 0 && pick_frame_chunks(opt, n_frames, c, h, lead, k);
+    if (chunk) *chunk = chunked ? c : 0;
+    if (halo) *halo = chunked ? h : 0;
+    if (n_chunks) *n_chunks = chunked ? k : 0;
     return SEQIK_OK;
 }
 #undef TRY_OUT

@@ -207,7 +207,11 @@ int seqik_stream_open(SeqikStream **out, int32_t n_legs, const SeqikLegParams *l
         s->layout = *layout;
         s->have_layout = true;
     }
-    if (opt) { s->opt = *opt; s->opt.stage_events = nullptr; s->opt.chunk_stats = nullptr; }
+    if (opt) {
+        s->opt = *opt;
+        s->opt.stage_events = nullptr; s->opt.chunk_stats = nullptr; s->opt.chunk_flags = nullptr; s->opt.chunk_states = nullptr;
+        s->opt.chunk_resume = 0; s->opt.frame_lead = 0;
+    }
     s->slots.resize(n_slots);
     rc = open_impl(s);
     if (rc != SEQIK_OK) { destroy(s); return rc; }

@@ -40,19 +40,37 @@ class SeqikOptions(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32),
                 ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("reserved", ctypes.c_int32 * 4),
                 ("frame_chunk", ctypes.c_int32), ("frame_halo", ctypes.c_int32), ("chunk_tol", ctypes.c_double),
-                ("chunk_rounds", ctypes.c_int32), ("pad_", ctypes.c_int32),
-                ("chunk_stats", ctypes.POINTER(ctypes.c_int32))]
+                ("chunk_rounds", ctypes.c_int32), ("frame_lead", ctypes.c_int32),
+                ("chunk_stats", ctypes.POINTER(ctypes.c_int32)),
+                ("chunk_flags", ctypes.POINTER(ctypes.c_uint8)), ("chunk_states", ctypes.POINTER(ctypes.c_double)),
+                ("chunk_resume", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+N_CHUNK_STATS = 16
 CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
-                      "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check")
+                      "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check",
+                      "chains_walked_serially", "chunks_of_those_chains")
+CHUNK_FLAG_FAILED_FIRST, CHUNK_FLAG_REPAIRED, CHUNK_FLAG_SWEPT, CHUNK_FLAG_SERIAL = 1, 2, 4, 8
 
 
 def chunk_stats_dict(stats):
-    """int32[8] of ``SeqikOptions.chunk_stats`` -> dict (all zero: the call ran serially; ``chunks`` negative: automatic
-    mode tried that many chunks, found more than one in eight inconsistent and returned the serial walk instead)."""
+    """int32[16] of ``SeqikOptions.chunk_stats`` -> dict (all zero: the call ran serially; ``chains_walked_serially``:
+    chains the automatic mode's per-chain guard handed to the serial walk because more than one of their chunks in eight
+    failed the first verification)."""
     return {k: int(v) for k, v in zip(CHUNK_STATS_FIELDS, stats)}
+
+
+def frame_chunk_plan(n_frames, frame_chunk=-1, frame_halo=0, frame_lead=0):
+    """``seqik_frame_chunk_plan``: (frames per chunk, run-in frames, chunks per chain) a call over recordings of
+    ``n_frames`` frames would use -- (0, 0, 0) when it would be walked serially.  No GPU needed."""
+    opt = SeqikOptions()
+    opt.frame_chunk, opt.frame_halo, opt.frame_lead = int(frame_chunk), int(frame_halo), int(frame_lead)
+    c, h, k = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int64(0)
+    rc = load().seqik_frame_chunk_plan(int(n_frames), ctypes.byref(opt), ctypes.byref(c), ctypes.byref(h), ctypes.byref(k))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return int(c.value), int(h.value), int(k.value)
 
 
 class SeqikLayout(ctypes.Structure):
@@ -162,6 +180,9 @@ def load():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+        L.seqik_frame_chunk_plan.restype = ctypes.c_int
+        L.seqik_frame_chunk_plan.argtypes = [ctypes.c_int64, ctypes.POINTER(SeqikOptions), _ip, _ip,
+                                             ctypes.POINTER(ctypes.c_int64)]
         L.seqik_validate_legs_generic.restype = ctypes.c_int
         L.seqik_validate_legs_generic.argtypes = [ctypes.POINTER(SeqikLegParams), ctypes.c_int32]
         L.seqik_solve_generic.restype = ctypes.c_int
@@ -217,7 +238,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
-                    "seqik_validate_legs",
+                    "seqik_validate_legs", "seqik_frame_chunk_plan",
                     "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
                     "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
@@ -484,7 +505,7 @@ def _affine_array(affine, n_legs):
 
 def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True, want_diag=False,
               device=-1, block_size=0, affine=None, init_angles=None, lanes_per_wave=0, staged=0, interleave_legs=0,
-              frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, pipeline=0):
+              frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, pipeline=0, want_chunk_flags=False):
     """``seqik_solve_seq`` on host arrays.
 
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
@@ -497,7 +518,9 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     solved in concurrently running pieces, equal to the serial walk to about ``chunk_tol`` (default 1e-6 rad).
     ``pipeline``: stage pipeline (``SeqikOptions.reserved[3]``): 0 = automatic (few chains), 1 = never, 2 = always.
     ``device``: HIP device ordinal, -1 = the calling thread's current device.
-    Returns dict(angles, fk or None, status or None, nfev or None, chunk_stats).
+    ``want_chunk_flags``: also return the per-chunk report ``chunk_flags`` (S, L, K) uint8 (``CHUNK_FLAG_*`` bits: failed
+    the first verification / repaired / swept / chain walked serially); None when the call was not chunked.
+    Returns dict(angles, fk or None, status or None, nfev or None, chunk_stats, chunk_flags).
     """
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
@@ -524,13 +547,19 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     opt.reserved[2] = interleave_legs
     opt.reserved[3] = pipeline
     opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
-    stats = np.zeros(8, dtype=np.int32)
+    stats = np.zeros(N_CHUNK_STATS, dtype=np.int32)
     opt.chunk_stats = stats.ctypes.data_as(_ip)
     if init_angles is not None:
         init_angles = np.ascontiguousarray(init_angles, dtype=np.float64)
         if init_angles.shape != (S, L, 7):
             raise ValueError(f"init_angles must have shape {(S, L, 7)}")
     lib = load()
+    flags = None
+    if want_chunk_flags and frame_chunk != 0 and first_stage == 1 and last_stage == 4 and not want_diag:
+        k = frame_chunk_plan(N, frame_chunk, frame_halo)[2]
+        if k > 0:
+            flags = np.zeros((S, L, k), dtype=np.uint8)
+            opt.chunk_flags = flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     rc = lib.seqik_solve_seq(pose.ctypes.data_as(_dp), S, L, N, arr, first_stage, last_stage,
                              angles.ctypes.data_as(_dp),
                              fk.ctypes.data_as(_dp) if fk is not None else None,
@@ -540,13 +569,14 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
                              _affine_array(affine, L), ctypes.byref(opt))
     if rc != SEQIK_OK:
         _raise(rc)
-    return dict(angles=angles, fk=fk, status=status, nfev=nfev, chunk_stats=chunk_stats_dict(stats))
+    return dict(angles=angles, fk=fk, status=status, nfev=nfev, chunk_stats=chunk_stats_dict(stats), chunk_flags=flags)
 
 
 def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_status=0, d_nfev=0,
                      first_stage=1, last_stage=4, stream=0, block_size=0, layout=None, affine=None, d_init=0,
                      stage_events=None, lanes_per_wave=0, staged=0, interleave_legs=0,
-                     frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, d_chunk_stats=0, pipeline=0):
+                     frame_chunk=0, frame_halo=0, chunk_tol=0.0, chunk_rounds=0, d_chunk_stats=0, pipeline=0,
+                     frame_lead=0, d_chunk_flags=0, d_chunk_states=0, chunk_resume=0):
     """``seqik_solve_seq_device``: raw device pointers (ints), asynchronous on ``stream``.
     ``layout``: a ``SeqikLayout`` (``planar_layout(n_frames)``) or None for the dense layout.
     ``stage_events``: optional 5 raw hipEvent_t handles (e.g. ``torch.cuda.Event(...).cuda_event`` after a
@@ -559,8 +589,13 @@ def solve_seq_device(d_pose, n_seq, n_legs, n_frames, legs, d_angles, d_fk=0, d_
     opt.reserved[2] = interleave_legs
     opt.reserved[3] = pipeline
     opt.frame_chunk, opt.frame_halo, opt.chunk_tol, opt.chunk_rounds = frame_chunk, frame_halo, chunk_tol, chunk_rounds
-    if d_chunk_stats:  # device int32[8]
+    opt.frame_lead, opt.chunk_resume = int(frame_lead), int(chunk_resume)
+    if d_chunk_stats:  # device int32[16]
         opt.chunk_stats = ctypes.cast(ctypes.c_void_p(int(d_chunk_stats)), _ip)
+    if d_chunk_flags:  # device uint8 [n_seq][n_legs][K]
+        opt.chunk_flags = ctypes.cast(ctypes.c_void_p(int(d_chunk_flags)), ctypes.POINTER(ctypes.c_uint8))
+    if d_chunk_states:  # device float64 [n_seq][n_legs][K][7]
+        opt.chunk_states = ctypes.cast(ctypes.c_void_p(int(d_chunk_states)), _dp)
     if stage_events is not None:
         ev = (ctypes.c_void_p * 5)(*[ctypes.c_void_p(int(e)) for e in stage_events])
         opt.stage_events = ctypes.cast(ev, ctypes.POINTER(ctypes.c_void_p))

@@ -22,16 +22,30 @@ from .kinematic_chain import KinematicChainSeq
 def run_ik_and_fk_many(recordings: Sequence[Dict[str, np.ndarray]], kinematic_chain_class: KinematicChainSeq,
                        initial_angles: Optional[Dict[str, Dict[str, np.ndarray]]] = None,
                        pad_to_multiple: int = 0, device: int = -1,
-                       leg_affine: Optional[Dict[str, tuple]] = None
+                       leg_affine: Optional[Dict[str, tuple]] = None, frame_parallel=None,
+                       reports: Optional[list] = None
                        ) -> List[Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]]:
-    """``LegInvKinSeq(rec, kinematic_chain_class, initial_angles).run_ik_and_fk()`` for every ``rec``.
+    """``LegInvKinSeq(rec, kinematic_chain_class, initial_angles).run_ik_and_fk(frame_parallel=...)`` for every ``rec``.
+
+    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` (None = its default, the serial walk).  With ``"auto"`` the
+    chunk geometry depends on a recording's length only, so every recording gets the bits it would get alone (with
+    ``pad_to_multiple`` it is the PADDED length that counts).  ``reports``: a list that receives one
+    ``frame_chunk_report`` dict per recording.
 
     recordings: dicts ``"<leg>_leg" -> (N_i, 5, 3)`` holding the same leg keys (other keys are ignored);
     all legs of one recording must have the same number of frames.  ``pad_to_multiple`` > 0 rounds the
     lengths up to that multiple so that recordings of similar length share a launch.
     Returns a list of ``(joint_angles_dict, forward_kinematics_dict)`` in input order."""
+    from .leg_inverse_kinematics import chunk_report, default_frame_parallel
     if initial_angles is None:
         initial_angles = INITIAL_ANGLES
+    if frame_parallel is None:
+        frame_parallel = default_frame_parallel()
+    chunk_opts = dict(frame_chunk=0)
+    if frame_parallel:
+        fp = frame_parallel if isinstance(frame_parallel, dict) else {}
+        chunk_opts = dict(frame_chunk=int(fp.get("chunk", -1)), frame_halo=int(fp.get("halo", 0)),
+                          chunk_tol=float(fp.get("tol", 0.0)), chunk_rounds=int(fp.get("rounds", 0)), want_chunk_flags=True)
     kc = kinematic_chain_class
     if not recordings:
         return []
@@ -59,7 +73,8 @@ def run_ik_and_fk_many(recordings: Sequence[Dict[str, np.ndarray]], kinematic_ch
                 a = np.asarray(recordings[i][name], dtype=np.float64)[:, :5, :]
                 pose[s, li, :lengths[i]] = a
                 pose[s, li, lengths[i]:] = a[-1] if lengths[i] else 0.0
-        out = _lib.solve_seq(pose, legs, want_fk=True, device=device, affine=affine) if n_pad else None
+        out = _lib.solve_seq(pose, legs, want_fk=True, device=device, affine=affine, **chunk_opts) if n_pad else None
+        reps = chunk_report(out, [leg for _, leg in segs], n_pad) if n_pad else [{} for _ in idx]
         for s, i in enumerate(idx):
             n = lengths[i]
             ang, fk = {}, {}
@@ -68,4 +83,8 @@ def run_ik_and_fk_many(recordings: Sequence[Dict[str, np.ndarray]], kinematic_ch
                     ang[f"Angle_{leg}_{dof}"] = out["angles"][s, li, :n, d].copy() if n_pad else np.zeros(0)
                 fk[name] = out["fk"][s, li, :n].copy() if n_pad else np.zeros((0, 9, 3))
             results[i] = (ang, fk)
+            if reports is not None:
+                while len(reports) < len(recordings):
+                    reports.append({})
+                reports[i] = reps[s]
     return results

@@ -11,6 +11,8 @@ from pathlib import Path
 from typing import Dict, Literal, Optional, Tuple, Union
 import logging
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -186,6 +188,35 @@ class LegInvKinBase(ABC):
             self.logger.info("Joint angles and forward kinematics are saved at %s", export_path)
 
 
+def default_frame_parallel():
+    """Default of ``run_ik_and_fk(frame_parallel=...)``: ``False`` = the reference's serial walk, unless the
+    environment variable SEQIK_FRAME_PARALLEL says ``auto``."""
+    v = os.environ.get("SEQIK_FRAME_PARALLEL", "").strip().lower()
+    return "auto" if v in ("auto", "1", "true", "yes") else False
+
+
+def chunk_report(out, leg_names, n_frames):
+    """Per recording (sequence) and leg, where a chunked ``_lib.solve_seq`` result was hard: list over sequences of
+    ``{leg: {...}}`` built from ``chunk_stats`` / ``chunk_flags``; empty dicts when the call was walked serially."""
+    flags, st = out.get("chunk_flags"), out["chunk_stats"]
+    if flags is None or st["chunks"] == 0:
+        return [{} for _ in range(out["angles"].shape[0])]
+    c = st["frames_per_chunk"]
+    reports = []
+    for s in range(flags.shape[0]):
+        rep = {}
+        for li, leg in enumerate(leg_names):
+            f = flags[s, li]
+            redone = (f & (_lib.CHUNK_FLAG_REPAIRED | _lib.CHUNK_FLAG_SWEPT)) != 0
+            spans = [min(c, n_frames - k * c) for k in np.flatnonzero(redone)]
+            rep[leg] = {"frames_per_chunk": c, "run_in_frames": st["run_in_frames"],
+                        "failed_first_check": [int(k) * c for k in np.flatnonzero(f & _lib.CHUNK_FLAG_FAILED_FIRST)],
+                        "frames_repaired": int(sum(spans)),
+                        "walked_serially": bool((f & _lib.CHUNK_FLAG_SERIAL).any())}
+        reports.append(rep)
+    return reports
+
+
 class LegInvKinSeq(LegInvKinBase):
     """Sequential inverse kinematics: four stages per frame, each matching one more joint.
 
@@ -207,6 +238,8 @@ class LegInvKinSeq(LegInvKinBase):
         self.solver_nfev = {}
         #: chunk statistics of the last launch (``_lib.CHUNK_STATS_FIELDS``; all zero = serial walk)
         self.frame_chunk_stats = {}
+        #: per leg, where a chunked run was hard (see ``run_ik_and_fk``); empty after a serial walk
+        self.frame_chunk_report = {}
 
     def _leg_params(self, leg_name, initial_angles=None):
         kc = self.kinematic_chain_class
@@ -266,25 +299,31 @@ class LegInvKinSeq(LegInvKinBase):
         kwargs: ``stages`` (default [1, 2, 3, 4], consecutive), ``hide_progress_bar`` (accepted,
         unused: there is no per-frame host loop), ``diagnostics`` (also collect scipy status/nfev),
         ``frame_parallel``: how the serial frame loop of the reference (:259-282, frame t warm-started from frame
-        t-1) is mapped to the GPU --
+        t-1, :272) is mapped to the GPU --
 
-        * ``"auto"`` (default): recordings of 48 frames and more are cut into frame chunks that are solved
-          concurrently, verified against their true predecessor and repaired on the device
-          (``SeqikOptions.frame_chunk = -1``, include/seqik.h).  Every frame is still solved by the reference's
-          algorithm from a warm start within 1e-6 rad of the serial one; the result equals the serial walk to
-          ~1e-5 rad on well-posed frames (the reference's own run-to-run noise is ~5e-5 rad), 10-50x faster for
-          one recording.  Applies to runs of all four stages without diagnostics; others are walked serially.  The
-          library checks the speculation: if more than one chunk in eight fails its first verification (poses with
-          several equivalent leg configurations) it returns the serial walk instead
-          (``frame_chunk_stats["chunks"]`` is then negative).
-        * ``False``: the serial walk (bit-identical to the oracle restatement of the reference).
-        * ``True`` or a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters.
+        * ``False`` (DEFAULT): the reference's semantics -- every chain is walked frame by frame, bit-identical to the
+          oracle restatement of the reference.  (Environment variable ``SEQIK_FRAME_PARALLEL=auto`` changes the
+          default for a process; an explicit argument always wins.)
+        * ``"auto"``: recordings of 48 frames and more are cut into frame chunks that are solved concurrently, verified
+          against their true predecessor and repaired on the device (``SeqikOptions.frame_chunk = -1``,
+          include/seqik.h): 10-70x faster for one recording.  Every frame is still solved by the reference's algorithm,
+          from a warm start within 1e-6 rad of the serial one; the result equals the serial walk to ~1e-5 rad on
+          well-posed frames (the reference's own run-to-run noise is ~5e-5 rad).  The chunk geometry is a function of
+          the recording's length alone, so a recording gives the same bits alone, inside ``run_ik_and_fk_many`` or in a
+          larger batch.  Applies to runs of all four stages without diagnostics; others are walked serially.  The
+          library guards the speculation per leg: a leg of which more than one chunk in eight fails its first
+          verification (poses with several equivalent leg configurations, kinematic singularities) is walked
+          serially instead (``frame_chunk_report[leg]["walked_serially"]``).
+        * ``True`` or a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters (no guard).
 
-        ``self.frame_chunk_stats`` holds the chunk statistics of the last launch.
+        After a chunked run ``self.frame_chunk_stats`` holds the statistics of the last launch and
+        ``self.frame_chunk_report[leg]`` says where the recording was hard: ``frames_per_chunk``, ``run_in_frames``,
+        ``failed_first_check`` (first frames of the chunks whose run-in did not reproduce the true state -- chaotic
+        episodes show up here), ``frames_repaired``, ``walked_serially``.
         Returns ``(joint_angles_dict, forward_kinematics_dict)``."""
         stages = list(kwargs.get("stages", [1, 2, 3, 4]))
         diagnostics = bool(kwargs.get("diagnostics", False))
-        frame_parallel = kwargs.get("frame_parallel", "auto")
+        frame_parallel = kwargs.get("frame_parallel", default_frame_parallel())
         chunk_opts = dict(frame_chunk=0)
         if frame_parallel is not False and frame_parallel is not None:
             explicit = frame_parallel is True or isinstance(frame_parallel, dict)
@@ -315,8 +354,10 @@ class LegInvKinSeq(LegInvKinBase):
             if self.leg_affine is not None:
                 affine = [_lib.make_affine(*self.leg_affine[leg_name]) for _, leg_name, _ in items]
             out = _lib.solve_seq(pose, legs, first_stage, last_stage, angles=prior, want_fk=True,
-                                 want_diag=diagnostics, device=self.device, affine=affine, **chunk_opts)
+                                 want_diag=diagnostics, device=self.device, affine=affine,
+                                 want_chunk_flags=chunk_opts["frame_chunk"] != 0, **chunk_opts)
             self.frame_chunk_stats = out["chunk_stats"]
+            self.frame_chunk_report.update(chunk_report(out, [leg_name for _, leg_name, _ in items], n_frames)[0])
             for li, (segment_name, leg_name, _) in enumerate(items):
                 for stage in stages:
                     for dof in STAGE_DOFS[stage]:

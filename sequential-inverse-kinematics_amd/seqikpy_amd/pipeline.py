@@ -20,11 +20,16 @@ from .kinematic_chain import KinematicChainSeq
 
 def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: KinematicChainSeq,
                 body_template: Dict[str, np.ndarray], initial_angles: Optional[Dict] = None, device: int = -1,
-                frame_parallel="auto") -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
+                frame_parallel=None, stats: Optional[dict] = None) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """Returns ``(body_joint_angles, forward_kinematics)``: the 7 head / antenna angles (when ``R_head``, ``L_head``
     and ``Neck`` are present) + 7 angles per leg, and the ``"<leg>_leg" -> (N, 9, 3)`` joint positions.
-    ``frame_parallel``: ``"auto"`` (verified frame chunks, as ``LegInvKinSeq.run_ik_and_fk``) or ``False`` (serial)."""
+    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` -- ``False`` / None (default: the reference's serial walk) or
+    ``"auto"`` (verified frame chunks; the same device-side per-leg guard as every other entry point).  ``stats``: a dict
+    that receives the chunk statistics of the launch."""
     import torch
+    from .leg_inverse_kinematics import default_frame_parallel
+    if frame_parallel is None:
+        frame_parallel = default_frame_parallel()
     if initial_angles is None:
         initial_angles = INITIAL_ANGLES
     kc = kinematic_chain_class
@@ -45,8 +50,10 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
         d_fk = torch.zeros((1, len(segs), n, 9, 3), dtype=torch.float64, device="cuda")
         cur = torch.cuda.current_stream()
         leg_stream.wait_stream(cur)
+        d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
         _lib.solve_seq_device(d_pose.data_ptr(), 1, len(segs), n, legs, d_ang.data_ptr(), d_fk.data_ptr(),
-                              stream=leg_stream.cuda_stream, frame_chunk=-1 if frame_parallel else 0)
+                              stream=leg_stream.cuda_stream, frame_chunk=-1 if frame_parallel else 0,
+                              d_chunk_stats=d_stats.data_ptr())
         if with_head:
             hk = HeadInverseKinematics(aligned_pos, body_template, log_level="ERROR")
             r = np.ascontiguousarray(aligned_pos["R_head"], dtype=np.float64)
@@ -65,6 +72,8 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
         head_stream.synchronize()
         ang, fk = d_ang.cpu().numpy(), d_fk.cpu().numpy()
         head = d_head.cpu().numpy() if with_head else None
+        if stats is not None:
+            stats.update(_lib.chunk_stats_dict(d_stats.cpu().numpy()))
     body = {}
     if with_head:
         body.update({name: head[i].copy() for i, name in enumerate(ANGLE_NAMES)})

@@ -1,55 +1,121 @@
-"""TEST INFRASTRUCTURE -- model of the frame-chunk mode (``SeqikOptions.frame_chunk``, include/seqik.h) built on the
-C oracle: the same sequence of solves the library enqueues (speculative pass, ``rounds`` x {verify, repair}, verify +
-serial sweep), every solve being an oracle run over the frames of a chunk.  The HIP path must reproduce it bit for bit.
+"""TEST INFRASTRUCTURE -- model of the frame-chunk mode (``SeqikOptions.frame_chunk``, include/seqik.h, ABI 3) built on the
+C oracle: the same sequence of solves the library enqueues (speculative pass, first verification with the per-chain
+guard of the automatic mode, ``rounds`` x {scan, repair}, scan + serial sweep, serial walk of the chains the guard gave
+up on), every solve being an oracle run over the frames of a chunk.  The HIP path must reproduce it bit for bit,
+statistics and per-chunk report included.  Also models a SLAB of a longer recording (``frame_lead``) and the
+``chunk_resume`` call that settles its first chunk once the true state in front of it is known (frame sharding over ranks).
 """
 import numpy as np
 
+FAILED_FIRST, REPAIRED, SWEPT, SERIAL = 1, 2, 4, 8
 
-def chunked_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, init=None):
-    """One chain: pose (N, 5, 3) -> dict(angles (N, 7), fk (N, 9, 3), stats int32[8]) (stats as chunk_stats)."""
-    N = pose.shape[0]
-    C, h = int(chunk), int(halo)
-    K = -(-N // C)
-    angles, fk = np.zeros((N, 7)), np.zeros((N, 9, 3))
-    ss = np.zeros((K, 7))
-    stats = np.zeros(8, np.int32)
-    stats[:3] = (K, C, h)
 
-    def solve(k, repair):
-        a, b = k * C, min((k + 1) * C, N)
+def plan(n_frames, frame_chunk=-1, frame_halo=0, frame_lead=0):
+    """Restatement of pick_frame_chunks (csrc/seqik_hip.hip): (C, h, K) or (0, 0, 0) when the call is walked serially."""
+    if frame_chunk == 0 or frame_lead >= n_frames:
+        return 0, 0, 0
+    n = n_frames - frame_lead
+    h = frame_halo if frame_halo > 0 else 8
+    c = frame_chunk
+    if c < 0:
+        if n < 48:
+            return 0, 0, 0
+        c = ((6 * n // 196608 + 7) // 8) * 8
+        c = min(max(c, 8), 64)
+        if c == 8 and 6 * ((n + 7) // 8) <= 1024:
+            c = 4
+            if frame_halo <= 0:
+                h = 4
+    if c >= n and frame_lead == 0:
+        return 0, 0, 0
+    return int(c), int(h), int(-(-n // c))
+
+
+class ChunkedChain:
+    """One chain of a chunked call.  ``speculate()`` then ``settle()`` = one library call; a later ``settle(init=...,
+    resume=True)`` = a ``chunk_resume`` call."""
+
+    def __init__(self, oracle, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, init=None, guard=False, lead=0):
+        self.o, self.pose, self.par = oracle, pose, (seg, bounds, seeds)
+        self.N, self.C, self.h, self.lead = pose.shape[0], int(chunk), int(halo), int(lead)
+        self.K = -(-(self.N - self.lead) // self.C)
+        self.tol, self.rounds, self.init, self.guard = tol, rounds, init, guard and lead == 0
+        self.angles, self.fk = np.zeros((self.N, 7)), np.zeros((self.N, 9, 3))
+        self.ss = np.zeros((self.K, 7))
+        self.flags = np.zeros(self.K, np.uint8)
+        self.stats = np.zeros(16, np.int32)
+        self.serial = False
+
+    def span(self, k):
+        return self.lead + k * self.C, min(self.lead + (k + 1) * self.C, self.N)
+
+    def _solve(self, k, repair, flag=0):
+        a, b = self.span(k)
+        seg, bounds, seeds = self.par
         if repair:
-            ss[k] = angles[a - 1]
-            r = oracle.seq_leg(pose[a:b], seg, bounds, seeds, init=angles[a - 1].copy())
+            start = self.init if k == 0 else self.angles[a - 1]
+            self.ss[k] = start
+            r = self.o.seq_leg(self.pose[a:b], seg, bounds, seeds, init=np.array(start, dtype=np.float64).copy())
             off = 0
+            self.flags[k] |= flag
         else:
-            t0 = max(0, a - h) if k > 0 else 0
-            r = oracle.seq_leg(pose[t0:b], seg, bounds, seeds, init=init if k == 0 else None)
+            run_in = k > 0 or self.lead > 0
+            t0 = a - self.h if (k > 0 and a > self.h) else 0
+            r = self.o.seq_leg(self.pose[t0:b], seg, bounds, seeds, init=None if run_in else self.init)
             off = a - t0
-            if k > 0:
-                ss[k] = r["angles"][off - 1]
-        angles[a:b] = r["angles"][off:]
-        fk[a:b] = r["fk"][off:]
+            if run_in:
+                self.ss[k] = r["angles"][off - 1]
+        self.angles[a:b] = r["angles"][off:]
+        self.fk[a:b] = r["fk"][off:]
 
-    for k in range(K):
-        solve(k, False)
+    def speculate(self):
+        for k in range(self.K):
+            self._solve(k, False)
 
-    def inconsistent(k):
-        return not np.all(np.abs(ss[k] - angles[k * C - 1]) <= tol)
+    def _inconsistent(self, k):
+        truth = self.init if k == 0 else self.angles[self.lead + k * self.C - 1]
+        return not np.all(np.abs(self.ss[k] - truth) <= self.tol)
 
-    for r in range(rounds + 1):
-        inc = [k for k in range(1, K) if inconsistent(k)]
-        if r == 0:
-            stats[7] = len(inc)
-        if not inc:
-            break
-        if r < rounds:
-            ready = [k for k in inc if not (k > 1 and (k - 1) in inc)]
-            stats[3 + min(r, 2)] += len(ready)
-            for k in ready:
-                solve(k, True)
-        else:
-            for k in range(1, K):
-                if inconsistent(k):
-                    solve(k, True)
-                    stats[6] += 1
-    return dict(angles=angles, fk=fk, stats=stats)
+    def settle(self, init=None, resume=False):
+        if init is not None:
+            self.init = init
+        self.stats[:] = 0
+        self.stats[:3] = (self.K, self.C, self.h)
+        k_first = 0 if ((self.lead > 0 or resume) and self.init is not None) else 1
+        fails = [k for k in range(k_first, self.K) if self._inconsistent(k)]
+        if not resume:
+            self.flags[:] = 0
+        self.flags[fails] |= FAILED_FIRST
+        self.stats[7] = len(fails)
+        if self.guard and not resume and len(fails) * 8 > self.K:
+            self.serial = True
+            self.flags |= SERIAL
+            self.stats[8], self.stats[9] = 1, self.K
+            seg, bounds, seeds = self.par
+            r = self.o.seq_leg(self.pose, seg, bounds, seeds, init=self.init)
+            self.angles[:], self.fk[:] = r["angles"], r["fk"]
+            return self
+        for r in range(self.rounds + 1):
+            inc = [k for k in range(k_first, self.K) if self._inconsistent(k)]
+            if not inc:
+                break
+            if r < self.rounds:
+                ready = [k for k in inc if not (k > k_first and (k - 1) in inc)]
+                self.stats[3 + min(r, 2)] += len(ready)
+                for k in ready:
+                    self._solve(k, True, REPAIRED)
+            else:
+                for k in range(k_first, self.K):
+                    if self._inconsistent(k):
+                        self._solve(k, True, SWEPT)
+                        self.stats[6] += 1
+        return self
+
+
+def chunked_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, init=None, guard=False):
+    """One chain: pose (N, 5, 3) -> dict(angles (N, 7), fk (N, 9, 3), stats int32[16], flags uint8[K]) (as chunk_stats /
+    chunk_flags)."""
+    m = ChunkedChain(oracle, pose, seg, bounds, seeds, chunk, halo, tol, rounds, init, guard)
+    m.speculate()
+    m.settle()
+    return dict(angles=m.angles, fk=m.fk, stats=m.stats, flags=m.flags)

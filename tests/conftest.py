@@ -74,7 +74,8 @@ class HostHarness:
         self.lib.harness_sincos.argtypes = [ctypes.c_double, dp, dp]
         self.lib.harness_run_chunked.restype = ctypes.c_int
         self.lib.harness_run_chunked.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), ctypes.c_int32,
-                                                 ctypes.c_int32, ctypes.c_double, ctypes.c_int32, dp, dp, dp, ip]
+                                                 ctypes.c_int32, ctypes.c_double, ctypes.c_int32, dp, dp, dp, ip,
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8)]
         self.lib.harness_run_generic.restype = ctypes.c_int
         self.lib.harness_run_generic.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), dp, dp, ip, ip, dp]
         self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
@@ -114,13 +115,17 @@ class HostHarness:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
 
-    def run_chunked(self, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, want_fk=True, init=None):
+    def run_chunked(self, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, want_fk=True, init=None, guard=False,
+                    lead=0):
         """Frame chunks: the device core's CHUNKED code + a serial re-enactment of the launch sequence."""
         dp = ctypes.POINTER(ctypes.c_double)
         pose = np.ascontiguousarray(pose, dtype=np.float64)
         n = pose.shape[0]
         ang, fk = np.zeros((n, 7)), np.full((n, 9, 3), np.nan)
-        stats = np.zeros(8, np.int32)
+        if lead:
+            fk[:lead] = 0.0
+        stats = np.zeros(16, np.int32)
+        flags = np.zeros(-(-(n - lead) // chunk), np.uint8)
         lp = LegParamsC()
         for i in range(4):
             lp.seg[i] = seg[i]
@@ -132,10 +137,11 @@ class HostHarness:
         rc = self.lib.harness_run_chunked(pose.ctypes.data_as(dp), n, ctypes.byref(lp), chunk, halo, tol, rounds,
                                           ang.ctypes.data_as(dp), fk.ctypes.data_as(dp) if want_fk else None,
                                           np.ascontiguousarray(init, dtype=np.float64).ctypes.data_as(dp) if init is not None else None,
-                                          stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+                                          stats.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(bool(guard)), int(lead),
+                                          flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
         if rc != 0:
             raise ValueError(f"harness rc={rc}")
-        return dict(angles=ang, fk=fk if want_fk else None, stats=stats)
+        return dict(angles=ang, fk=fk if want_fk else None, stats=stats, flags=flags)
 
     def run_generic(self, pose, seg, bounds, seeds, init=None):
         dp = ctypes.POINTER(ctypes.c_double)

@@ -53,30 +53,11 @@ extern "C" int harness_run_chain(const double *pose, int64_t n_frames, const Seq
 }
 
 // Frame chunks (SeqikOptions.frame_chunk): the device code's CHUNKED instantiation of run_stage plus a serial
-// re-enactment of the launch sequence of seqik_hip.hip (speculative pass, R x {scan, repair}, scan + sweep) for one
-// chain.  stats as SeqikOptions.chunk_stats.
-static void harness_solve_chunk(const seqik::LegConst &lc, const double *pose, int64_t N, double *angles, double *fk,
-                                int64_t k, int64_t C, int64_t h, bool repair, const double *init0, double *ss, double *ws)
+// re-enactment of the launch sequence of seqik_hip.hip (speculative pass, first verification with the automatic mode's
+// per-chain guard, R x {scan, repair}, scan + sweep, serial walk of a chain the guard gave up on) for one chain.
+// stats as SeqikOptions.chunk_stats (int32[16]), flags as SeqikOptions.chunk_flags (uint8[K]).
+static void harness_run_stages(const seqik::LegConst &lc, seqik::ChainIO &io, bool fk)
 {
-    seqik::ChainIO io;
-    io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
-    io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
-    io.fk = fk; io.status = nullptr; io.nfev = nullptr;
-    io.frames = ws;
-    io.t_store = k * C;
-    io.n_frames = (k + 1) * C < N ? (k + 1) * C : N;
-    if (!repair) {
-        io.t_begin = (k * C > h) ? k * C - h : 0;
-        io.init = (k == 0) ? init0 : nullptr;
-        io.init_stride = 1;
-        io.start_state = (k > 0) ? ss + k * 7 : nullptr;
-    } else {
-        io.t_begin = io.t_store;
-        io.init = angles + (io.t_store - 1) * 7;
-        io.init_stride = 1;
-        io.start_state = nullptr;
-        for (int d = 0; d < 7; ++d) ss[k * 7 + d] = io.init[d];
-    }
     if (fk) {
         seqik::run_stage<1, false, false, false, true, true>(lc, io);
         seqik::run_stage<2, true, false, false, true, true>(lc, io);
@@ -90,45 +71,97 @@ static void harness_solve_chunk(const seqik::LegConst &lc, const double *pose, i
     }
 }
 
+static void harness_solve_chunk(const seqik::LegConst &lc, const double *pose, int64_t N, double *angles, double *fk,
+                                int64_t k, int64_t C, int64_t h, int64_t lead, bool repair, const double *init0, double *ss,
+                                double *ws)
+{
+    seqik::ChainIO io;
+    io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
+    io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
+    io.fk = fk; io.status = nullptr; io.nfev = nullptr;
+    io.frames = ws;
+    io.t_store = lead + k * C;
+    io.n_frames = lead + (k + 1) * C < N ? lead + (k + 1) * C : N;
+    if (!repair) {
+        const bool run_in = k > 0 || lead > 0;
+        io.t_begin = (k > 0 && io.t_store > h) ? io.t_store - h : 0;
+        io.init = run_in ? nullptr : init0;
+        io.init_stride = 1;
+        io.start_state = run_in ? ss + k * 7 : nullptr;
+    } else {
+        io.t_begin = io.t_store;
+        io.init = (k == 0) ? init0 : angles + (io.t_store - 1) * 7;
+        io.init_stride = 1;
+        io.start_state = nullptr;
+        for (int d = 0; d < 7; ++d) ss[k * 7 + d] = io.init[d];
+    }
+    harness_run_stages(lc, io, fk != nullptr);
+}
+
 extern "C" int harness_run_chunked(const double *pose, int64_t N, const SeqikLegParams *leg, int32_t C, int32_t h,
                                    double tol, int32_t rounds, double *angles, double *fk, const double *init,
-                                   int32_t *stats)
+                                   int32_t *stats, int32_t guard, int32_t lead, uint8_t *flags)
 {
     int rc = seqik::validate_leg(*leg, 1, 4);
     if (rc != SEQIK_OK) return rc;
     seqik::LegConst lc;
     seqik::make_leg_consts(*leg, nullptr, lc);
-    const int64_t K = (N + C - 1) / C;
-    std::vector<double> ss((size_t)K * 7, 0.0), ws((size_t)(C + h) * 12 + 1);
-    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    const int64_t K = (N - lead + C - 1) / C;
+    std::vector<double> ss((size_t)K * 7, 0.0), ws((size_t)(C + (h > lead ? h : lead)) * 12 + 1);
+    std::vector<uint8_t> fl((size_t)K, 0);
+    for (int i = 0; i < 16; ++i) stats[i] = 0;
     stats[0] = (int32_t)K; stats[1] = C; stats[2] = h;
-    for (int64_t k = 0; k < K; ++k) harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, false, init, ss.data(), ws.data());
+    for (int64_t k = 0; k < K; ++k) harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, lead, false, init, ss.data(), ws.data());
+    const int64_t k_first = (lead > 0 && init) ? 0 : 1;
     auto inconsistent = [&](int64_t k) {
         bool bad = false;
-        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[k * 7 + d] - angles[(k * C - 1) * 7 + d]) <= tol);
+        const double *truth = (k == 0) ? init : angles + (lead + k * C - 1) * 7;
+        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[k * 7 + d] - truth[d]) <= tol);
         return bad;
     };
+    int fails = 0;
+    for (int64_t k = k_first; k < K; ++k)
+        if (inconsistent(k)) { ++fails; fl[k] |= 1; }
+    stats[7] = fails;
+    if (guard && lead == 0 && (int64_t)fails * 8 > K) {  // the guard: this chain is walked serially
+        stats[8] = 1; stats[9] = (int32_t)K;
+        for (int64_t k = 0; k < K; ++k) fl[k] |= 8;
+        seqik::ChainIO io;
+        io.pose = pose; io.pose_row = 3; io.pose_frame = 15;
+        io.angles = angles; io.ang_dof = 1; io.ang_frame = 7;
+        io.fk = fk; io.status = nullptr; io.nfev = nullptr;
+        std::vector<double> wsN((size_t)N * 12 + 1);
+        io.frames = wsN.data();
+        io.t_begin = 0; io.t_store = 0; io.n_frames = N; io.init = init; io.init_stride = 1; io.start_state = nullptr;
+        harness_run_stages(lc, io, fk != nullptr);
+        if (flags) for (int64_t k = 0; k < K; ++k) flags[k] = fl[k];
+        return SEQIK_OK;
+    }
     for (int r = 0; r <= rounds; ++r) {
         std::vector<int64_t> ready;
         int pending = 0;
-        for (int64_t k = 1; k < K; ++k)
+        for (int64_t k = k_first; k < K; ++k)
             if (inconsistent(k)) {
                 ++pending;
-                if (!(k > 1 && inconsistent(k - 1))) ready.push_back(k);
+                if (!(k > k_first && inconsistent(k - 1))) ready.push_back(k);
             }
-        if (r == 0) stats[7] = pending;
         if (pending == 0) break;
         if (r < rounds) {
             stats[3 + (r < 2 ? r : 2)] += (int32_t)ready.size();
-            for (int64_t k : ready) harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, true, nullptr, ss.data(), ws.data());
+            for (int64_t k : ready) {
+                harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, lead, true, init, ss.data(), ws.data());
+                fl[k] |= 2;
+            }
         } else {
-            for (int64_t k = 1; k < K; ++k)
+            for (int64_t k = k_first; k < K; ++k)
                 if (inconsistent(k)) {
-                    harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, true, nullptr, ss.data(), ws.data());
+                    harness_solve_chunk(lc, pose, N, angles, fk, k, C, h, lead, true, init, ss.data(), ws.data());
+                    fl[k] |= 4;
                     stats[6] += 1;
                 }
         }
     }
+    if (flags) for (int64_t k = 0; k < K; ++k) flags[k] = fl[k];
     return SEQIK_OK;
 }
 

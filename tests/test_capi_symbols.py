@@ -27,7 +27,7 @@ def test_header_declares_expected_entry_points():
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
-                                           "seqik_host_unregister", "seqik_stream_open", "seqik_stream_submit",
+                                           "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_stream_open", "seqik_stream_submit",
                                            "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close",
                                            "seqik_align_stats_open", "seqik_align_stats_add", "seqik_align_stats_finish",
                                            "seqik_align_stats_reset", "seqik_align_stats_close"])
@@ -38,14 +38,16 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 2 == hiplib.ABI_VERSION
+    assert lib.seqik_abi_version() == 3 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):
     assert ctypes.sizeof(hiplib.SeqikLegParams) == 8 * (4 + 14 + 27)
-    assert ctypes.sizeof(hiplib.SeqikOptions) == 64  # ABI 2: + frame chunk options
+    assert ctypes.sizeof(hiplib.SeqikOptions) == 88  # ABI 3: + chunk_flags, chunk_states, chunk_resume
     assert hiplib.SeqikOptions.frame_chunk.offset == 32 and hiplib.SeqikOptions.chunk_tol.offset == 40
-    assert hiplib.SeqikOptions.chunk_stats.offset == 56
+    assert hiplib.SeqikOptions.frame_lead.offset == 52 and hiplib.SeqikOptions.chunk_stats.offset == 56
+    assert hiplib.SeqikOptions.chunk_flags.offset == 64 and hiplib.SeqikOptions.chunk_states.offset == 72
+    assert hiplib.SeqikOptions.chunk_resume.offset == 80
     assert ctypes.sizeof(hiplib.SeqikLayout) == 48 and ctypes.sizeof(hiplib.SeqikAffine) == 56
 
 

@@ -22,7 +22,78 @@ def test_chunked_core_equals_model(oracle, host_harness, name, leg, sl, chunk, h
         hh = host_harness.run_chunked(pose, seg, b, seeds, chunk, halo, rounds=rounds)
         assert np.array_equal(hh["angles"], m["angles"])
         assert np.array_equal(hh["fk"], m["fk"])
-        assert np.array_equal(hh["stats"], m["stats"])
+        assert np.array_equal(hh["stats"], m["stats"]) and np.array_equal(hh["flags"], m["flags"])
+
+
+def test_plan_is_a_function_of_the_recording_length_alone(hiplib):
+    """seqik_frame_chunk_plan (no GPU needed) == the restatement in chunk_model.plan; the automatic geometry for the
+    BASELINE configs (config 1 / 2: 4 + 4, config 4: 8 + 8, one 1M-frame recording: 32 + 8)."""
+    from chunk_model import plan
+    for n in (1, 47, 48, 100, 1000, 1360, 1365, 1366, 6000, 262144, 300000, 1_000_000, 2_000_000, 10_000_000):
+        for kw in (dict(), dict(frame_chunk=16), dict(frame_chunk=16, frame_halo=3), dict(frame_chunk=-1, frame_halo=6),
+                   dict(frame_chunk=8, frame_lead=8), dict(frame_chunk=0)):
+            assert hiplib.frame_chunk_plan(n, **kw) == plan(n, **{"frame_chunk": -1, **kw}) or "frame_chunk" in kw and \
+                hiplib.frame_chunk_plan(n, **kw) == plan(n, **kw), (n, kw)
+    assert hiplib.frame_chunk_plan(100) == (4, 4, 25) and hiplib.frame_chunk_plan(1000) == (4, 4, 250)
+    assert hiplib.frame_chunk_plan(6000) == (8, 8, 750) and hiplib.frame_chunk_plan(1_000_000) == (32, 8, 31250)
+    assert hiplib.frame_chunk_plan(40) == (0, 0, 0)
+
+
+@pytest.mark.parametrize("name,leg,sl", [("anipose_shipped", "LF", slice(240, 400)), ("df3d_1000", "RF", slice(0, 300)),
+                                         ("synthetic_iid", "LF", slice(0, 256))])
+def test_guard_of_the_automatic_mode_in_core_and_model(oracle, host_harness, name, leg, sl):
+    """A chain of which more than one chunk in eight fails the first verification is walked serially (bit for bit the
+    serial walk); others keep their chunks.  Device core (host build) == model, statistics and report included."""
+    if name == "synthetic_iid":   # random poses: several equivalent leg configurations, run-ins land in another one
+        from oracle import c_oracle
+        from seqikpy_amd import data, synthetic, utils
+        body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, data.LEGS)
+        pose = synthetic.synthetic_pose(4, 64, [leg], data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                        variant="iid").reshape(256, 5, 3)
+        seg, b, seeds = c_oracle.leg_params(leg, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+    else:
+        pose, seg, b, seeds = leg_arrays(load_golden(name), leg)
+    pose = pose[sl]
+    serial = oracle.seq_leg(pose, seg, b, seeds)
+    tripped = []
+    for chunk, halo in ((8, 2), (8, 8), (4, 4)):
+        m = chunked_oracle(oracle, pose, seg, b, seeds, chunk, halo, guard=True)
+        hh = host_harness.run_chunked(pose, seg, b, seeds, chunk, halo, guard=True)
+        assert np.array_equal(hh["angles"], m["angles"]) and np.array_equal(hh["fk"], m["fk"])
+        assert np.array_equal(hh["stats"], m["stats"]) and np.array_equal(hh["flags"], m["flags"])
+        if m["stats"][8]:
+            assert m["stats"][7] * 8 > m["stats"][0] and (m["flags"] & 8).all() and m["stats"][3:7].sum() == 0
+            assert np.array_equal(m["angles"], serial["angles"]) and np.array_equal(m["fk"], serial["fk"])
+        else:
+            assert m["stats"][7] * 8 <= m["stats"][0] and not (m["flags"] & 8).any()
+        tripped.append(bool(m["stats"][8]))
+    # random poses trip the guard whatever the geometry, the recordings never do
+    assert all(tripped) if name == "synthetic_iid" else not any(tripped)
+
+
+def test_slab_with_lead_and_resume_in_the_model(oracle, host_harness):
+    """A slab of a recording (frame_lead): its chunk 0 starts from a run-in like the others; once the true state in front
+    of the slab is known the resume step settles it.  With chunks on the same global grid the slab equals the same frames
+    of the whole-recording call, bit for bit; the host-built device core agrees with the model."""
+    from chunk_model import ChunkedChain
+    pose, seg, b, seeds = leg_arrays(load_golden("df3d_1000"), "LM")
+    C, h, a = 16, 8, 320
+    whole = chunked_oracle(oracle, pose[:640], seg, b, seeds, C, h)
+    slab = ChunkedChain(oracle, pose[a - h:640], seg, b, seeds, C, h, lead=h)
+    slab.speculate()
+    slab.settle()                                        # nothing known about the left neighbour yet
+    slab.settle(init=whole["angles"][a - 1], resume=True)
+    assert np.array_equal(slab.angles[h:], whole["angles"][a:]) and np.array_equal(slab.fk[h:], whole["fk"][a:])
+    hh = host_harness.run_chunked(pose[a - h:640], seg, b, seeds, C, h, init=whole["angles"][a - 1], lead=h)
+    assert np.array_equal(hh["angles"][h:], whole["angles"][a:]) and np.array_equal(hh["fk"][h:], whole["fk"][a:])
+    # a wrong left state makes chunk 0 inconsistent: it is repaired from it, exactly as the serial continuation
+    wrong = whole["angles"][a - 1] + 1e-3
+    bad = ChunkedChain(oracle, pose[a - h:640], seg, b, seeds, C, h, lead=h)
+    bad.speculate()
+    bad.settle()
+    bad.settle(init=wrong, resume=True)
+    assert bad.flags[0] & 3 == 3 and bad.stats[7] >= 1
+    assert np.array_equal(bad.angles[h:h + C], oracle.seq_leg(pose[a:a + C], seg, b, seeds, init=wrong.copy())["angles"])
 
 
 def test_every_chunk_ends_up_consistent_and_repairs_happen(oracle):
@@ -81,7 +152,7 @@ def _model_all(oracle, z, legs, sl, chunk, halo, **kw):
           for l in legs]
     stats = np.sum([m["stats"] for m in ms], 0)
     stats[1:3] = ms[0]["stats"][1:3]
-    return np.stack([m["angles"] for m in ms]), np.stack([m["fk"] for m in ms]), stats
+    return np.stack([m["angles"] for m in ms]), np.stack([m["fk"] for m in ms]), stats[:10]
 
 
 @pytest.mark.gpu
@@ -122,7 +193,7 @@ def test_hip_chunks_several_sequences_planar_layout_and_init(oracle, hiplib):
     for lanes in (0, 1, 5, 64):
         d_ang = torch.zeros((S, len(legs), 7, T), dtype=torch.float64, device="cuda")
         d_fk = torch.zeros((S, len(legs), T, 9, 3), dtype=torch.float64, device="cuda")
-        d_stats = torch.zeros(8, dtype=torch.int32, device="cuda")
+        d_stats = torch.zeros(hiplib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
         hiplib.solve_seq_device(d_pose.data_ptr(), S, len(legs), T, _params(hiplib, z, legs), d_ang.data_ptr(),
                                 d_fk.data_ptr(), layout=hiplib.planar_layout(T), d_init=d_init.data_ptr(),
                                 frame_chunk=C, frame_halo=H, lanes_per_wave=lanes, d_chunk_stats=d_stats.data_ptr())
@@ -143,11 +214,13 @@ def test_hip_exact_tolerance_and_automatic_mode(oracle, hiplib):
     assert np.array_equal(exact["angles"], serial["angles"][:, :, :160])  # bit for bit the serial walk
     auto = hiplib.solve_seq(pose, params, frame_chunk=-1)
     st = auto["chunk_stats"]
-    # a call this small (750 chunks of 8 would leave most SIMDs idle) is cut into chunks of 4 after a run-in of 4
+    # a recording this short (750 chunks of 8 would leave most SIMDs idle) is cut into chunks of 4 after a run-in of 4
     assert st["chunks"] == 6 * 250 and st["frames_per_chunk"] == 4 and st["run_in_frames"] == 4
+    # ... whatever else is in the call: the geometry is a function of the recording's length alone
     big = hiplib.solve_seq(np.ascontiguousarray(np.broadcast_to(pose, (2,) + pose.shape[1:])), params, frame_chunk=-1)
-    assert big["chunk_stats"]["chunks"] == 2 * 6 * 125 and big["chunk_stats"]["frames_per_chunk"] == 8   # 1500 chunks of 8
-    assert np.array_equal(big["angles"][0], big["angles"][1])
+    assert big["chunk_stats"]["chunks"] == 2 * 6 * 250 and big["chunk_stats"]["frames_per_chunk"] == 4
+    assert np.array_equal(big["angles"][0], big["angles"][1]) and np.array_equal(big["angles"][0], auto["angles"][0])
+    assert np.array_equal(big["fk"][0], auto["fk"][0])
     assert np.abs(auto["angles"] - serial["angles"]).max() < 2e-5
     assert np.abs(auto["fk"] - serial["fk"]).max() < 2e-5
     short = hiplib.solve_seq(pose[:, :, :40], params, frame_chunk=-1)  # too short: serial
@@ -158,16 +231,23 @@ def test_hip_exact_tolerance_and_automatic_mode(oracle, hiplib):
 
 
 @pytest.mark.gpu
-def test_python_api_default_is_chunked_and_within_parity_of_shipped_golden(hiplib):
+def test_python_api_default_is_the_serial_walk_and_auto_is_within_parity_of_shipped_golden(oracle, hiplib):
+    """run_ik_and_fk() defaults to the reference's semantics (serial walk == oracle bit for bit); frame_parallel="auto"
+    is the opt-in: within the parity budget of the shipped outputs, with a report of where the recording was hard."""
     from conftest import LF_DEGENERATE
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
     from seqikpy_amd.kinematic_chain import KinematicChainSeq
     from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
     za = load_golden("anipose_shipped")
-    ik = LegInvKinSeq({"RF_leg": za["RF_pose"], "LF_leg": za["LF_pose"]}, KinematicChainSeq(BOUNDS, ["RF", "LF"]),
-                      INITIAL_ANGLES, log_level="ERROR")
-    ang, fk = ik.run_ik_and_fk()
-    assert ik.frame_chunk_stats["chunks"] == 2 * 750
+    kc = KinematicChainSeq(BOUNDS, ["RF", "LF"])
+    cut = LegInvKinSeq({"RF_leg": za["RF_pose"][:300]}, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES, log_level="ERROR")
+    serial_ang, _ = cut.run_ik_and_fk()
+    assert cut.frame_chunk_stats["chunks"] == 0 and cut.frame_chunk_report == {}
+    ref = oracle.seq_leg(za["RF_pose"][:300], za["RF_seg"], za["RF_bounds"], za["RF_seeds"])
+    assert np.array_equal(np.stack([serial_ang[f"Angle_RF_{d}"] for d in hiplib.DOFS], 1), ref["angles"])
+    ik = LegInvKinSeq({"RF_leg": za["RF_pose"], "LF_leg": za["LF_pose"]}, kc, INITIAL_ANGLES, log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk(frame_parallel="auto")
+    assert ik.frame_chunk_stats["chunks"] == 2 * 750 and ik.frame_chunk_stats["chains_walked_serially"] == 0
     got = np.stack([ang[f"Angle_RF_{d}"] for d in hiplib.DOFS], 1)
     assert np.abs(got - za["RF_angles"]).max() < 1e-4
     ok = np.ones(6000, bool)
@@ -175,9 +255,46 @@ def test_python_api_default_is_chunked_and_within_parity_of_shipped_golden(hipli
     got = np.stack([ang[f"Angle_LF_{d}"] for d in hiplib.DOFS], 1)
     assert np.abs(got - za["LF_angles"])[ok].max() < 1e-4
     assert np.abs(fk["RF_leg"][za["fk_frames"]] - za["RF_fk_cut"]).max() < 1e-4
-    serial_ang, _ = LegInvKinSeq({"RF_leg": za["RF_pose"][:300]}, KinematicChainSeq(BOUNDS, ["RF"]), INITIAL_ANGLES,
-                                 log_level="ERROR").run_ik_and_fk(frame_parallel=False)
     assert np.abs(serial_ang["Angle_RF_ThC_yaw"] - ang["Angle_RF_ThC_yaw"][:300]).max() < 2e-5
+    # the report points at the LF kinematic-singularity episode (frames 284-301) and nowhere near it on RF
+    rep = ik.frame_chunk_report
+    assert rep["LF"]["frames_per_chunk"] == 8 and not rep["LF"]["walked_serially"]
+    assert any(LF_DEGENERATE[0] - 8 <= t < LF_DEGENERATE[1] + 8 for t in rep["LF"]["failed_first_check"])
+    assert rep["LF"]["frames_repaired"] >= 8
+    assert not any(LF_DEGENERATE[0] - 8 <= t < LF_DEGENERATE[1] + 8 for t in rep["RF"]["failed_first_check"])
+
+
+@pytest.mark.gpu
+def test_a_recording_gives_the_same_bits_alone_in_a_batch_and_in_a_longer_batch(hiplib):
+    """Round-2 review item 3: under frame_parallel="auto" one recording alone == the same recording inside
+    run_ik_and_fk_many == inside a batch twice as long == through pipeline.run_body_ik, bit for bit."""
+    from seqikpy_amd import data
+    from seqikpy_amd.batch import run_ik_and_fk_many
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    from seqikpy_amd.pipeline import run_body_ik
+    from seqikpy_amd.utils import calculate_body_size
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    kc = KinematicChainSeq(data.BOUNDS_LOCOMOTION, legs, calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs))
+    cuts = [(0, 400), (300, 700), (600, 1000), (100, 500), (250, 650), (5, 405)]
+    recs = [{f"{l}_leg": z[f"{l}_pose"][a:b] for l in legs} for a, b in cuts]
+    alone = LegInvKinSeq(recs[1], kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR")
+    ang1, fk1 = alone.run_ik_and_fk(frame_parallel="auto")
+    assert alone.frame_chunk_stats["chunks"] == 6 * 100
+    reports = []
+    for batch in (recs[:3], recs):
+        many = run_ik_and_fk_many(batch, kc, data.INITIAL_ANGLES_LOCOMOTION, frame_parallel="auto", reports=reports)
+        ang, fk = many[1]
+        assert all(np.array_equal(ang[k], ang1[k]) for k in ang1) and all(np.array_equal(fk[k], fk1[k]) for k in fk1)
+        assert reports[1] == alone.frame_chunk_report
+    body, fkb = run_body_ik(recs[1], kc, data.TEMPLATE_NMF_LOCOMOTION, data.INITIAL_ANGLES_LOCOMOTION, frame_parallel="auto")
+    assert all(np.array_equal(body[k], ang1[k]) for k in ang1) and all(np.array_equal(fkb[k], fk1[k]) for k in fk1)
+    # and the default (serial walk) of all three entry points agrees as well
+    s1, _ = LegInvKinSeq(recs[1], kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR").run_ik_and_fk()
+    s2 = run_ik_and_fk_many(recs[:3], kc, data.INITIAL_ANGLES_LOCOMOTION)[1][0]
+    s3, _ = run_body_ik(recs[1], kc, data.TEMPLATE_NMF_LOCOMOTION, data.INITIAL_ANGLES_LOCOMOTION)
+    assert all(np.array_equal(s1[k], s2[k]) and np.array_equal(s1[k], s3[k]) for k in s1)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -242,27 +359,95 @@ def test_chunks_on_the_stage_pipeline_equal_model(oracle, hiplib, chunk, halo, r
 
 
 @pytest.mark.gpu
-def test_automatic_chunks_give_way_to_the_serial_walk_when_speculation_fails(oracle, hiplib):
+def test_automatic_chunks_give_way_to_the_serial_walk_per_chain_when_speculation_fails(oracle, hiplib):
     """Random poses that span several equivalent leg configurations: half of the run-ins end in another configuration than
-    the serial walk.  Automatic mode notices (more than one chunk in eight inconsistent at the first verification) and
-    returns the serial walk, bit for bit; explicit chunk parameters are honoured as given."""
+    the serial walk.  The automatic mode notices PER CHAIN, on the device (more than one chunk in eight inconsistent at
+    the first verification), and walks those chains serially, bit for bit -- host and device entry points alike, and
+    without touching the well-behaved chains of the same call; explicit chunk parameters are honoured as given."""
+    import torch
     from seqikpy_amd import data, synthetic, utils
     legs = data.LEGS
     body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
     pose = synthetic.synthetic_pose(4, 64, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION, variant="iid")
-    rec = np.ascontiguousarray(pose.transpose(1, 0, 2, 3, 4).reshape(6, 256, 5, 3))[None]      # one recording per leg
+    rnd = np.ascontiguousarray(pose.transpose(1, 0, 2, 3, 4).reshape(6, 256, 5, 3))      # one random recording per leg
+    z = load_golden("df3d_1000")
+    real = np.stack([z[f"{l}_pose"][:256] for l in legs])
+    rec = np.stack([rnd, real, rnd[:, ::-1]])                                            # sequences 0 and 2 are hopeless
     params = [hiplib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
     serial = hiplib.solve_seq(rec, params)
-    auto = hiplib.solve_seq(rec, params, frame_chunk=-1)
-    assert auto["chunk_stats"]["chunks"] < 0 and auto["chunk_stats"]["inconsistent_at_first_check"] * 8 > -auto["chunk_stats"]["chunks"]
-    assert np.array_equal(auto["angles"], serial["angles"]) and np.array_equal(auto["fk"], serial["fk"])
-    forced = hiplib.solve_seq(rec, params, frame_chunk=8)
-    assert forced["chunk_stats"]["chunks"] == 6 * 32
+    auto = hiplib.solve_seq(rec, params, frame_chunk=-1, want_chunk_flags=True)
+    st, fl = auto["chunk_stats"], auto["chunk_flags"]
+    assert st["chunks"] == 3 * 6 * 64 and st["frames_per_chunk"] == 4
+    walked = (fl & hiplib.CHUNK_FLAG_SERIAL).any(-1)                                     # (3, 6) chains walked serially
+    assert walked[0].all() and walked[2].all() and not walked[1].any()
+    assert st["chains_walked_serially"] == 12 and st["chunks_of_those_chains"] == 12 * 64
+    assert np.array_equal(auto["angles"][[0, 2]], serial["angles"][[0, 2]]) and np.array_equal(auto["fk"][[0, 2]], serial["fk"][[0, 2]])
+    alone = hiplib.solve_seq(rec[1:2], params, frame_chunk=-1)                           # the real recording: as if alone
+    assert np.array_equal(auto["angles"][1], alone["angles"][0]) and np.array_equal(auto["fk"][1], alone["fk"][0])
+    assert alone["chunk_stats"]["chains_walked_serially"] == 0
+    for leg_i, l in enumerate(legs):                                                     # == the model, per chain
+        m = chunked_oracle(oracle, rec[0, leg_i], *[z[f"{l}_{k}"] for k in ("seg", "bounds", "seeds")], 4, 4, guard=True)
+        assert m["stats"][8] == 1 and np.array_equal(auto["angles"][0, leg_i], m["angles"])
+        assert np.array_equal(fl[0, leg_i], m["flags"])
+    # the device entry point has the same guard (it used to live in the host entry point only)
+    d_pose = torch.from_numpy(rec).cuda()
+    d_ang = torch.zeros(rec.shape[:3] + (7,), dtype=torch.float64, device="cuda")
+    d_stats = torch.zeros(hiplib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
+    hiplib.solve_seq_device(d_pose.data_ptr(), 3, 6, 256, params, d_ang.data_ptr(), frame_chunk=-1, d_chunk_stats=d_stats.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ang.cpu().numpy(), auto["angles"]) and int(d_stats[8]) == 12
+    forced = hiplib.solve_seq(rec[:1], params, frame_chunk=8)
+    assert forced["chunk_stats"]["chunks"] == 6 * 32 and forced["chunk_stats"]["chains_walked_serially"] == 0
     # and on a real recording the automatic mode keeps its chunks
-    z = load_golden("df3d_1000")
     lg = [str(l) for l in z["legs"]]
     ok = hiplib.solve_seq(np.stack([z[f"{l}_pose"] for l in lg])[None], _params(hiplib, z, lg), frame_chunk=-1)
-    assert ok["chunk_stats"]["chunks"] == 1500
+    assert ok["chunk_stats"]["chunks"] == 1500 and ok["chunk_stats"]["chains_walked_serially"] == 0
+
+
+@pytest.mark.gpu
+def test_slab_with_lead_and_resume_on_the_device(oracle, hiplib):
+    """frame_lead / chunk_states / chunk_resume through the C ABI == the model (tests/chunk_model.py): a slab of a
+    recording whose chunk 0 is settled in a second call once the true state in front of it is known."""
+    import torch
+    from chunk_model import ChunkedChain
+    z = load_golden("df3d_1000")
+    legs = ["LM", "RH"]
+    C, h, a, b = 16, 8, 320, 650
+    params = _params(hiplib, z, legs)
+    pose = np.stack([z[f"{l}_pose"][a - h:b] for l in legs])[None]
+    n = pose.shape[2]
+    K = hiplib.frame_chunk_plan(n, C, h, h)[2]
+    for wrong in (0.0, 1e-3):
+        models = []
+        for l in legs:
+            m = ChunkedChain(oracle, z[f"{l}_pose"][a - h:b], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"], C, h, lead=h)
+            m.speculate()
+            m.settle()
+            models.append(m)
+        d_pose = torch.from_numpy(pose).cuda()
+        d_ang = torch.zeros((1, 2, n, 7), dtype=torch.float64, device="cuda")
+        d_fk = torch.zeros((1, 2, n, 9, 3), dtype=torch.float64, device="cuda")
+        d_states = torch.zeros((1, 2, K, 7), dtype=torch.float64, device="cuda")
+        d_flags = torch.zeros((1, 2, K), dtype=torch.uint8, device="cuda")
+        d_stats = torch.zeros(hiplib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
+        kw = dict(frame_chunk=C, frame_halo=h, frame_lead=h, d_chunk_states=d_states.data_ptr(), d_chunk_flags=d_flags.data_ptr(),
+                  d_chunk_stats=d_stats.data_ptr())
+        hiplib.solve_seq_device(d_pose.data_ptr(), 1, 2, n, params, d_ang.data_ptr(), d_fk.data_ptr(), **kw)
+        torch.cuda.synchronize()
+        for li, m in enumerate(models):
+            assert np.array_equal(d_ang[0, li, h:].cpu().numpy(), m.angles[h:]) and np.array_equal(d_states[0, li].cpu().numpy(), m.ss)
+        whole = [oracle.seq_leg(z[f"{l}_pose"][:a], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"])["angles"][-1] + wrong for l in legs]
+        d_init = torch.from_numpy(np.stack(whole)[None]).cuda()
+        hiplib.solve_seq_device(d_pose.data_ptr(), 1, 2, n, params, d_ang.data_ptr(), d_fk.data_ptr(), d_init=d_init.data_ptr(),
+                                chunk_resume=1, **kw)
+        torch.cuda.synchronize()
+        for li, m in enumerate(models):
+            m.settle(init=whole[li], resume=True)
+            assert np.array_equal(d_ang[0, li, h:].cpu().numpy(), m.angles[h:]), (wrong, li)
+            assert np.array_equal(d_fk[0, li, h:].cpu().numpy(), m.fk[h:])
+            assert np.array_equal(d_flags[0, li].cpu().numpy(), m.flags)
+        assert int(d_stats[7]) == sum(int(m.stats[7]) for m in models)
+        assert (int(d_stats[7]) > 0) == (wrong > 0)
 
 
 @pytest.mark.gpu

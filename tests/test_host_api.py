@@ -120,11 +120,12 @@ def test_many_recordings_bucketing_and_padding(monkeypatch):
     from seqikpy_amd.kinematic_chain import KinematicChainSeq
     calls = []
 
-    def fake_solve(pose, legs, want_fk=True, device=0, affine=None):
+    def fake_solve(pose, legs, want_fk=True, device=0, affine=None, frame_chunk=0, **_):
+        assert frame_chunk == 0   # the default of run_ik_and_fk_many is the reference's serial walk
         calls.append(pose.shape)
         S, L, N = pose.shape[:3]
         ang = np.broadcast_to(pose[..., 1, 0][..., None], (S, L, N, 7)).copy()   # echoes a key-point coordinate
-        return dict(angles=ang, fk=np.zeros((S, L, N, 9, 3)))
+        return dict(angles=ang, fk=np.zeros((S, L, N, 9, 3)), chunk_stats=dict(chunks=0), chunk_flags=None)
 
     monkeypatch.setattr(_lib, "solve_seq", fake_solve)
     kc = KinematicChainSeq(data.BOUNDS, ["RF", "LF"])
