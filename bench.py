@@ -148,6 +148,9 @@ def parse():
                          "which every wave takes its chains through the four stages in turn")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
+    ap.add_argument("--one-recording", action="store_true",
+                    help="config 3 literally: ONE recording of --frames frames x 6 legs (real locomotion poses repeated), "
+                         "frame-sharded over the ranks on the library's frame chunks, end states exchanged, angles all-gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-python-baseline", action="store_true",
                     help="skip the Python + scipy process-pool leg of the CPU baseline (about 20 s)")
@@ -331,6 +334,65 @@ def single_recording(n_frames=1_000_000, steps=4):
     return out
 
 
+def one_recording_leg(dist, world, rank, n_frames, steps, warmup, coll_dev="cpu"):
+    """Config 3 read literally: ONE recording of n_frames x 6 legs (the df3d locomotion recording of the fixtures repeated
+    end to end), contiguous frame slabs over the ranks (seqikpy_amd.frame_sharding: every rank's slab goes through the
+    library's frame chunks with a run-in, the ranks all-gather their 56-byte end states, settle their first chunk in a
+    resume call, and all-gather the joint angles; FK stays sharded).  A step = one such solve with the key points
+    resident in HBM.  At N = 1 this is `single_recording`."""
+    from seqikpy_amd import frame_sharding
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    L = len(legs)
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    base = np.stack([z[f"{l}_pose"] for l in legs])                                          # (L, 1000, 5, 3)
+    pose = np.tile(base, (1, -(-n_frames // base.shape[1]), 1, 1))[None, :, :n_frames]       # (1, L, N, 5, 3)
+    rec = frame_sharding.FrameShardedRecording(pose, params, want_fk=True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(max(1, warmup)):
+        out = rec.solve(gather_fk=False)
+    sync()
+    rec.spec_events = []          # solve() records a pair of HIP events around the speculative pass of every step
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = rec.solve(gather_fk=False)
+    sync()
+    mine = time.perf_counter() - t0
+    tmax = mine
+    if dist:
+        t = torch.tensor([mine], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    # check on rank 0: the first 2000 frames against the serial walk of those frames (chunk 0 bit for bit, the rest to the
+    # verification tolerance's noise floor) and against the fixture's reference angles
+    chk = None
+    if rank == 0:
+        n_head = min(n_frames, 2000)
+        ser = _lib.solve_seq(np.ascontiguousarray(pose[:, :, :n_head]), params, want_fk=False)["angles"]
+        got = out["angles"][:, :, :n_head].cpu().numpy()
+        ref = np.stack([z[f"{l}_angles"] for l in legs])[None]
+        n_ref = min(n_frames, 1000)
+        chk = {"frames_walked_serially": n_head, "max_abs_vs_serial": float(np.abs(got - ser).max()),
+               "first_chunk_equals_serial_bit_for_bit": bool(np.array_equal(got[:, :, :rec.C], ser[:, :, :rec.C])),
+               "max_abs_vs_reference_first_1000_frames": float(np.abs(got[:, :, :n_ref] - ref[:, :, :n_ref]).max())}
+    spec_ms = [a.elapsed_time(b) for a, b in rec.spec_events] if rec.spec_events else []
+    return {"value": L * n_frames * steps / tmax, "unit": "leg-frame solves/s", "ms_per_step": tmax / steps * 1e3, "steps": steps,
+            "speculative_pass_ms_this_rank": float(np.mean(spec_ms)) if spec_ms else None,
+            "frames": n_frames, "legs": L, "frames_per_rank": [b - a for a, b in rec.slabs],
+            "frames_per_chunk": rec.C, "run_in_frames": rec.h, "boundary_rounds": rec.stats.get("boundary_rounds"),
+            "resume_calls_per_step_this_rank": rec.stats.get("resume_calls"),
+            "data": "df3d locomotion recording (fixture, 1000 frames x 6 legs) repeated end to end",
+            "exchange": "all-gather of 56 B end states per leg and rank + one padded all-gather of the joint angles; FK stays sharded",
+            "check": chk}
+
+
 def parity_report():
     """HIP vs the committed reference fixtures, on the GPU, fixtures only (no oracle involved): the shipped anipose
     outputs (reference's leg_joint_angles.pkl, RF + LF x 6000 frames) and the df3d recording solved by the
@@ -400,6 +462,37 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
+
+    if args.one_recording:
+        # config 3 read literally is the whole job of this run: one recording, frame-sharded over the ranks
+        leg = one_recording_leg(dist, world, rank, args.frames, args.steps, args.warmup, coll_dev)
+        if rank == 0:
+            units_rank0 = 6 * leg["frames_per_rank"][0]
+            spec = leg["speculative_pass_ms_this_rank"]
+            ach = BYTES_PATH * units_rank0 / (spec * 1e-3) / 1e9 if spec else None
+            out = {"metric": "leg-IK solves/s (frames x 6 legs); max |d theta| vs reference in `check`",
+                   "value": leg["value"], "unit": "leg-frame solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "f64", "data": "synthetic",
+                   "config": {"workload": "config 3 literally: ONE recording of %d frames x 6 legs, contiguous frame slabs over "
+                                          "the ranks (library frame chunks, end-state exchange, angle all-gather)" % args.frames,
+                              "parallelism": f"frame-sharded x{world}" if world > 1 else "1 GPU",
+                              "backend": backend, **{k: leg[k] for k in ("frames_per_rank", "frames_per_chunk", "run_in_frames",
+                                                                          "boundary_rounds", "data", "exchange")}},
+                   "roofline": {"bound": "hbm", "kernel": "seqik_chunk_kernel<true, SPEC> (speculative pass of rank 0's slab)",
+                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if ach else None,
+                                "traffic": None, "avg_launch_ms": spec, "bytes_per_unit": BYTES_PATH,
+                                "note": "algorithmic bytes of rank 0's slab / duration of its speculative pass (HIP events on the "
+                                        "launch stream); the path is FP64-issue-bound, see the default run's roofline"},
+                   "check": leg["check"]}
+            sys.stdout.flush()
+            os.dup2(json_fd, 1)
+            print(json.dumps(out), flush=True)
+            os.dup2(2, 1)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     T = args.frames_per_seq
     S_total = args.frames // T
@@ -607,6 +700,9 @@ def main():
             if hasattr(g2, "close"):
                 g2.close()
             del g2, b2, bufs2, pose2
+            # config 3 read literally: ONE recording frame-sharded over the ranks (short leg; `--one-recording` runs it alone)
+            torch.cuda.empty_cache()
+            multi["one_recording"] = one_recording_leg(dist, world, rank, args.frames, max(3, min(10, args.steps)), 1, coll_dev)
 
     if rank == 0:
         out = {

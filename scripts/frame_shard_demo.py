@@ -48,7 +48,7 @@ def main():
         keep = np.ones(6000, bool)
         keep[280:310] = False                                               # the LF singular episode amplifies 1e-6
         print(json.dumps({"world": world, "backend": args.backend, "seconds": dt, "slab_rank0": st["slab"],
-                          "boundary_rounds": st["boundary_rounds"],
+                          "boundary_rounds": st["boundary_rounds"], "resume_calls": st["resume_calls"],
                           "max_abs_vs_serial_RF": float(err[0].max()), "max_abs_vs_serial_LF_outside_episode": float(err[1][keep].max()),
                           "fk_max_abs_vs_serial_RF": float(np.abs(out["fk"][0, 0] - serial["fk"][0, 0]).max())}))
     dist.barrier()

@@ -7,12 +7,13 @@ Same module / class names as the reference for this path:
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
 
 plus, beyond the reference: ``batch.run_ik_and_fk_many`` (many recordings in one launch),
-``streaming.SeqikStream`` (slabs from pinned host memory), ``frame_parallel`` (one long recording).
+``streaming.SeqikStream`` (slabs from pinned host memory), ``run_ik_and_fk(frame_parallel="auto")`` (one long recording
+in verified frame chunks), ``frame_sharding`` (one recording over the GPUs of a node).
 
 All arithmetic runs in ``csrc/libseqik_hip.so`` (hand-written HIP for gfx950) behind the C ABI
 of ``include/seqik.h``; there is no CPU fallback.
 """
-__version__ = "0.1.0"
+__version__ = "0.3.0"
 
 import os as _os
 

@@ -2,30 +2,38 @@
 "1M frames x 6 legs, frame-sharded").
 
 The reference walks a recording serially: frame t is warm-started from frame t-1
-(``seqikpy/leg_inverse_kinematics.py:272``), so contiguous frame slabs on different ranks are coupled through
-one 7-angle state per leg at every slab boundary.  The scheme is the library's frame chunks
-(``SeqikOptions.frame_chunk``, include/seqik.h) one level up:
+(``seqikpy/leg_inverse_kinematics.py:259-282``, warm start ``:272``), so contiguous frame slabs on different ranks are
+coupled through one 7-angle state per leg at every slab boundary.  The scheme is the library's frame chunks
+(``SeqikOptions.frame_chunk``, include/seqik.h) with the slab boundaries on the SAME global chunk grid, so the ranks
+together do what one GPU does for the whole recording:
 
-1. every rank solves its slab ``[a_r, b_r)`` in ONE library call with frame chunks (speculation, verification and
-   repair of the chunks inside the slab happen on its GPU); ranks > 0 start ``halo`` frames early from the seeds
-   (speculation: on well-posed data the solver forgets its start point within a few frames);
-2. the ranks exchange their end states (one tiny all-gather: ``world x S x L x 7`` doubles) and each rank compares
-   the state its run-in reached with the true end state of its left neighbour;
-3. a rank whose boundary disagrees by more than ``tol`` re-solves its slab from the true state (``init_angles``,
-   bit-identical to the serial continuation); its own end state may change, so step 2 repeats until no rank
-   changed -- at most ``world - 1`` rounds, zero or one on real data;
-4. one padded all-gather returns the joint angles (and the FK) of all frames to every rank -- over RCCL/xGMI the
-   "final joint-angle gather" of the north star.
+1. every rank hands its slab ``[a_r, b_r)`` (whole chunks) plus the ``lead = min(halo, a_r)`` frames in front of it to
+   ``seqik_solve_seq_device`` with ``frame_lead = lead``: all chunks of the slab -- the first one too -- start from a
+   run-in and are verified / repaired against their predecessor inside the slab on the rank's GPU; the start states
+   stay in a caller-owned buffer (``chunk_states``);
+2. the ranks all-gather their END states (the 7 angles of frame ``b_r - 1``: 56 bytes per leg and rank);
+3. every rank > 0 makes a ``chunk_resume`` call with the true end state of its left neighbour as ``init_angles``:
+   only verification runs, and a repair of the boundary chunk (and whatever it cascades into) if the run-in had not
+   reproduced that state to ``tol``.  If that changed the rank's own end state, steps 2-3 repeat (at most
+   ``world - 1`` times; never on well-posed data);
+4. one padded all-gather returns the joint angles of all frames to every rank -- over RCCL / xGMI the "final
+   joint-angle gather" of the north star.  The forward kinematics can be gathered the same way or stay sharded.
 
-No data-path collective runs while the kernels do: the exchange of step 2 is 56 bytes per leg and rank.
-The result equals the serial solve to about ``tol`` (exactly, where a boundary had to be repaired).
+No collective runs while the kernels do.  Chunk k of the recording is solved from the same run-in, verified against
+the same predecessor and repaired from the same state as in a one-GPU call with the same (chunk, halo, tol): the
+result is that call's, bit for bit, as long as no repair cascade crosses a rank boundary in a different round order
+(tests: world 2 / 3 on gloo against the one-rank result; on the recordings no boundary needs a repair at all).
+The automatic mode's per-chain guard (chains with many inconsistent chunks walked serially) belongs to one-GPU calls;
+here the chunk geometry is fixed up front (``_lib.frame_chunk_plan`` of the whole recording) and explicit.
+
+torch is used for device memory and the process group only.
 """
-from typing import Dict, List, Optional
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 
 from . import _lib
-from .sharding import all_gather_rows, partition
+from .sharding import partition
 
 
 def frame_slab(n_frames: int, world: int, rank: int, chunk: int):
@@ -35,74 +43,192 @@ def frame_slab(n_frames: int, world: int, rank: int, chunk: int):
     return min(k0 * chunk, n_frames), min(k1 * chunk, n_frames)
 
 
-def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: int = 32, halo: int = 16, tol: float = 1e-6,
-                        want_fk: bool = True, affine=None, device: int = -1, group=None,
-                        stats: Optional[Dict] = None):
-    """``pose`` (S, L, N, 5, 3) -- the same array on every rank, of which a rank only touches its slab and the
-    ``halo`` frames in front of it -- -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) on every rank.
-    Needs an initialised ``torch.distributed`` process group ("nccl" = RCCL on the GPUs, "gloo" in tests)."""
-    import torch
-    import torch.distributed as dist
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    S, L, N = pose.shape[:3]
-    a, b = frame_slab(N, world, rank, chunk)
-    lead = min(halo, a) if rank > 0 else 0
-    dev = torch.device("cuda", device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+def chunk_geometry(n_frames: int, chunk: Optional[int] = None, halo: Optional[int] = None):
+    """(frames per chunk, run-in frames) of a recording: the given ones, or the library's automatic choice for a
+    recording of this length (``seqik_frame_chunk_plan``); a recording too short for chunks is one chunk."""
+    if chunk is None or chunk <= 0:
+        c, h, _ = _lib.frame_chunk_plan(n_frames, -1, halo or 0)
+        if c == 0:
+            return max(int(n_frames), 1), max(int(halo or 1), 1)
+        return c, h
+    return int(chunk), max(int(halo if halo else 8), 1)
 
-    # chunks inside the slab: the library's frame chunks; tol = 0 asks for exactness there too
-    chunk_kw = dict(frame_chunk=int(chunk), frame_halo=max(int(halo), 1), chunk_tol=float(tol) if tol > 0 else -1.0)
 
-    def local_solve(init):
-        """The slab from the seeds with a run-in of ``lead`` frames (init None), or from the true state of the left
-        neighbour.  Returns the slab's results and the state the run-in reached just before frame a."""
-        st = {}
-        if b <= a:
-            return dict(angles=np.zeros((S, L, 0, 7)), fk=np.zeros((S, L, 0, 9, 3)) if want_fk else None), st
-        first = a - lead if init is None else a
-        res = _lib.solve_seq(np.ascontiguousarray(pose[:, :, first:b]), legs, want_fk=want_fk, affine=affine, device=device,
-                             init_angles=init, **chunk_kw)
-        off = a - first
-        st["start_state0"] = res["angles"][:, :, off - 1].copy() if off > 0 else None
-        st["chunk_stats"] = res.get("chunk_stats")
-        return dict(angles=res["angles"][:, :, off:], fk=res["fk"][:, :, off:] if want_fk else None), st
+class DeviceSlab:
+    """A rank's slab on its GPU: key points, angles, FK and chunk start states stay in HBM between the calls."""
 
-    out, st = local_solve(None)
-    start_state = st.get("start_state0")          # what the run-in reached just before frame a (None on rank 0)
-    rounds, resolved = 0, 0
-    left = None
-    while world > 1:
-        # end state of every rank (an empty slab hands its left neighbour's state through)
-        mine = out["angles"][:, :, -1] if b > a else (left if left is not None else np.zeros((S, L, 7)))
-        ends = [torch.empty((S, L, 7), dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(ends, torch.from_numpy(np.ascontiguousarray(mine)).to(dev), group=group)
-        changed = 0
-        if rank > 0 and b > a:
-            left = ends[rank - 1].cpu().numpy()
-            bad = start_state is None or np.abs(start_state - left).max() > tol
-            if bad:
-                out, _ = local_solve(left)
-                start_state = left                # from now on this slab starts from the true state
-                changed, resolved = 1, resolved + 1
-        elif rank > 0:
-            left = ends[rank - 1].cpu().numpy()
-        flag = torch.tensor([changed], dtype=torch.int64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
-        if int(flag.item()) == 0:
-            break
-        rounds += 1
-        if rounds > world:  # cannot happen: a repaired boundary is exact, repairs only move rightwards
-            raise RuntimeError("frame sharding did not converge")
+    def __init__(self, pose_slab: np.ndarray, legs: List, chunk: int, halo: int, tol: float, lead: int, want_fk: bool,
+                 affine=None, device: int = -1):
+        import torch
+        self.torch = torch
+        self.S, self.L, self.n = pose_slab.shape[:3]
+        self.legs, self.lead, self.want_fk, self.affine = legs, int(lead), want_fk, affine
+        self.kw = dict(frame_chunk=int(chunk), frame_halo=int(halo), chunk_tol=float(tol) if tol > 0 else -1.0)
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device is None or device < 0 else device)
+        self.K = max(_lib.frame_chunk_plan(self.n, int(chunk), int(halo), self.lead)[2], 1)
+        # planar device layout (include/seqik.h, SeqikLayout): every key-point row and every joint is its own time series
+        self.layout = _lib.planar_layout(self.n)
+        with torch.cuda.device(self.dev):
+            self.d_pose = torch.from_numpy(np.ascontiguousarray(pose_slab.transpose(0, 1, 3, 2, 4))).to(self.dev)  # [S][L][5][n][3]
+            self.d_ang = torch.zeros((self.S, self.L, 7, self.n), dtype=torch.float64, device=self.dev)           # [S][L][7][n]
+            self.d_fk = torch.zeros((self.S, self.L, self.n, 9, 3), dtype=torch.float64, device=self.dev) if want_fk else None
+            self.d_states = torch.zeros((self.S, self.L, self.K, 7), dtype=torch.float64, device=self.dev)
+            self.d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device=self.dev)
+        self.chunked = _lib.frame_chunk_plan(self.n, int(chunk), int(halo), self.lead)[2] > 0
+        self.repaired = 0
 
-    counts = [frame_slab(N, world, r, chunk)[1] - frame_slab(N, world, r, chunk)[0] for r in range(world)]
+    def _call(self, d_init=0, resume=0):
+        torch = self.torch
+        with torch.cuda.device(self.dev):
+            kw = dict(self.kw, frame_lead=self.lead, d_chunk_states=self.d_states.data_ptr(), chunk_resume=resume,
+                      d_chunk_stats=self.d_stats.data_ptr()) if self.chunked else {}
+            _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.n, self.legs, self.d_ang.data_ptr(),
+                                  self.d_fk.data_ptr() if self.want_fk else 0, d_init=d_init, affine=self.affine,
+                                  layout=self.layout, stream=torch.cuda.current_stream(self.dev).cuda_stream, **kw)
 
-    def gather(x, tail):  # (S, L, n_r, ...) -> (S, L, N, ...)
-        t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 2, 0))).to(dev)
-        full = all_gather_rows(t, counts, group) if world > 1 else t
-        return np.ascontiguousarray(np.moveaxis(full.cpu().numpy(), 0, 2))
+    def speculate(self):
+        self._call()
 
-    angles = gather(out["angles"], (7,))
-    fk = gather(out["fk"], (9, 3)) if want_fk else None
+    def resume(self, left_state):
+        """``left_state`` (S, L, 7): the true state of the frame in front of the slab (device tensor)."""
+        if not self.chunked:   # (only a slab that IS the whole, short recording is walked serially; it has no left neighbour)
+            raise RuntimeError("a serially walked slab cannot be resumed")
+        self._left = left_state.to(self.dev).contiguous()
+        self._call(d_init=self._left.data_ptr(), resume=1)
+        st = self.d_stats.cpu().numpy()
+        self.repaired += int(st[3:7].sum())
+
+    def end_state(self):
+        return self.d_ang[:, :, :, self.n - 1].contiguous()
+
+    def angles(self):
+        """(S, L, frames of the slab, 7) view of the planar buffer"""
+        return self.d_ang[:, :, :, self.lead:].permute(0, 1, 3, 2)
+
+    def fk(self):
+        return self.d_fk[:, :, self.lead:] if self.want_fk else None
+
+    def chunk_stats(self):
+        return _lib.chunk_stats_dict(self.d_stats.cpu().numpy())
+
+
+class FrameShardedRecording:
+    """One recording (or S recordings advancing together) sharded by frame over the ranks of ``group``.
+
+    ``pose`` (S, L, N, 5, 3) -- the same array on every rank, of which a rank only touches its slab and the run-in frames
+    in front of it.  ``solve()`` runs steps 1-4 of the module docstring on the data resident on the GPUs and may be
+    called repeatedly (benchmark steps).  ``slab_factory``: test hook (an oracle-built slab on the CPU)."""
+
+    def __init__(self, pose: np.ndarray, legs: List, chunk: Optional[int] = None, halo: Optional[int] = None,
+                 tol: float = 1e-6, want_fk: bool = True, affine=None, device: int = -1, group=None,
+                 slab_factory: Optional[Callable] = None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.S, self.L, self.N = pose.shape[:3]
+        self.C, self.h = chunk_geometry(self.N, chunk, halo)
+        self.tol, self.want_fk = tol, want_fk
+        self.slabs = [frame_slab(self.N, self.world, r, self.C) for r in range(self.world)]
+        self.a, self.b = self.slabs[self.rank]
+        self.lead = min(self.h, self.a) if self.rank > 0 else 0
+        # the nearest rank to the left that owns frames (slabs can be empty when there are fewer chunks than ranks)
+        self.left_of = None
+        for r in range(self.rank - 1, -1, -1):
+            if self.slabs[r][1] > self.slabs[r][0]:
+                self.left_of = r
+                break
+        self.slab = None
+        if self.b > self.a:
+            make = slab_factory or DeviceSlab
+            self.slab = make(np.ascontiguousarray(pose[:, :, self.a - self.lead:self.b]), legs, self.C, self.h, tol, self.lead,
+                             want_fk, affine, device)
+        on_gpu = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.coll_dev = (self.slab.dev if (self.slab is not None and hasattr(self.slab, "dev")) else
+                         torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
+        self.stats: Dict = {}
+        #: set to a list to have solve() append a (start, end) pair of HIP events around each speculative pass
+        self.spec_events: Optional[list] = None
+
+    def _gather_ends(self):
+        torch, dist = self.torch, self.dist
+        mine = (self.slab.end_state() if self.slab is not None else
+                torch.zeros((self.S, self.L, 7), dtype=torch.float64)).to(self.coll_dev).contiguous()
+        ends = [torch.empty((self.S, self.L, 7), dtype=torch.float64, device=self.coll_dev) for _ in range(self.world)]
+        dist.all_gather(ends, mine, group=self.group)
+        return ends
+
+    def solve(self, gather_fk: Optional[bool] = None):
+        """-> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) as tensors on every rank (on the GPU under RCCL)."""
+        torch, dist = self.torch, self.dist
+        if self.slab is not None:
+            if self.spec_events is not None and hasattr(self.slab, "dev"):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.slab.speculate()
+                e1.record()
+                self.spec_events.append((e0, e1))
+            else:
+                self.slab.speculate()
+        rounds, resumed = 0, 0
+        if self.world > 1:
+            left_prev = None
+            while True:
+                ends = self._gather_ends()
+                changed = 0
+                if self.slab is not None and self.left_of is not None:
+                    left = ends[self.left_of]
+                    if left_prev is None or not torch.equal(left, left_prev):
+                        before = self.slab.end_state().clone()
+                        self.slab.resume(left)
+                        resumed += 1
+                        left_prev = left.clone()
+                        changed = int(not torch.equal(before, self.slab.end_state()))
+                flag = torch.tensor([changed], dtype=torch.int64, device=self.coll_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.group)
+                if int(flag.item()) == 0:
+                    break
+                rounds += 1
+                if rounds > self.world:  # cannot happen: a settled boundary is exact, changes only travel rightwards
+                    raise RuntimeError("frame sharding did not converge")
+        self.stats = dict(slab=(self.a, self.b), lead=self.lead, chunk=self.C, halo=self.h, boundary_rounds=rounds,
+                          resume_calls=resumed,
+                          chunks_repaired_after_exchange=getattr(self.slab, "repaired", 0) if self.slab is not None else 0)
+        if gather_fk is None:
+            gather_fk = self.want_fk
+        return dict(angles=self._gather(lambda s: s.angles(), (7,)),
+                    fk=self._gather(lambda s: s.fk(), (9, 3)) if (self.want_fk and gather_fk) else None)
+
+    def _gather(self, get, tail):
+        """(S, L, n_r, ...) per rank -> (S, L, N, ...) on every rank: one padded all-gather along the frame axis."""
+        torch, dist = self.torch, self.dist
+        if self.slab is not None:
+            x = get(self.slab)
+        else:
+            x = torch.zeros((self.S, self.L, 0) + tail, dtype=torch.float64)
+        if self.world == 1:
+            return x
+        counts = [b - a for a, b in self.slabs]
+        m = max(counts)
+        buf = torch.zeros((m, self.S, self.L) + tail, dtype=torch.float64, device=self.coll_dev)
+        buf[:x.shape[2]] = x.to(self.coll_dev).movedim(2, 0)
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(out, buf, group=self.group)
+        full = torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
+        return full.movedim(0, 2).contiguous()
+
+
+def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: Optional[int] = None, halo: Optional[int] = None,
+                        tol: float = 1e-6, want_fk: bool = True, affine=None, device: int = -1, group=None,
+                        stats: Optional[Dict] = None, slab_factory: Optional[Callable] = None):
+    """``pose`` (S, L, N, 5, 3) -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) as numpy arrays on every rank.
+    ``chunk`` / ``halo`` None: the library's automatic geometry for a recording of N frames.  Needs an initialised
+    ``torch.distributed`` process group when there is more than one rank ("nccl" = RCCL on the GPUs, "gloo" in tests)."""
+    rec = FrameShardedRecording(pose, legs, chunk, halo, tol, want_fk, affine, device, group, slab_factory)
+    out = rec.solve()
     if stats is not None:
-        stats.update(slab=(a, b), lead=lead, boundary_rounds=rounds, slab_resolved=resolved,
-                     local_chunk_stats=st.get("chunk_stats"))
-    return dict(angles=angles, fk=fk)
+        stats.update(rec.stats)
+        if rec.slab is not None and hasattr(rec.slab, "chunk_stats"):
+            stats["local_chunk_stats"] = rec.slab.chunk_stats()
+    return dict(angles=out["angles"].cpu().numpy(), fk=out["fk"].cpu().numpy() if out["fk"] is not None else None)

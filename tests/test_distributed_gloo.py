@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
-from conftest import PKG_PARENT, ROOT
+from conftest import PKG_PARENT, ROOT, load_golden
 
 
 def _worker(rank, world, port, out_dir):
@@ -103,63 +103,102 @@ def test_gather_pipeline_double_buffering(tmp_path, world):
     assert np.array_equal(seen, np.array([[100.0 * s + r for r in range(world)] for s in range(5)]))
 
 
+class OracleSlab:
+    """Stand-in for frame_sharding.DeviceSlab on the CPU: the model of the library's chunked call (tests/chunk_model.py,
+    built on the C oracle) for every chain of the slab, with the same frame_lead / chunk_resume semantics."""
+
+    def __init__(self, pose_slab, legs, chunk, halo, tol, lead, want_fk, affine=None, device=-1):
+        import torch
+        from chunk_model import ChunkedChain
+        from oracle import c_oracle
+        self.torch = torch
+        z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+        self.S, self.L, self.n = pose_slab.shape[:3]
+        self.lead, self.repaired = lead, 0
+        self.serial = lead == 0 and chunk >= self.n      # (what pick_frame_chunks does with a one-chunk call)
+        self.chains = [[ChunkedChain(c_oracle, pose_slab[s, li], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"],
+                                     chunk, halo, tol=max(tol, 0.0), lead=lead) for li, leg in enumerate(legs)]
+                       for s in range(self.S)]
+        self.oracle = c_oracle
+
+    def speculate(self):
+        for row in self.chains:
+            for m in row:
+                if self.serial:
+                    r = self.oracle.seq_leg(m.pose, *m.par)
+                    m.angles[:], m.fk[:] = r["angles"], r["fk"]
+                else:
+                    m.speculate()
+                    m.settle()
+
+    def resume(self, left):
+        for s, row in enumerate(self.chains):
+            for li, m in enumerate(row):
+                m.settle(init=left[s, li].numpy().copy(), resume=True)
+                self.repaired += int(m.stats[3:7].sum())
+
+    def _stack(self, get):
+        return self.torch.from_numpy(np.stack([np.stack([get(m) for m in row]) for row in self.chains]))
+
+    def end_state(self):
+        return self._stack(lambda m: m.angles[-1])
+
+    def angles(self):
+        return self._stack(lambda m: m.angles[self.lead:])
+
+    def fk(self):
+        return self._stack(lambda m: m.fk[self.lead:])
+
+
 def _frame_shard_worker(rank, world, port, out_dir):
-    for p in (PKG_PARENT, ROOT):
+    for p in (PKG_PARENT, ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import torch.distributed as dist
-    from oracle import c_oracle
-    from seqikpy_amd import _lib, frame_sharding
+    from seqikpy_amd import frame_sharding
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
     legs = ["RF", "LM", "RH"]
-
-    def solve(pose, legs_params, want_fk=True, affine=None, device=0, init_angles=None, **_):
-        S, L, N = pose.shape[:3]
-        ang, fk = np.zeros((S, L, N, 7)), np.zeros((S, L, N, 9, 3))
-        for s in range(S):
-            for li, leg in enumerate(legs):
-                r = c_oracle.seq_leg(pose[s, li], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"],
-                                     init=None if init_angles is None else init_angles[s, li])
-                ang[s, li], fk[s, li] = r["angles"], r["fk"]
-        return dict(angles=ang, fk=fk)
-
-    _lib.solve_seq = solve      # the oracle stands in for the library: this test is about the orchestration
     pose = np.stack([z[f"{l}_pose"][:610] for l in legs])[None]
     res = {}
     for name, tol in (("spec", 1e-6), ("exact", 0.0)):
         st = {}
-        out = frame_sharding.solve_frame_sharded(pose, legs, chunk=50, halo=8, tol=tol, stats=st)
+        out = frame_sharding.solve_frame_sharded(pose, legs, chunk=50, halo=8, tol=tol, stats=st, slab_factory=OracleSlab)
         res[name + "_angles"], res[name + "_fk"] = out["angles"], out["fk"]
         res[name + "_rounds"], res[name + "_slab"] = st["boundary_rounds"], np.array(st["slab"])
+        res[name + "_resumes"] = st["resume_calls"]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
-    if rank == 0:
-        serial = solve(pose, legs)
-        np.savez(os.path.join(out_dir, "serial.npz"), angles=serial["angles"], fk=serial["fk"])
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 3])
-def test_one_recording_sharded_by_frame_over_ranks(tmp_path, world):
-    """610 frames x 3 legs cut into slabs of whole 50-frame chunks over 2 / 3 ranks: speculative run-in +
-    boundary verification (== serial to ~tol), and with tol = 0 every boundary is repaired from the true state
-    (== serial bit for bit, after world - 1 rounds); every rank ends up with the whole result."""
+def test_one_recording_sharded_by_frame_over_ranks(tmp_path, oracle, world):
+    """610 frames x 3 legs cut into slabs of whole 50-frame chunks over 2 / 3 ranks (the model of the library's chunked
+    call stands in for the GPU): every slab speculates from a run-in, end states are all-gathered, each rank > 0 settles
+    its first chunk against its left neighbour's true end state in a resume step.  The result is the ONE-rank chunked
+    result bit for bit; with tol = 0 every boundary is repaired from the true state and the result is the serial walk,
+    bit for bit; every rank ends up with the whole recording."""
+    from chunk_model import chunked_oracle
     port = 33500 + (os.getpid() % 2000) + world
     mp.spawn(_frame_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    serial = np.load(tmp_path / "serial.npz")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = ["RF", "LM", "RH"]
+    par = {l: (z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs}
+    one = [chunked_oracle(oracle, z[f"{l}_pose"][:610], *par[l], 50, 8) for l in legs]
+    serial = [oracle.seq_leg(z[f"{l}_pose"][:610], *par[l]) for l in legs]
     slabs = []
     for r in range(world):
-        z = np.load(tmp_path / f"rank{r}.npz")
-        assert z["spec_angles"].shape == serial["angles"].shape
-        assert np.abs(z["spec_angles"] - serial["angles"]).max() < 2e-5
-        assert np.abs(z["spec_fk"] - serial["fk"]).max() < 2e-5
-        assert np.array_equal(z["exact_angles"], serial["angles"]) and np.array_equal(z["exact_fk"], serial["fk"])
-        assert int(z["exact_rounds"]) == world - 1
-        slabs.append(tuple(z["spec_slab"]))
+        got = np.load(tmp_path / f"rank{r}.npz")
+        for li in range(len(legs)):
+            assert np.array_equal(got["spec_angles"][0, li], one[li]["angles"]) and np.array_equal(got["spec_fk"][0, li], one[li]["fk"])
+            assert np.array_equal(got["exact_angles"][0, li], serial[li]["angles"]) and np.array_equal(got["exact_fk"][0, li], serial[li]["fk"])
+        assert int(got["spec_rounds"]) == 0 and int(got["exact_rounds"]) == world - 1
+        assert int(got["spec_resumes"]) == (1 if r > 0 else 0)
+        slabs.append(tuple(got["spec_slab"]))
     assert slabs[0][0] == 0 and slabs[-1][1] == 610 and all(slabs[i][1] == slabs[i + 1][0] for i in range(world - 1))
 
 
@@ -385,4 +424,83 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"])
     assert "peer writes" in m["gather_compare"]["peer"]["ran_as"]
     assert m["strong"]["sequences_per_gpu"] == 64 and m["strong"]["leg_frames_per_step_all_ranks"] == 8192 * 6
+    assert sum(m["one_recording"]["frames_per_rank"]) == 8192 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
     assert abs(b["value"] - 2 * 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+
+
+def _frame_shard_gpu_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from seqikpy_amd import _lib, frame_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)   # the ranks share the box's GPU; the library calls and the exchange are the real ones
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.tile(np.stack([z[f"{l}_pose"] for l in legs]), (1, 50, 1, 1))[None]   # 50 000 frames x 6 legs
+    st = {}
+    out = frame_sharding.solve_frame_sharded(pose, params, stats=st)                # automatic geometry of 50 000 frames
+    res = dict(angles=out["angles"], fk=out["fk"], slab=np.array(st["slab"]), geometry=np.array([st["chunk"], st["halo"]]),
+               rounds=st["boundary_rounds"], resumes=st["resume_calls"], repaired=st["chunks_repaired_after_exchange"])
+    # a nasty one: the anipose LF episode with a short run-in -- repairs inside the slabs and across the boundary
+    za = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
+    pa = [_lib.leg_params_from_arrays(za[f"{l}_seg"], za[f"{l}_bounds"], za[f"{l}_seeds"]) for l in ("LF", "RF")]
+    pose_a = np.stack([za[f"{l}_pose"][200:520] for l in ("LF", "RF")])[None]
+    out_a = frame_sharding.solve_frame_sharded(pose_a, pa, chunk=8, halo=2, stats=st)
+    res.update(a_angles=out_a["angles"], a_fk=out_a["fk"])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_recording_sharded_by_frame_on_the_gpu_equals_one_rank(tmp_path, hiplib, world):
+    """Round-2 review item 4: ONE recording (df3d x 50 = 50 000 frames x 6 legs), frame-sharded over 2 / 3 ranks that
+    hand their slabs to the library's frame chunks (frame_lead, chunk_states, chunk_resume), == the one-rank chunked
+    call with the same geometry, bit for bit -- angles and FK, on every rank."""
+    port = 35500 + (os.getpid() % 2000) + world
+    mp.spawn(_frame_shard_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.tile(np.stack([z[f"{l}_pose"] for l in legs]), (1, 50, 1, 1))[None]
+    c, h, k = hiplib.frame_chunk_plan(50_000)
+    one = hiplib.solve_seq(pose, params, frame_chunk=c, frame_halo=h)
+    assert one["chunk_stats"]["chunks"] == 6 * k
+    za = load_golden("anipose_shipped")
+    pa = [hiplib.leg_params_from_arrays(za[f"{l}_seg"], za[f"{l}_bounds"], za[f"{l}_seeds"]) for l in ("LF", "RF")]
+    one_a = hiplib.solve_seq(np.stack([za[f"{l}_pose"][200:520] for l in ("LF", "RF")])[None], pa, frame_chunk=8, frame_halo=2)
+    assert one_a["chunk_stats"]["inconsistent_at_first_check"] > 0
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert tuple(got["geometry"]) == (c, h)
+        assert np.array_equal(got["angles"], one["angles"]) and np.array_equal(got["fk"], one["fk"]), r
+        assert int(got["resumes"]) == (1 if r > 0 else 0) and int(got["rounds"]) == 0
+        assert np.array_equal(got["a_angles"], one_a["angles"]) and np.array_equal(got["a_fk"], one_a["fk"]), r
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_one_recording_frame_sharded_over_two_ranks(tmp_path):
+    """`python3 bench.py --gpus 2 --one-recording`: config 3 literally -- one recording, contiguous frame slabs on the
+    ranks' GPUs (here both on the box's GPU), one JSON line with the check against the serial walk."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames", "40000", "--one-recording"], env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and "ONE recording" in b["config"]["workload"]
+    assert sum(b["config"]["frames_per_rank"]) == 40000 and b["config"]["boundary_rounds"] == 0
+    assert b["check"]["first_chunk_equals_serial_bit_for_bit"] and b["check"]["max_abs_vs_serial"] < 2e-5
+    assert b["check"]["max_abs_vs_reference_first_1000_frames"] < 1e-4
+    assert abs(b["value"] - 40000 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]

@@ -265,6 +265,31 @@ def test_python_api_default_is_the_serial_walk_and_auto_is_within_parity_of_ship
 
 
 @pytest.mark.gpu
+def test_python_api_explicit_chunk_parameters(hiplib):
+    """run_ik_and_fk(frame_parallel=dict(chunk=..., halo=...)) on the shipped grooming recording (config 4): within the
+    parity bar of the shipped outputs; unknown options and stage subsets are refused."""
+    from conftest import LF_DEGENERATE
+    from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
+    from seqikpy_amd.kinematic_chain import KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinSeq
+    za = load_golden("anipose_shipped")
+    ik = LegInvKinSeq({"RF_leg": za["RF_pose"], "LF_leg": za["LF_pose"]}, KinematicChainSeq(BOUNDS, ["RF", "LF"]),
+                      INITIAL_ANGLES, log_level="ERROR")
+    ang, fk = ik.run_ik_and_fk(frame_parallel=dict(chunk=32, halo=16))
+    got = np.stack([ang[f"Angle_RF_{d}"] for d in hiplib.DOFS], 1)
+    assert np.abs(got - za["RF_angles"]).max() < 1e-4
+    ok = np.ones(6000, bool)
+    ok[LF_DEGENERATE[0]:LF_DEGENERATE[1]] = False
+    got = np.stack([ang[f"Angle_LF_{d}"] for d in hiplib.DOFS], 1)
+    assert np.abs(got - za["LF_angles"])[ok].max() < 1e-4
+    assert ik.frame_chunk_stats["chunks"] == 2 * 188 and ik.frame_chunk_report["RF"]["frames_per_chunk"] == 32
+    with pytest.raises(ValueError):
+        ik.run_ik_and_fk(frame_parallel=dict(chunks=3))
+    with pytest.raises(ValueError):
+        ik.run_ik_and_fk(frame_parallel=True, stages=[1, 2])
+
+
+@pytest.mark.gpu
 def test_a_recording_gives_the_same_bits_alone_in_a_batch_and_in_a_longer_batch(hiplib):
     """Round-2 review item 3: under frame_parallel="auto" one recording alone == the same recording inside
     run_ik_and_fk_many == inside a batch twice as long == through pipeline.run_body_ik, bit for bit."""
