@@ -123,7 +123,7 @@ BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
 BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 + 24, 4: 48 + 96 + 8 + 144}
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
-TRAFFIC_FILES = ("traffic_r02.json", "traffic_r01.json")  # newest first; used only if it matches the workload
+TRAFFIC_ROUNDS = ("r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
 LF_WINDOW = (284, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
@@ -393,6 +393,58 @@ def one_recording_leg(dist, world, rank, n_frames, steps, warmup, coll_dev="cpu"
             "check": chk}
 
 
+def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index):
+    """The VALU-side roofline figures from the newest committed PMC summary (profiles/traffic_rNN*.json, written by
+    scripts/summarize_profile.py) that matches this workload -- used only if it was measured on THIS build: the summary
+    carries the sha256 of the solver kernels' sources, which must equal the sources the loaded library was built from.
+    -> (traffic, valu, fp64, matches_build, file)"""
+    suffix = ("_staged" if staged else "") + ("" if variant == "iid" else "_" + variant)
+    for rnd in TRAFFIC_ROUNDS:
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{rnd}{suffix}.json")
+        if not os.path.exists(tpath):
+            continue
+        tj = json.load(open(tpath))
+        if tj.get("units_per_launch") != units_per_step or tj.get("variant") != variant:
+            continue
+        matches = tj.get("csrc_sha256") == _lib.csrc_sha256()
+        traffic = tj.get(f"{key}_hbm_bytes_per_launch")
+        if not matches:   # counters of another build say nothing about this one
+            return None, None, None, False, os.path.basename(tpath)
+        valu, fp64 = None, None
+        names = [f"stage{k}" for k in (1, 2, 3, 4)] if staged else ["fused"]
+        insts = [tj.get(f"{n}_valu_insts_per_launch") for n in names]
+        mix = {c: [tj.get(f"{n}_f64_{c}_insts_per_launch") for n in names] for c in ("add", "mul", "fma", "trans")}
+        utils_ = [tj.get(f"{n}_valu_lane_utilisation") for n in names]
+        if all(v is not None for v in insts) and all(v is not None for vs in mix.values() for v in vs):
+            # What actually bounds the path: VALU issue.  A wave64 FP64 instruction occupies its SIMD's 16 f64 lanes
+            # for 4 cycles; every other VALU instruction (selects, compares, moves, 64-bit address arithmetic) takes
+            # 2 cycles on the SIMD-32 when several waves share a SIMD (MI355X_MICROARCH.md, "Execution model" and the
+            # cycle-constants row `v_fma_f32` wave64).  The quarter-rate rcp / rsq / sqrt seeds are priced like the
+            # other f64 instructions, so this is a FLOOR: the step cannot be shorter than
+            #     (f64 instructions x 4 + other VALU instructions x 2) / (SIMDs x clock).
+            n_cu, clock_khz, _ = _lib.device_attributes(device_index)
+            simds, clock_hz = n_cu * 4, clock_khz * 1e3
+            n_f64 = sum(sum(vs) for vs in mix.values())
+            n_all = sum(insts)
+            floor_ms = (n_f64 * 4.0 + (n_all - n_f64) * 2.0) / (simds * clock_hz) * 1e3
+            valu = {"valu_insts_per_step": n_all, "f64_insts_per_step": n_f64, "simds": simds, "clock_MHz": clock_khz / 1e3,
+                    "cycles_per_inst": {"f64": 4, "other": 2},
+                    "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": ms_per_step,
+                    "frac_of_valu_issue_floor": floor_ms / ms_per_step,
+                    "lane_utilisation": utils_,
+                    "source": "SQ_INSTS_VALU / SQ_INSTS_VALU_*_F64 / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch "
+                              f"from profiles/{os.path.basename(tpath)} (rocprofv3 --pmc, own passes), timing live"}
+            if all(u is not None for u in utils_):
+                # FP64 operations actually performed: wave-level instruction counts by class x 64 lanes x the
+                # share of active lanes (FMA = 2 flops), against the 78.6 TFLOP/s FP64 vector peak
+                flops = sum((mix["add"][i] + mix["mul"][i] + mix["trans"][i] + 2.0 * mix["fma"][i]) * 64.0 * utils_[i]
+                            for i in range(len(names)))
+                fp64 = {"flops_per_step": flops, "f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
+                        "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
+        return traffic, valu, fp64, True, os.path.basename(tpath)
+    return None, None, None, None, None
+
+
 def parity_report():
     """HIP vs the committed reference fixtures, on the GPU, fixtures only (no oracle involved): the shipped anipose
     outputs (reference's leg_joint_angles.pkl, RF + LF x 6000 frames) and the df3d recording solved by the
@@ -598,46 +650,7 @@ def main():
     else:  # one kernel per step: event [0] is recorded in front of it, [1] behind it
         kname, key, bytes_unit, dom_ms = "seqik_fused_kernel<true>", "fused", BYTES_PATH, float(mean_stage_ms[0])
     ach_gbs = bytes_unit * units_per_step / (dom_ms * 1e-3) / 1e9
-    traffic, valu, fp64 = None, None, None
-    for fn in TRAFFIC_FILES:
-        tpath = os.path.join(ROOT, "profiles", fn.replace(".json", "_staged.json") if args.staged else fn)
-        if not os.path.exists(tpath):
-            continue
-        tj = json.load(open(tpath))
-        if tj.get("units_per_launch") != units_per_step or tj.get("variant") != args.variant:
-            continue
-        traffic = tj.get(f"{key}_hbm_bytes_per_launch")
-        names = [f"stage{k}" for k in (1, 2, 3, 4)] if args.staged else ["fused"]
-        insts = [tj.get(f"{n}_valu_insts_per_launch") for n in names]
-        mix = {c: [tj.get(f"{n}_f64_{c}_insts_per_launch") for n in names] for c in ("add", "mul", "fma", "trans")}
-        utils_ = [tj.get(f"{n}_valu_lane_utilisation") for n in names]
-        if all(v is not None for v in insts) and all(v is not None for vs in mix.values() for v in vs):
-            # What actually bounds the path: VALU issue.  A wave64 FP64 instruction occupies its SIMD's 16 f64 lanes
-            # for 4 cycles; every other VALU instruction (selects, compares, moves, 64-bit address arithmetic) takes
-            # 2 cycles on the SIMD-32 when several waves share a SIMD (MI355X_MICROARCH.md, "Execution model" and the
-            # cycle-constants row `v_fma_f32` wave64).  The quarter-rate rcp / rsq / sqrt seeds are priced like the
-            # other f64 instructions, so this is a FLOOR: the step cannot be shorter than
-            #     (f64 instructions x 4 + other VALU instructions x 2) / (SIMDs x clock).
-            n_cu, clock_khz, _ = _lib.device_attributes(device_index)
-            simds, clock_hz = n_cu * 4, clock_khz * 1e3
-            n_f64 = sum(sum(vs) for vs in mix.values())
-            n_all = sum(insts)
-            floor_ms = (n_f64 * 4.0 + (n_all - n_f64) * 2.0) / (simds * clock_hz) * 1e3
-            valu = {"valu_insts_per_step": n_all, "f64_insts_per_step": n_f64, "simds": simds, "clock_MHz": clock_khz / 1e3,
-                    "cycles_per_inst": {"f64": 4, "other": 2},
-                    "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": ms_per_step,
-                    "frac_of_valu_issue_floor": floor_ms / ms_per_step,
-                    "lane_utilisation": utils_,
-                    "source": "SQ_INSTS_VALU / SQ_INSTS_VALU_*_F64 / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch "
-                              f"from profiles/{os.path.basename(tpath)} (rocprofv3 --pmc, own passes), timing live"}
-            if all(u is not None for u in utils_):
-                # FP64 operations actually performed: wave-level instruction counts by class x 64 lanes x the
-                # share of active lanes (FMA = 2 flops), against the 78.6 TFLOP/s FP64 vector peak
-                flops = sum((mix["add"][i] + mix["mul"][i] + mix["trans"][i] + 2.0 * mix["fma"][i]) * 64.0 * utils_[i]
-                            for i in range(len(names)))
-                fp64 = {"flops_per_step": flops, "f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
-                        "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
-        break
+    traffic, valu, fp64, pmc_matches_build, pmc_file = pmc_roofline(args.variant, args.staged, key, units_per_step, ms_per_step, device_index)
     hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
            "bytes_per_unit": bytes_unit,
            "note": "algorithmic bytes x units per launch / the kernel's average launch duration (launches of "
@@ -652,9 +665,13 @@ def main():
                             "actually performed by active lanes per second (PMC instruction mix x lane share, live "
                             "timing) against the vector FP64 peak; `valu_issue` = how close the step is to the floor its "
                             "wave-instruction count allows; `hbm` = the algorithmic-bytes figure"}
-    else:  # no matching PMC summary for this workload: only the HBM figure can be stated
+    else:  # no PMC summary of THIS build for this workload: only the HBM figure can be stated
         roofline = {"bound": "hbm", "kernel": kname, **hbm, "traffic": traffic, "avg_launch_ms": dom_ms,
-                    "note": hbm["note"] + " (no PMC summary under profiles/ matches this workload, so the VALU figures are absent)"}
+                    "note": hbm["note"] + (" (the PMC summary under profiles/ was measured on other kernel sources than this "
+                                           "build's: the VALU figures are withheld)" if pmc_matches_build is False else
+                                           " (no PMC summary under profiles/ matches this workload, so the VALU figures are absent)")}
+    roofline["pmc_matches_build"] = pmc_matches_build
+    roofline["pmc_file"] = pmc_file
     if args.staged:
         roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
         roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
@@ -763,8 +780,16 @@ def main():
             bo = Batch(pose_o, params, args, args.streams)
             ko = max(12, min(40, args.steps // 2))
             dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=3)
-            out["variants"] = {other: {"value": bo.units * ko / dto, "unit": "leg-frame solves/s", "ms_per_step": dto / ko * 1e3,
-                                       "steps": ko, "streams": len(bo.streams)},
+            ms_o = dto / ko * 1e3
+            _, valu_o, fp64_o, match_o, file_o = pmc_roofline(other, args.staged, key, bo.units, ms_o, device_index)
+            roof_o = {"pmc_matches_build": match_o, "pmc_file": file_o}
+            if fp64_o:
+                tfl_o = fp64_o["flops_per_step"] / (ms_o * 1e-3) / 1e12
+                roof_o.update({"bound": "valu-fp64", "achieved": tfl_o, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tfl_o / FP64_VECTOR_PEAK_TF, "frac_of_valu_issue_floor": valu_o["frac_of_valu_issue_floor"],
+                               "lane_utilisation": valu_o["lane_utilisation"], "valu_insts_per_step": valu_o["valu_insts_per_step"]})
+            out["variants"] = {other: {"value": bo.units * ko / dto, "unit": "leg-frame solves/s", "ms_per_step": ms_o,
+                                       "steps": ko, "streams": len(bo.streams), "roofline": roof_o},
                                "note": "smooth = temporally continuous targets (band-limited random walk): the realistic "
                                        "case; iid = every frame an unrelated pose"}
             del bo

@@ -15,9 +15,11 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 stats = pd.read_csv(newest(f"{src}/{tag}_stats/*/*_kernel_stats.csv"))
-stats.to_csv(f"{dst}/{rnd}_bench_kernel_stats.csv", index=False)
 bench_line = [l for l in open(f"{src}/{tag}_stats.log") if l.startswith('{"metric"')][0]
-open(f"{dst}/{rnd}_bench_under_rocprof.json", "w").write(bench_line)
+variant = json.loads(bench_line)["config"]["variant"]
+vtag = "" if variant == "iid" else "_" + variant
+stats.to_csv(f"{dst}/{rnd}_bench{vtag}_kernel_stats.csv", index=False)
+open(f"{dst}/{rnd}_bench{vtag}_under_rocprof.json", "w").write(bench_line)
 
 def pmc(kind):
     d = pd.read_csv(newest(f"{src}/{tag}_{kind}/*/*_counter_collection.csv"))
@@ -29,11 +31,15 @@ def pmc(kind):
 fetch, write, sq = pmc("fetch"), pmc("write"), pmc("sq")
 f64 = pmc("f64") if glob.glob(f"{src}/{tag}_f64/*/*_counter_collection.csv") else None
 pm = pd.concat([fetch, write, sq] + ([f64] if f64 is not None else []), axis=1)
-pm.to_csv(f"{dst}/{rnd}_bench_pmc_per_launch.csv")
+pm.to_csv(f"{dst}/{rnd}_bench{vtag}_pmc_per_launch.csv")
 b = json.loads(bench_line)
 units = b["config"]["sequences_per_gpu"] * b["config"]["legs"] * b["config"]["frames_per_sequence"]
+sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+from seqikpy_amd import _lib  # noqa: E402
 out = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* (separate passes) on `python3 bench.py --no-cpu-baseline`",
        "units_per_launch": units, "variant": b["config"]["variant"],
+       # the build these counters belong to: bench.py uses them only while the solver kernels' sources are unchanged
+       "csrc_sha256": _lib.csrc_sha256(), "csrc_files": _lib.KERNEL_SOURCES,
        "note": "FETCH_SIZE / WRITE_SIZE are in KiB; bytes = value * 1024, mean over the launches of the run. "
                "FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 and under-reports wide (16 B/lane) streaming reads by 2x "
                "(MI355X_MICROARCH.md); these kernels issue 8-byte per-lane loads, for which the counter is uncalibrated, "
@@ -50,6 +56,7 @@ for k in pm.index:
     if f64 is not None:  # wave-level FP64 instructions by class (FMA counts two flops)
         for c in ("ADD", "MUL", "FMA", "TRANS"):
             out[f"{k}_f64_{c.lower()}_insts_per_launch"] = float(f64.loc[k, f"SQ_INSTS_VALU_{c}_F64"])
-json.dump(out, open(f"{dst}/traffic_{rnd}.json", "w"), indent=1)
+suffix = ("_staged" if "stage1" in pm.index else "") + ("" if b["config"]["variant"] == "iid" else "_" + b["config"]["variant"])
+json.dump(out, open(f"{dst}/traffic_{rnd}{suffix}.json", "w"), indent=1)
 print(pm.round(0).to_string())
 print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("bytes_per_launch")}, indent=0))

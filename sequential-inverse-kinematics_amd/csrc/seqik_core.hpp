@@ -44,6 +44,65 @@ namespace seqik {
 enum : int { AXIS_X = 0, AXIS_Y = 1, AXIS_Z = 2 };
 
 SEQIK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---------------------------------------------------------------------------
+// IEEE division and square root, as the compiler expands them for gfx950 minus the range scaling.
+//
+// hipcc expands a binary64 `a / b` into 11 instructions -- v_div_scale x 2, v_rcp_f64, four Newton multiply-adds, a
+// multiply, a residual multiply-add, v_div_fmas, v_div_fixup -- and `sqrt(x)` into 18 (scale test + v_ldexp, v_rsq_f64,
+// two multiplies, seven multiply-adds, v_ldexp back, a zero / infinity test with two selects).  The v_div_scale /
+// v_div_fmas / v_ldexp steps only move operands whose exponents are within ~2^250 of the limits of the format into a
+// range where the Newton iteration cannot over- or underflow: for every other operand they are the identity, and the
+// remaining sequence -- the same instructions on the same values -- gives the same, correctly rounded result.  div_() and
+// sqrt_() are those sequences without the scaling (9 and 13 instructions: v_div_fixup, which supplies the IEEE results for
+// zero / infinite / NaN operands, and the zero / infinity selects of the square root stay).  A pass of the solver holds
+// ~25 divisions and ~14 square roots: 7 % fewer vector instructions per benchmark step.
+//   Valid while |a|, |b|, |a / b| lie in [2^-767, 2^767] or are 0 / inf / NaN (division) and x >= 2^-767 or x == 0
+// (square root).  Angles, segment lengths, residuals, Jacobians, trust-region radii and multipliers of this solver live
+// between ~1e-100 and ~1e+20 for any key points a camera can produce (the smallest quantity, the Levenberg-Marquardt
+// multiplier after scipy's ten thousandfold reductions, is ~1e-50 and enters as its square).  The oracle divides and takes
+// roots with the host's IEEE operations; every parity test and the soak therefore also checks this equivalence.
+// SEQIK_IEEE_DIV_SQRT=1 builds the kernels with the compiler's full expansions (A/B check, tests/tools/soak_parity.py).
+// ---------------------------------------------------------------------------
+#ifndef SEQIK_IEEE_DIV_SQRT
+#define SEQIK_IEEE_DIV_SQRT 0
+#endif
+
+SEQIK_HD double div_(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !SEQIK_IEEE_DIV_SQRT
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = a * y;
+    double r = __builtin_fma(-b, q, a);
+    q = __builtin_fma(r, y, q);
+    return __builtin_amdgcn_div_fixup(q, b, a);
+#else
+    return a / b;
+#endif
+}
+
+SEQIK_HD double sqrt_(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !SEQIK_IEEE_DIV_SQRT
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0 and +inf are their own square roots
+#else
+    return sqrt(x);
+#endif
+}
 enum : int { STATUS_NONE = -99 };
 
 // ---------------------------------------------------------------------------
@@ -224,7 +283,7 @@ SEQIK_HD double norm2v(const double *a)
 {
     double acc = a[0] * a[0];
     if constexpr (NA == 2) acc = fma_(a[1], a[1], acc);
-    return sqrt(acc);
+    return sqrt_(acc);
 }
 
 template <int NA>
@@ -296,8 +355,8 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
         acc = fma_(Jh[1][0], Jh[1][0], acc);
         acc = fma_(Jh[2][0], Jh[2][0], acc);
         acc = fma_(q[0], q[0], acc);
-        double sv0 = sqrt(acc);
-        double inv0 = (sv0 > 0.0) ? 1.0 / sv0 : 0.0;
+        double sv0 = sqrt_(acc);
+        double inv0 = (sv0 > 0.0) ? div_(1.0, sv0) : 0.0;
         double u0 = (Jh[0][0] * inv0) * f[0];
         u0 = fma_(Jh[1][0] * inv0, f[1], u0);
         u0 = fma_(Jh[2][0] * inv0, f[2], u0);
@@ -326,12 +385,12 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
             }
             have_norms = true;
             if (gamma == 0.0) break;
-            if (fabs(gamma) <= TOL * sqrt(alpha * beta)) break;
+            if (fabs(gamma) <= TOL * sqrt_(alpha * beta)) break;
             have_norms = false;
-            double zeta = (beta - alpha) / (2.0 * gamma);
-            double t = 1.0 / (fabs(zeta) + sqrt(fma_(zeta, zeta, 1.0)));
+            double zeta = div_(beta - alpha, 2.0 * gamma);
+            double t = div_(1.0, fabs(zeta) + sqrt_(fma_(zeta, zeta, 1.0)));
             if (zeta < 0.0) t = -t;
-            double c = 1.0 / sqrt(fma_(t, t, 1.0));
+            double c = div_(1.0, sqrt_(fma_(t, t, 1.0)));
             double sn = c * t;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -351,10 +410,10 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
 #pragma unroll
             for (int i = 0; i < 5; ++i) { alpha = fma_(A[i][0], A[i][0], alpha); beta = fma_(A[i][1], A[i][1], beta); }
         }
-        double sv0 = sqrt(alpha);
-        double sv1 = sqrt(beta);
-        double inv0 = (sv0 > 0.0) ? 1.0 / sv0 : 0.0;
-        double inv1 = (sv1 > 0.0) ? 1.0 / sv1 : 0.0;
+        double sv0 = sqrt_(alpha);
+        double sv1 = sqrt_(beta);
+        double inv0 = (sv0 > 0.0) ? div_(1.0, sv0) : 0.0;
+        double inv1 = (sv1 > 0.0) ? div_(1.0, sv1) : 0.0;
         double u0 = (A[0][0] * inv0) * f[0], u1 = (A[0][1] * inv1) * f[0];
 #pragma unroll
         for (int k = 1; k < 3; ++k) {
@@ -377,19 +436,19 @@ SEQIK_HD void svd_active(const double Jh[3][2], const double *q, const double *f
 template <int NA>
 SEQIK_HD void phi_and_ratio(double alpha, const double *suf, const double *s, double Delta, double &phi, double &ratio)
 {
-    double r0 = 1.0 / fma_(s[0], s[0], alpha);
+    double r0 = div_(1.0, fma_(s[0], s[0], alpha));
     double t0 = suf[0] * r0;
     double acc = (t0 * t0) * r0;
     double nn = t0 * t0;
     if constexpr (NA == 2) {
-        double r1 = 1.0 / fma_(s[1], s[1], alpha);
+        double r1 = div_(1.0, fma_(s[1], s[1], alpha));
         double t1 = suf[1] * r1;
         acc = fma_(t1 * t1, r1, acc);
         nn = fma_(t1, t1, nn);
     }
-    double p_norm = sqrt(nn);
+    double p_norm = sqrt_(nn);
     phi = p_norm - Delta;
-    ratio = -(phi * p_norm) / acc;
+    ratio = div_(-(phi * p_norm), acc);
 }
 
 template <int NA>
@@ -422,13 +481,13 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
         double threshold = EPS * 3 * s[0];
         full_rank = s[NA - 1] > threshold;
         if (full_rank) {
-            tmp[0] = uf[0] / s[0];
-            if constexpr (NA == 2) tmp[1] = uf[1] / s[1];
+            tmp[0] = div_(uf[0], s[0]);
+            if constexpr (NA == 2) tmp[1] = div_(uf[1], s[1]);
             apply_V_neg<NA>(V, tmp, p);
             if (norm2v<NA>(p) <= Delta) { alpha_io = 0.0; return; }
         }
     }
-    const double inv_Delta = 1.0 / Delta;
+    const double inv_Delta = div_(1.0, Delta);
     double alpha_upper = norm2v<NA>(suf) * inv_Delta;
     double alpha_lower = 0.0;
     if (full_rank) {
@@ -437,10 +496,10 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
         alpha_lower = -ratio;
     }
     double alpha = alpha_io;
-    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
     for (int it = 0; it < 10; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
-            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+            alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
         double phi, ratio;
         phi_and_ratio<NA>(alpha, suf, s, Delta, phi, ratio);
         if (phi < 0) alpha_upper = alpha;
@@ -448,10 +507,10 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
-    tmp[0] = suf[0] / fma_(s[0], s[0], alpha);
-    if constexpr (NA == 2) tmp[1] = suf[1] / fma_(s[1], s[1], alpha);
+    tmp[0] = div_(suf[0], fma_(s[0], s[0], alpha));
+    if constexpr (NA == 2) tmp[1] = div_(suf[1], fma_(s[1], s[1], alpha));
     apply_V_neg<NA>(V, tmp, p);
-    double scale = Delta / norm2v<NA>(p);
+    double scale = div_(Delta, norm2v<NA>(p));
     p[0] = p[0] * scale;
     if constexpr (NA == 2) p[1] = p[1] * scale;
     alpha_io = alpha;
@@ -459,10 +518,10 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
 
 // ---------------------------------------------------------------------------
 // Trust-region step of the 2-unknown stages (1-3) in closed form (mirrors oracle solve_tr_2x2 operation for
-// operation).  scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] (5 x 2); all it
+// operation).  scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt_(diag_h))]] (5 x 2); all it
 // needs is p(alpha) = -(A^T A + alpha I)^-1 J_h^T f, ||p||, phi'(alpha) = -p^T (A^T A + alpha I)^-1 p / ||p|| and, for
 // its rank test, the extreme singular values.  A^T A = J_h^T J_h + diag(diag_h) is 2 x 2: the inverse by cofactors,
-// the singular values from its eigenvalues (lambda_max = tr/2 + sqrt(((a-c)/2)^2 + b^2), lambda_min = det /
+// the singular values from its eigenvalues (lambda_max = tr/2 + sqrt_(((a-c)/2)^2 + b^2), lambda_min = det /
 // lambda_max).  Root search, bracket updates and the final rescaling are scipy's.  On the shipped recordings this
 // follows the SVD-based variant to 6e-6 rad with the same evaluation counts on 99.8 % of the solves and the same
 // distance to the reference; it removes the one-sided Jacobi sweeps (3 divisions + 3 square roots
@@ -472,7 +531,7 @@ SEQIK_HD void solve_lsq_trust_region(const double *uf, const double *s, const do
 SEQIK_HD void tr2_apply(double aa, double b, double cc, const double *r, double *q)
 {
     double det = fma_(aa, cc, -(b * b));
-    double inv = 1.0 / det;
+    double inv = div_(1.0, det);
     q[0] = fma_(cc, r[0], -(b * r[1])) * inv;
     q[1] = fma_(aa, r[1], -(b * r[0])) * inv;
 }
@@ -482,11 +541,11 @@ SEQIK_HD void tr2_phi(double aa, double b, double cc, const double *r, double De
 {
     double q[2];
     tr2_apply(aa, b, cc, r, pp);
-    double p_norm = sqrt(fma_(pp[1], pp[1], pp[0] * pp[0]));
+    double p_norm = sqrt_(fma_(pp[1], pp[1], pp[0] * pp[0]));
     tr2_apply(aa, b, cc, pp, q);
     double acc = fma_(pp[1], q[1], pp[0] * q[0]);
     phi = p_norm - Delta;
-    ratio = -(phi * p_norm) / acc;
+    ratio = div_(-(phi * p_norm), acc);
 }
 
 template <bool DEFICIENT>
@@ -505,16 +564,16 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
     bool full_rank = false;
     if constexpr (!DEFICIENT) {
         double h = 0.5 * (a - c);
-        double lmax = fma_(0.5, a + c, sqrt(fma_(h, h, b * b)));
-        double lmin = fma_(a, c, -(b * b)) / lmax;
+        double lmax = fma_(0.5, a + c, sqrt_(fma_(h, h, b * b)));
+        double lmin = div_(fma_(a, c, -(b * b)), lmax);
         full_rank = lmin > 4.437342591868191e-31 * lmax;  // (3 eps)^2: s_min > eps * m * s_max
         if (full_rank) {
             tr2_apply(a + 0.0, b, c + 0.0, r, pp);
-            if (sqrt(fma_(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; alpha_io = 0.0; return; }
+            if (sqrt_(fma_(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; alpha_io = 0.0; return; }
         }
     }
-    const double inv_Delta = 1.0 / Delta;
-    double alpha_upper = sqrt(fma_(r[1], r[1], r[0] * r[0])) * inv_Delta;
+    const double inv_Delta = div_(1.0, Delta);
+    double alpha_upper = sqrt_(fma_(r[1], r[1], r[0] * r[0])) * inv_Delta;
     double alpha_lower = 0.0;
     double phi = 0.0, ratio = 0.0;
     if (full_rank) {
@@ -522,7 +581,7 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
         alpha_lower = -ratio;
     }
     double alpha = alpha_io;
-    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
     // SHORTCUT of the m < n root search (mirrors oracle solve_tr_2x2, where it is derived): when the Gauss-Newton
     // step lies well inside the trust region scipy's ten iterations are ten resets alpha <- 0.001 alpha_upper plus
     // one Newton step from the last alpha, so only that alpha is evaluated; otherwise the verbatim loop runs.
@@ -548,7 +607,7 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
     double aa_prev = __builtin_nan(""), cc_prev = __builtin_nan("");
     for (int it = 0; it < 10 && !shortcut; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
-            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+            alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
         const double aa = a + alpha, cc = c + alpha;
         if (!(aa == aa_prev && cc == cc_prev)) {
             tr2_phi(aa, b, cc, r, Delta, pp, phi, ratio);
@@ -561,7 +620,7 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
         if (fabs(phi) < 0.01 * Delta) break;
     }
     tr2_apply(a + alpha, b, c + alpha, r, pp);
-    double scale = Delta / sqrt(fma_(pp[1], pp[1], pp[0] * pp[0]));
+    double scale = div_(Delta, sqrt_(fma_(pp[1], pp[1], pp[0] * pp[0])));
     p[0] = -(pp[0] * scale);
     p[1] = -(pp[1] * scale);
     alpha_io = alpha;
@@ -582,12 +641,12 @@ SEQIK_HD double step_size_to_bound(const double *x, const double *s, const doubl
     const double INF = __builtin_huge_val();
     double steps[2] = {INF, INF};
     if (s[0] != 0.0) {
-        double inv_s = 1.0 / s[0];
+        double inv_s = div_(1.0, s[0]);
         steps[0] = fmax((lb[0] - x[0]) * inv_s, (ub[0] - x[0]) * inv_s);
     }
     if constexpr (NA == 2)
         if (s[1] != 0.0) {
-            double inv_s = 1.0 / s[1];
+            double inv_s = div_(1.0, s[1]);
             steps[1] = fmax((lb[1] - x[1]) * inv_s, (ub[1] - x[1]) * inv_s);
         }
     double min_step = fmin(steps[0], steps[1]);
@@ -622,7 +681,7 @@ SEQIK_HD double minimize_quadratic_1d(double a, double b, double lb, double ub, 
         if (y < ybest) { ybest = y; tbest = ub; }
     }
     if (a != 0) {
-        double extremum = -0.5 * b / a;
+        double extremum = div_(-0.5 * b, a);
         if (lb < extremum && extremum < ub) {
             double y = fma_(extremum, fma_(a, extremum, b), c);
             if (y < ybest) { ybest = y; tbest = extremum; }
@@ -661,17 +720,17 @@ SEQIK_HD double select_step_reflective(
         double a = dot2v<NA>(r_h, r_h);
         double b = dot2v<NA>(p_h, r_h);
         double c = fma_(-Delta, Delta, dot2v<NA>(p_h, p_h));
-        double dd = sqrt(fma_(b, b, -(a * c)));
+        double dd = sqrt_(fma_(b, b, -(a * c)));
         double q = -(b + copysign(dd, b));
-        double t1 = q / a;
-        double t2 = c / q;
+        double t1 = div_(q, a);
+        double t2 = div_(c, q);
         to_tr = (t1 < t2) ? t2 : t1;
     }
     double to_bound = step_size_to_bound<NA>(x_on_bound, r, lb, ub, nullptr);
     double r_stride = fmin(to_bound, to_tr);
     double r_stride_l, r_stride_u;
     if (r_stride > 0) {
-        r_stride_l = (1 - theta) * p_stride / r_stride;
+        r_stride_l = div_((1 - theta) * p_stride, r_stride);
         r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
     } else {
         r_stride_l = 0;
@@ -708,7 +767,7 @@ SEQIK_HD double select_step_reflective(
     double ag_h[2], ag[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
-    to_tr = Delta / norm2v<NA>(ag_h);
+    to_tr = div_(Delta, norm2v<NA>(ag_h));
     to_bound = step_size_to_bound<NA>(x, ag, lb, ub, nullptr);
     double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
     double ag_value;
@@ -801,7 +860,7 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
         double s1, c1, f1[3];
         sincos_cw(x1, s1, c1);
         residual_sc<STAGE>(P, s1, c1, sb, cb, f1);
-        double inv_dx = 1.0 / dx;
+        double inv_dx = div_(1.0, dx);
 #pragma unroll
         for (int i = 0; i < 3; ++i) J[i][0] = (f1[i] - f0[i]) * inv_dx;
     }
@@ -812,7 +871,7 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
         double s1, c1, f1[3];
         sincos_cw(x1, s1, c1);
         residual_sc<STAGE>(P, sa, ca, s1, c1, f1);
-        double inv_dx = 1.0 / dx;
+        double inv_dx = div_(1.0, dx);
 #pragma unroll
         for (int i = 0; i < 3; ++i) J[i][1] = (f1[i] - f0[i]) * inv_dx;
     } else {
@@ -875,7 +934,7 @@ SEQIK_HD void fd_jacobian_pair(const StageProblem<STAGE> &P, const double *x, co
     double s1, c1, f1[3];
     sincos_cw(x1, s1, c1);
     residual_sc<STAGE>(P, odd ? sa : s1, odd ? ca : c1, odd ? s1 : sb, odd ? c1 : cb, f1);
-    double inv_dx = 1.0 / dx;
+    double inv_dx = div_(1.0, dx);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double mine = (f1[i] - f0[i]) * inv_dx;
@@ -1195,19 +1254,19 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             cl_scaling(x[0], g[0], lb[0], ub[0], v[0], dv[0]);
             if constexpr (NA == 2) cl_scaling(x[1], g[1], lb[1], ub[1], v[1], dv[1]);
             else { v[1] = 1.0; dv[1] = 0.0; }
-            // d = sqrt(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
+            // d = sqrt_(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
             double d[2];
-            d[0] = sqrt(v[0]);
-            d[1] = (NA == 2) ? sqrt(v[1]) : 1.0;
+            d[0] = sqrt_(v[0]);
+            d[1] = (NA == 2) ? sqrt_(v[1]) : 1.0;
             if (first_pass) {
-                // Delta_0 = || x0 / sqrt(v) || over ALL links (inert entries: v = 1)
+                // Delta_0 = || x0 / sqrt_(v) || over ALL links (inert entries: v = 1)
                 double acc = sc.x_pre_sq;
                 // (x is still the start point x0 here: no step has been taken yet)
-                double t0 = x[0] / d[0];
+                double t0 = div_(x[0], d[0]);
                 acc = fma_(t0, t0, acc);
-                if constexpr (NA == 2) { double t1 = x[1] / d[1]; acc = fma_(t1, t1, acc); }
+                if constexpr (NA == 2) { double t1 = div_(x[1], d[1]); acc = fma_(t1, t1, acc); }
                 acc = fma_(sc.x_suf, sc.x_suf, acc);
-                Delta = sqrt(acc);
+                Delta = sqrt_(acc);
                 if (Delta == 0) Delta = 1.0;
                 first_pass = false;
             }
@@ -1237,7 +1296,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if constexpr (NA == 2) {
                     solve_tr_2x2<T::DEFICIENT>(Jh, diag_h, f, Delta, alpha, p_h);
                 } else {  // one unknown: the "SVD" is a column norm
-                    double q[2] = {sqrt(diag_h[0]), 0.0}, s[2], V[2][2], uf[2];
+                    double q[2] = {sqrt_(diag_h[0]), 0.0}, s[2], V[2][2], uf[2];
                     svd_active<1>(Jh, q, f, s, V, uf);
                     solve_lsq_trust_region<1, false>(uf, s, V, Delta, alpha, p_h);
                 }
@@ -1263,7 +1322,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double cost_new = 0.5 * dot3(f_new, f_new);
                 double actual_reduction = cost - cost_new;
                 double ratio;
-                if (predicted_reduction > 0) ratio = actual_reduction / predicted_reduction;
+                if (predicted_reduction > 0) ratio = div_(actual_reduction, predicted_reduction);
                 else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
                 else ratio = 0;
                 double Delta_new = Delta;
@@ -1275,14 +1334,14 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 xn = fma_(x[0], x[0], xn);
                 if constexpr (NA == 2) xn = fma_(x[1], x[1], xn);
                 xn = fma_(sc.x_suf, sc.x_suf, xn);
-                xn = sqrt(xn);
+                xn = sqrt_(xn);
                 bool ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
                 bool xtol_ok = step_norm < xtol * (xtol + xn);
                 if (ftol_ok && xtol_ok) status = 4;
                 else if (ftol_ok) status = 2;
                 else if (xtol_ok) status = 3;
                 if (status == STATUS_NONE) {
-                    alpha = alpha * (Delta / Delta_new);
+                    alpha = alpha * div_(Delta, Delta_new);
                     Delta = Delta_new;
                 }
                 if (actual_reduction > 0) {

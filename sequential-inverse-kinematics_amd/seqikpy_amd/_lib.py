@@ -114,6 +114,20 @@ def _hipcc():
     return "hipcc"
 
 
+KERNEL_SOURCES = ["seqik_core.hpp", "seqik_consts.hpp", "seqik_hip.hip"]   # what the solver kernels are compiled from
+
+
+def csrc_sha256(files=None) -> str:
+    """sha256 over the solver kernels' sources (in ``KERNEL_SOURCES`` order): ties a committed PMC summary
+    (profiles/traffic_rNN.json, written by scripts/summarize_profile.py) to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in (files or KERNEL_SOURCES):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True

@@ -11,6 +11,15 @@ import torch.multiprocessing as mp
 from conftest import PKG_PARENT, ROOT, load_golden
 
 
+def free_port():
+    """A rendezvous port nobody is listening on right now (fixed, pid-derived ports collided with sockets of earlier
+    tests now and then)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def _worker(rank, world, port, out_dir):
     for p in (PKG_PARENT, ROOT):
         if p not in sys.path:
@@ -55,7 +64,7 @@ def test_partition_is_balanced_and_complete():
 
 @pytest.mark.timeout(300)
 def test_two_rank_sharded_solve_equals_single_process(tmp_path):
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     single = np.load(tmp_path / "single.npy")
     for r in range(2):
@@ -97,7 +106,7 @@ def _pipeline_worker(rank, world, port, out_dir):
 def test_gather_pipeline_double_buffering(tmp_path, world):
     """Rank 0 posts one receive per peer and step (grouped point-to-point), the peers one send each; buffers
     alternate; what rank 0 sees for step s is every rank's block of step s."""
-    port = 31500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     seen = np.load(tmp_path / "seen.npy")
     assert np.array_equal(seen, np.array([[100.0 * s + r for r in range(world)] for s in range(5)]))
@@ -183,7 +192,7 @@ def test_one_recording_sharded_by_frame_over_ranks(tmp_path, oracle, world):
     result bit for bit; with tol = 0 every boundary is repaired from the true state and the result is the serial walk,
     bit for bit; every rank ends up with the whole recording."""
     from chunk_model import chunked_oracle
-    port = 33500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_frame_shard_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
     legs = ["RF", "LM", "RH"]
@@ -224,7 +233,7 @@ def test_gather_pipeline_on_rccl_single_rank(hiplib, kind):
     pose = np.stack([np.stack([z[f"{l}_pose"][k * T:(k + 1) * T] for l in legs]) for k in range(4)])  # (4, 6, T, 5, 3)
     want = hiplib.solve_seq(pose, params, want_fk=False)["angles"]
     opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-    port = 29541 if kind == "peer writes" else 29542
+    port = free_port()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0), pg_options=opts)
     try:
@@ -302,7 +311,7 @@ def test_peer_write_gather_between_processes(tmp_path):
     block per step with seqik_peer_copy; the 8-byte all-reduce (gloo here, RCCL on a node) is the completion flag.
     What rank 0 sees for step s is every rank's block of step s, whole (min == max == 100 s + rank)."""
     world = 3
-    port = 31900 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_peer_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     seen = np.load(tmp_path / "seen.npy")
     want = np.array([[100.0 * s + r for r in range(world)] * 2 for s in range(7)])
@@ -358,7 +367,7 @@ def test_strong_scaling_shares_tile_the_fixed_problem(tmp_path, world):
     assert [rank_share(10, 4, r, "strong")[:2] for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
     with pytest.raises(ValueError):
         rank_share(10, 2, 0, "sideways")
-    port = 33500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert np.array_equal(np.load(tmp_path / "gathered.npy"), np.load(tmp_path / "single.npy"))
     u = np.load(tmp_path / "units.npy")
@@ -374,7 +383,7 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(tmp_path):
     import subprocess
     env = dict(os.environ, SEQIK_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(34500 + os.getpid() % 1000), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "1", "--scaling", "strong", "--frames", "8192", "--no-cpu-baseline"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
@@ -465,7 +474,7 @@ def test_one_recording_sharded_by_frame_on_the_gpu_equals_one_rank(tmp_path, hip
     """Round-2 review item 4: ONE recording (df3d x 50 = 50 000 frames x 6 legs), frame-sharded over 2 / 3 ranks that
     hand their slabs to the library's frame chunks (frame_lead, chunk_states, chunk_resume), == the one-rank chunked
     call with the same geometry, bit for bit -- angles and FK, on every rank."""
-    port = 35500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_frame_shard_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     z = load_golden("df3d_1000")
     legs = [str(l) for l in z["legs"]]
