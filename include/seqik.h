@@ -144,7 +144,9 @@ typedef struct SeqikOptions {
     int32_t chunk_resume; /* 1: no speculative pass -- d_angles / d_fk / chunk_states hold the result of an earlier call
                              with the same geometry, d_init_angles the TRUE state in front of chunk 0; only
                              verification, repair rounds and sweep run (chunk 0 included).  Needs an explicit
-                             frame_chunk > 0 and chunk_states */
+                             frame_chunk > 0 and chunk_states.  2: as 1, and chunk 0 is accepted only if its run-in
+                             reproduced d_init_angles bit for bit (otherwise re-solved from it): the slab then continues
+                             the frames in front of it EXACTLY, like a carried slab of a stream */
     int32_t pad2_;
 } SeqikOptions;
 
@@ -319,6 +321,8 @@ int seqik_peer_copy(void *d_dst, const void *d_src, size_t bytes, void *hip_stre
  *                        (or until n_slots further slabs have been submitted).
  *   seqik_stream_wait    blocks until every submitted slab's results are in its host buffers
  *   seqik_stream_reset_carry   the next slab starts new recordings (frame 0 from the seeds again)
+ *   seqik_stream_set_carry     the next slab continues from a given state (a recording whose earlier frames were
+ *                        solved elsewhere: another GPU, another call)
  *   seqik_stream_close   drains and frees everything
  */
 typedef struct SeqikStream SeqikStream;
@@ -332,6 +336,9 @@ int seqik_stream_open(SeqikStream **out, int32_t n_legs, const SeqikLegParams *l
 int seqik_stream_submit(SeqikStream *s, const double *pose, int64_t n_seq, double *angles, double *fk);
 int seqik_stream_wait(SeqikStream *s);
 int seqik_stream_reset_carry(SeqikStream *s);
+/* carried streams: the next slab is warm-started from `init` [n_seq][n_legs][7] (the joint angles of the frame in front of
+ * it; host memory, or device memory of the stream's GPU when on_device != 0) instead of the seeds / the slab before */
+int seqik_stream_set_carry(SeqikStream *s, const double *init, int64_t n_seq, int32_t on_device);
 int seqik_stream_close(SeqikStream *s);
 
 /*

@@ -106,6 +106,62 @@ SEQIK_HD double sqrt_(double x)
 enum : int { STATUS_NONE = -99 };
 
 // ---------------------------------------------------------------------------
+// DIAGNOSTIC BUILD ONLY (-DSEQIK_BLOCK_CYCLES=1, scripts/block_cycles.py): where a wavefront's time goes inside run_stage.
+// A stamp (s_memtime, shader clock) at every block boundary; the cycles since the previous stamp are charged to the
+// block that just ended -- WAVE time, whatever the number of active lanes, which is what a pass costs.  Per-wave sums
+// are added to seqik_block_cycles[stage - 1][block] when the stage ends.  The product build has none of this.
+// ---------------------------------------------------------------------------
+#ifndef SEQIK_BLOCK_CYCLES
+#define SEQIK_BLOCK_CYCLES 0
+#endif
+enum : int { BLK_LOOP = 0, BLK_NEW_SOLVE, BLK_FD_JACOBIAN, BLK_SCALING, BLK_TR_STEP, BLK_IN_BOUNDS, BLK_REFLECTIVE,
+             BLK_TRIAL_EVAL, BLK_POST_TRIAL, BLK_FINISHED, BLK_PIPE_WAIT, BLK_COUNT };
+#if SEQIK_BLOCK_CYCLES && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long seqik_block_cycles[4][BLK_COUNT + 1];  // [..][BLK_COUNT] = passes (wave level)
+// (every stamp names the block that ENDS there, so each accumulator is indexed by a constant and lives in scalar
+// registers: an array indexed by a "current block" variable went to scratch memory, and the s_waitcnt vmcnt(0) of its
+// read-modify-write then charged the drain of the stores just issued to whatever stamp came next)
+struct BlockClock {
+    unsigned long long acc[BLK_COUNT];
+    unsigned long long last, passes;
+    __device__ __forceinline__ void start()
+    {
+#pragma unroll
+        for (int i = 0; i < BLK_COUNT; ++i) acc[i] = 0;
+        passes = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    template <int BLK>
+    __device__ __forceinline__ void end_of()
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[BLK] += now - last;
+        last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void finish(int stage)
+    {
+        end_of<BLK_LOOP>();
+        if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)__ballot(1)) - 1) {
+#pragma unroll
+            for (int i = 0; i < BLK_COUNT; ++i) atomicAdd(&seqik_block_cycles[stage - 1][i], acc[i]);
+            atomicAdd(&seqik_block_cycles[stage - 1][BLK_COUNT], passes);
+        }
+    }
+};
+#define SEQIK_BLK_DECL BlockClock blk_clock; blk_clock.start();
+#define SEQIK_BLK_END_OF(b) blk_clock.end_of<b>()
+#define SEQIK_BLK_PASS() (blk_clock.passes += 1)
+#define SEQIK_BLK_END(stage) blk_clock.finish(stage)
+#else
+#define SEQIK_BLK_DECL
+#define SEQIK_BLK_END_OF(b) ((void)0)
+#define SEQIK_BLK_PASS() ((void)0)
+#define SEQIK_BLK_END(stage) ((void)0)
+#endif
+
+// ---------------------------------------------------------------------------
 // Per-(leg, stage) constants, built on the host by make_leg_consts().
 // ---------------------------------------------------------------------------
 struct StageConst {
@@ -1134,7 +1190,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // (Tried and dropped: keeping finished lanes in the loop and letting all 64 lanes execute a burst of dummy
     // multiply-adds per pass while fewer than 16 lanes are still working, to keep the wave out of the slow sparse-EXEC
     // mode of scripts/microbench/exec_*.hip during the end-of-stage tail: 14.2 -> 15.0 ms per benchmark step.)
+    SEQIK_BLK_DECL
     while (t < io.n_frames) {
+        SEQIK_BLK_PASS();
+        SEQIK_BLK_END_OF(BLK_LOOP);
         if constexpr (PIPED) {
             // may this lane start frame t?  (only asked at a frame boundary; a lane in the middle of a solve runs on)
             bool stall = false;
@@ -1167,6 +1226,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             }
             pipe_spins = 0;
         }
+        if constexpr (PIPED) SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
         if (new_solve) {
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + STAGE * io.pose_row;
@@ -1242,11 +1302,13 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         }
 
         bool finished = false;
+        SEQIK_BLK_END_OF(BLK_NEW_SOLVE);
         if (WANT_DIAG || status == STATUS_NONE) {
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
             double J[3][2], g[2], v[2], dv[2];
             if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
             else fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
+            SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], J[0][j] * f[0]));
@@ -1293,6 +1355,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 // and the SVD are unchanged, so re-deriving them at the top of the next pass gives
                 // bit-identical values, and no lane ever makes the other 63 wait in an inner loop.
                 double p_h[2], p[2], step[2], step_h[2];
+                SEQIK_BLK_END_OF(BLK_SCALING);
                 if constexpr (NA == 2) {
                     solve_tr_2x2<T::DEFICIENT>(Jh, diag_h, f, Delta, alpha, p_h);
                 } else {  // one unknown: the "SVD" is a column norm
@@ -1300,6 +1363,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     svd_active<1>(Jh, q, f, s, V, uf);
                     solve_lsq_trust_region<1, false>(uf, s, V, Delta, alpha, p_h);
                 }
+                SEQIK_BLK_END_OF(BLK_TR_STEP);
                 p[0] = d[0] * p_h[0]; p[1] = d[1] * p_h[1];
                 double predicted_reduction;
                 double xp[2] = {x[0] + p[0], x[1] + p[1]};
@@ -1307,9 +1371,12 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     predicted_reduction = -evaluate_quadratic<NA>(Jh, g_h, p_h, diag_h);
                     step[0] = p[0]; step[1] = p[1]; step_h[0] = p_h[0]; step_h[1] = p_h[1];
                 } else {
+                    SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                     predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
                                                                      theta, step, step_h);
+                    SEQIK_BLK_END_OF(BLK_REFLECTIVE);
                 }
+                SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                 double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n, pe_n[3] = {0.0, 0.0, 0.0};
                 x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
                 if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);
@@ -1318,6 +1385,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 else
                     eval_residual<STAGE>(P, x_new[0], x_new[1], f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
                 nfev += 1;
+                SEQIK_BLK_END_OF(BLK_TRIAL_EVAL);
                 double step_h_norm = norm2v<NA>(step_h);
                 double cost_new = 0.5 * dot3(f_new, f_new);
                 double actual_reduction = cost - cost_new;
@@ -1357,10 +1425,14 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             finished = true;
         }
 
+        SEQIK_BLK_END_OF(BLK_POST_TRIAL);
         if (finished) {
             // ---- solve done: store, advance to the next frame -------------------------------
             const bool stored = !CHUNKED || t >= io.t_store;  // run-in frames leave nothing but the hand-off
-            if (stored) {
+#ifndef SEQIK_WHATIF_NO_STORES   // (timing experiments only: 1 = stage 1 stores nothing; results are garbage)
+#define SEQIK_WHATIF_NO_STORES 0
+#endif
+            if (stored && !(SEQIK_WHATIF_NO_STORES && STAGE == 1)) {
                 double *ang = io.angles + t * io.ang_frame;
                 ang[DOF0 * io.ang_dof] = x[0];
                 if constexpr (NA == 2) ang[(DOF0 + 1) * io.ang_dof] = x[1];
@@ -1383,7 +1455,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) w[(9 + i) * io.pipe.lane_stride] = after.t[i];
                     pipe_store(io.pipe.produced_out, fi + 1);
-                } else if constexpr (HANDOFF) {
+                } else if constexpr (HANDOFF && !(SEQIK_WHATIF_NO_STORES && STAGE == 1)) {
                     double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) w[i] = after.r[i];
@@ -1422,7 +1494,26 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             t += 1;
             new_solve = true;
         }
+        SEQIK_BLK_END_OF(BLK_FINISHED);
+#if SEQIK_BLOCK_CYCLES == 2   // experiment: what does a stamp right behind a stamp cost?
+        if constexpr (!PIPED) SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
+#endif
+#if SEQIK_BLOCK_CYCLES >= 3 && defined(__HIP_DEVICE_COMPILE__)
+        // experiment: a short stretch of code that only SEQIK_BLOCK_CYCLES lanes execute (a handful of dependent
+        // multiply-adds), in front of the reconvergence at the loop edge -- with the replicated workload, where nothing
+        // else diverges, this isolates what a sparse-EXEC stretch costs the wave
+        if constexpr (!PIPED) {
+            if ((int)(threadIdx.x & 63) < SEQIK_BLOCK_CYCLES) {
+                double dummy = cost;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(dummy));
+                asm volatile("" ::"v"(dummy));
+            }
+            SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
+        }
+#endif
     }
+    SEQIK_BLK_END(STAGE);
 }
 
 }  // namespace seqik

@@ -60,7 +60,7 @@ SEQIK_HD double vnorm7(const double *a)
 {
     double acc = 0.0;
     for (int i = 0; i < GN; ++i) acc = fma_(a[i], a[i], acc);
-    return sqrt(acc);
+    return sqrt_(acc);
 }
 
 SEQIK_HD double vdot7(const double *a, const double *b)
@@ -134,7 +134,7 @@ SEQIK_HD double pick7(const double *a, int j)  // a[j] without indexing a regist
 // ---------------------------------------------------------------------------
 // Trust-region step without an SVD (mirrors oracle solve_tr_woodbury operation for operation).
 //
-// scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt(diag_h))]] (10 x 7).  All it needs from
+// scipy's solve_lsq_trust_region works on the SVD of A = [[J_h], [diag(sqrt_(diag_h))]] (10 x 7).  All it needs from
 // it is p(alpha) = -(A^T A + alpha I)^-1 J_h^T f, ||p|| and phi'(alpha) = -p^T (A^T A + alpha I)^-1 p / ||p||.  With
 // B = diag(diag_h + alpha), W = B^-1 and A^T A = diag(diag_h) + J_h^T J_h the push-through identity gives
 //     (B + J_h^T J_h)^-1 r = W r - W J_h^T (I_3 + J_h W J_h^T)^-1 J_h W r,
@@ -154,7 +154,7 @@ SEQIK_HD void sym3_inverse(const double *m /* 00 01 02 11 12 22 */, double *inv)
     double c12 = fma_(m[1], m[2], -(m[0] * m[4]));
     double c22 = fma_(m[0], m[3], -(m[1] * m[1]));
     double det = fma_(m[2], c02, fma_(m[1], c01, m[0] * c00));
-    double r = 1.0 / det;
+    double r = div_(1.0, det);
     inv[0] = c00 * r; inv[1] = c01 * r; inv[2] = c02 * r; inv[3] = c11 * r; inv[4] = c12 * r; inv[5] = c22 * r;
 }
 
@@ -189,10 +189,10 @@ SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const d
 {
     double W[GN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6];
     if (jm >= 0) {
-        group8_gather(1.0 / (pick7(diag_h, jm) + alpha), W);
+        group8_gather(div_(1.0, pick7(diag_h, jm) + alpha), W);
     } else {
 #pragma unroll
-        for (int c = 0; c < GN; ++c) W[c] = 1.0 / (diag_h[c] + alpha);
+        for (int c = 0; c < GN; ++c) W[c] = div_(1.0, diag_h[c] + alpha);
     }
 #pragma unroll
     for (int c = 0; c < GN; ++c) {
@@ -208,7 +208,7 @@ SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const d
         woodbury_solve(Jh, W, Minv, pp, q);
         double acc = vdot7(pp, q);
         phi = p_norm - Delta;
-        ratio = -(phi * p_norm) / acc;
+        ratio = div_(-(phi * p_norm), acc);
     }
 }
 
@@ -219,11 +219,11 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
     double rhs[GN], pp[GN];
 #pragma unroll
     for (int c = 0; c < GN; ++c) rhs[c] = fma_(Jh[2][c], f[2], fma_(Jh[1][c], f[1], Jh[0][c] * f[0]));
-    const double inv_Delta = 1.0 / Delta;
+    const double inv_Delta = div_(1.0, Delta);
     double alpha_upper = vnorm7(rhs) * inv_Delta;
     double alpha_lower = 0.0;
     double alpha = alpha_io;
-    if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (alpha == 0.0) alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
     // shortcut of the m < n root search (see seqik_core.hpp solve_tr_2x2 / oracle solve_tr_2x2): Gauss-Newton step
     // inside the trust region = ten resets alpha <- 0.001 alpha_upper + one Newton step from the last alpha
     bool shortcut = false;
@@ -244,7 +244,7 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
     }
     for (int it = 0; it < 10 && !shortcut; ++it) {
         if (alpha < alpha_lower || alpha > alpha_upper)
-            alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+            alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
         double phi, ratio;
         woodbury_phi<true>(Jh, diag_h, rhs, alpha, Delta, pp, phi, ratio, jm);
         if (phi < 0) alpha_upper = alpha;
@@ -254,7 +254,7 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
     }
     double unused_phi, unused_ratio;
     woodbury_phi<false>(Jh, diag_h, rhs, alpha, Delta, pp, unused_phi, unused_ratio, jm);
-    double scale = Delta / vnorm7(pp);
+    double scale = div_(Delta, vnorm7(pp));
 #pragma unroll
     for (int c = 0; c < GN; ++c) p[c] = -(pp[c] * scale);
     alpha_io = alpha;
@@ -268,7 +268,7 @@ SEQIK_HD double step_size_to_bound7(const double *x, const double *s, const doub
     for (int i = 0; i < GN; ++i) {
         steps[i] = INF;
         if (s[i] != 0.0) {
-            double inv_s = 1.0 / s[i];
+            double inv_s = div_(1.0, s[i]);
             steps[i] = fmax((lb[i] - x[i]) * inv_s, (ub[i] - x[i]) * inv_s);
         }
         if (steps[i] < min_step) min_step = steps[i];
@@ -324,17 +324,17 @@ SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const doub
         double a = vdot7(r_h, r_h);
         double b = vdot7(p_h, r_h);
         double c = fma_(-Delta, Delta, vdot7(p_h, p_h));
-        double dd = sqrt(fma_(b, b, -(a * c)));
+        double dd = sqrt_(fma_(b, b, -(a * c)));
         double q = -(b + copysign(dd, b));
-        double t1 = q / a;
-        double t2 = c / q;
+        double t1 = div_(q, a);
+        double t2 = div_(c, q);
         to_tr = (t1 < t2) ? t2 : t1;
     }
     double to_bound = step_size_to_bound7(x_on_bound, r, lb, ub, nullptr);
     double r_stride = fmin(to_bound, to_tr);
     double r_stride_l, r_stride_u;
     if (r_stride > 0) {
-        r_stride_l = (1 - theta) * p_stride / r_stride;
+        r_stride_l = div_((1 - theta) * p_stride, r_stride);
         r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
     } else {
         r_stride_l = 0;
@@ -367,7 +367,7 @@ SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const doub
 
     double ag_h[GN], ag[GN];
     for (int i = 0; i < GN; ++i) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
-    to_tr = Delta / vnorm7(ag_h);
+    to_tr = div_(Delta, vnorm7(ag_h));
     to_bound = step_size_to_bound7(x, ag, lb, ub, nullptr);
     double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
     double ag_value;
@@ -471,7 +471,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
 #pragma unroll
                 for (int i = 0; i < GN; ++i) { sp[i] = (i == jm) ? s1 : sn[i]; cp[i] = (i == jm) ? c1 : cs[i]; }
                 generic_residual(gc, sp, cp, target, f1);
-                double inv_dx = 1.0 / dx;
+                double inv_dx = div_(1.0, dx);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) group8_gather((f1[k] - f[k]) * inv_dx, J[k]);
             } else {
@@ -483,7 +483,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                     sincos_cw(x1, sn[j], cs[j]);
                     generic_residual(gc, sn, cs, target, f1);
                     sn[j] = s_keep; cs[j] = c_keep;
-                    double inv_dx = 1.0 / dx;
+                    double inv_dx = div_(1.0, dx);
                     for (int k = 0; k < 3; ++k) J[k][j] = (f1[k] - f[k]) * inv_dx;
                 }
             }
@@ -493,9 +493,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             }
             if (first_pass) {
                 double acc = gc.x_pre_sq;
-                for (int j = 0; j < GN; ++j) { double tj = x[j] / sqrt(v[j]); acc = fma_(tj, tj, acc); }
+                for (int j = 0; j < GN; ++j) { double tj = div_(x[j], sqrt_(v[j])); acc = fma_(tj, tj, acc); }
                 acc = fma_(gc.x_suf, gc.x_suf, acc);
-                Delta = sqrt(acc);
+                Delta = sqrt_(acc);
                 if (Delta == 0) Delta = 1.0;
                 first_pass = false;
             }
@@ -507,9 +507,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 finished = true;
             } else {
                 double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
-                if constexpr (GROUPED) group8_gather(sqrt(pick7(v, jm)) * 1.0, d);
+                if constexpr (GROUPED) group8_gather(sqrt_(pick7(v, jm)) * 1.0, d);
                 for (int j = 0; j < GN; ++j) {
-                    if constexpr (!GROUPED) d[j] = sqrt(v[j]) * 1.0;
+                    if constexpr (!GROUPED) d[j] = sqrt_(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
                 }
@@ -539,7 +539,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double cost_new = 0.5 * dot3(f_new, f_new);
                 double actual_reduction = cost - cost_new;
                 double ratio;
-                if (predicted_reduction > 0) ratio = actual_reduction / predicted_reduction;
+                if (predicted_reduction > 0) ratio = div_(actual_reduction, predicted_reduction);
                 else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
                 else ratio = 0;
                 double Delta_new = Delta;
@@ -549,14 +549,14 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double xn = gc.x_pre_sq;
                 for (int j = 0; j < GN; ++j) xn = fma_(x[j], x[j], xn);
                 xn = fma_(gc.x_suf, gc.x_suf, xn);
-                xn = sqrt(xn);
+                xn = sqrt_(xn);
                 bool ftol_ok = (actual_reduction < ftol * cost) && (ratio > 0.25);
                 bool xtol_ok = step_norm < xtol * (xtol + xn);
                 if (ftol_ok && xtol_ok) status = 4;
                 else if (ftol_ok) status = 2;
                 else if (xtol_ok) status = 3;
                 if (status == STATUS_NONE) {
-                    alpha = alpha * (Delta / Delta_new);
+                    alpha = alpha * div_(Delta, Delta_new);
                     Delta = Delta_new;
                 }
                 if (actual_reduction > 0) {

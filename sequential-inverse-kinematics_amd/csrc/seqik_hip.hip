@@ -12,6 +12,21 @@
 #include "seqik_device_scope.hpp"
 #include "seqik_hostctx.hpp"
 
+#if SEQIK_BLOCK_CYCLES
+namespace seqik { __device__ unsigned long long seqik_block_cycles[4][BLK_COUNT + 1]; }
+// diagnostic builds only (scripts/block_cycles.py): copies the counters out (and zeroes them)
+extern "C" int seqik_debug_block_cycles(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(seqik::seqik_block_cycles), sizeof(unsigned long long) * 4 * (seqik::BLK_COUNT + 1)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zero[4 * (seqik::BLK_COUNT + 1)] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(seqik::seqik_block_cycles), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 namespace {
 
 constexpr int kMaxLegs = 8;   // LegConst table staged in LDS (a fly has 6 legs)
@@ -434,9 +449,12 @@ __device__ __forceinline__ bool chunk_inconsistent(const KernelArgs &a, const Ch
     const double *ss = ca.start_state + (c * ca.n_chunks + k) * 7;
     bool bad = false;
     if (k == 0) {
+        // chunk_resume = 2: the first chunk is an EXACT continuation (as a carried slab of a stream): anything but the
+        // caller's state bit for bit counts as inconsistent, so it is re-solved from it once
         const double *init = a.init + c * 7;
+        const double tol0 = (ca.resume == 2) ? 0.0 : ca.tol;
 #pragma unroll
-        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - init[d]) <= ca.tol);
+        for (int d = 0; d < 7; ++d) bad |= !(fabs(ss[d] - init[d]) <= tol0);
     } else {
         const double *ang = a.angles + c * a.ang_chain + (ca.lead + k * ca.chunk - 1) * a.ang_frame;
 #pragma unroll
@@ -1113,7 +1131,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         ca.flags = opt->chunk_flags;
         ca.round = 0;
         const bool resume = opt->chunk_resume != 0;
-        ca.resume = resume ? 1 : 0;
+        ca.resume = resume ? (opt->chunk_resume == 2 ? 2 : 1) : 0;
         if (resume && !opt->chunk_states)
             return fail(SEQIK_ERR_BAD_ARG, "chunk_resume needs the chunk_states of the call it resumes%s");
         // chunk 0 is verified (and repaired) like the others when it started from a run-in and the caller says what the

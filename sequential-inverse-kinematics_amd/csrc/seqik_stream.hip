@@ -291,6 +291,22 @@ int seqik_stream_reset_carry(SeqikStream *s)
     return SEQIK_OK;
 }
 
+int seqik_stream_set_carry(SeqikStream *s, const double *init, int64_t n_seq, int32_t on_device)
+{
+    if (!s || !init) return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_set_carry: null pointer");
+    if (!s->carry) return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_set_carry: the stream was not opened with carry");
+    if (n_seq <= 0 || n_seq > s->slab_seq) return s_fail(SEQIK_ERR_BAD_ARG, "seqik_stream_set_carry: n_seq exceeds the slab size");
+    seqik::DeviceScope scope;
+    STRY(scope.enter(s->device));
+    // ordered on the compute stream: behind the slab before (whose carry kernel writes the same buffer), in front of the next
+    STRY(hipMemcpyAsync(s->d_init, init, sizeof(double) * 7 * n_seq * s->n_legs,
+                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->compute[0]));
+    if (!on_device) STRY(hipStreamSynchronize(s->compute[0]));  // the caller's host buffer may go away
+    s->have_init = true;
+    s->carry_seq = n_seq;
+    return SEQIK_OK;
+}
+
 int seqik_stream_close(SeqikStream *s)
 {
     destroy(s);

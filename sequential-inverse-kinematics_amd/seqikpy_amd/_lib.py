@@ -232,6 +232,8 @@ def load():
         L.seqik_stream_submit.restype = ctypes.c_int
         L.seqik_stream_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                           ctypes.c_void_p]
+        L.seqik_stream_set_carry.restype = ctypes.c_int
+        L.seqik_stream_set_carry.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
         for name in ("seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close"):
             getattr(L, name).restype = ctypes.c_int
             getattr(L, name).argtypes = [ctypes.c_void_p]
@@ -258,7 +260,7 @@ EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
                     "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
-                    "seqik_stream_open", "seqik_stream_submit", "seqik_stream_wait", "seqik_stream_reset_carry",
+                    "seqik_stream_open", "seqik_stream_submit", "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry",
                     "seqik_stream_close", "seqik_align_stats_open", "seqik_align_stats_add",
                     "seqik_align_stats_finish", "seqik_align_stats_reset", "seqik_align_stats_close"]
 

@@ -58,10 +58,14 @@ class DeviceSlab:
     """A rank's slab on its GPU: key points, angles, FK and chunk start states stay in HBM between the calls."""
 
     def __init__(self, pose_slab: np.ndarray, legs: List, chunk: int, halo: int, tol: float, lead: int, want_fk: bool,
-                 affine=None, device: int = -1):
+                 affine=None, device: int = -1, planar: bool = False):
+        """``pose_slab`` (S, L, n, 5, 3), or with ``planar`` (S, L, 5, n, 3) (the device layout: no transpose)."""
         import torch
         self.torch = torch
-        self.S, self.L, self.n = pose_slab.shape[:3]
+        if planar:
+            self.S, self.L, _, self.n = pose_slab.shape[:4]
+        else:
+            self.S, self.L, self.n = pose_slab.shape[:3]
         self.legs, self.lead, self.want_fk, self.affine = legs, int(lead), want_fk, affine
         self.kw = dict(frame_chunk=int(chunk), frame_halo=int(halo), chunk_tol=float(tol) if tol > 0 else -1.0)
         self.dev = torch.device("cuda", torch.cuda.current_device() if device is None or device < 0 else device)
@@ -69,7 +73,8 @@ class DeviceSlab:
         # planar device layout (include/seqik.h, SeqikLayout): every key-point row and every joint is its own time series
         self.layout = _lib.planar_layout(self.n)
         with torch.cuda.device(self.dev):
-            self.d_pose = torch.from_numpy(np.ascontiguousarray(pose_slab.transpose(0, 1, 3, 2, 4))).to(self.dev)  # [S][L][5][n][3]
+            host = pose_slab if planar else pose_slab.transpose(0, 1, 3, 2, 4)
+            self.d_pose = torch.from_numpy(np.ascontiguousarray(host)).to(self.dev)                               # [S][L][5][n][3]
             self.d_ang = torch.zeros((self.S, self.L, 7, self.n), dtype=torch.float64, device=self.dev)           # [S][L][7][n]
             self.d_fk = torch.zeros((self.S, self.L, self.n, 9, 3), dtype=torch.float64, device=self.dev) if want_fk else None
             self.d_states = torch.zeros((self.S, self.L, self.K, 7), dtype=torch.float64, device=self.dev)
@@ -89,12 +94,13 @@ class DeviceSlab:
     def speculate(self):
         self._call()
 
-    def resume(self, left_state):
-        """``left_state`` (S, L, 7): the true state of the frame in front of the slab (device tensor)."""
+    def resume(self, left_state, exact: bool = False):
+        """``left_state`` (S, L, 7): the true state of the frame in front of the slab (device tensor).  ``exact``: the
+        first chunk must continue that state bit for bit (``chunk_resume = 2``), as a carried slab of a stream does."""
         if not self.chunked:   # (only a slab that IS the whole, short recording is walked serially; it has no left neighbour)
             raise RuntimeError("a serially walked slab cannot be resumed")
         self._left = left_state.to(self.dev).contiguous()
-        self._call(d_init=self._left.data_ptr(), resume=1)
+        self._call(d_init=self._left.data_ptr(), resume=2 if exact else 1)
         st = self.d_stats.cpu().numpy()
         self.repaired += int(st[3:7].sum())
 

@@ -127,6 +127,22 @@ class SeqikStream:
     def reset_carry(self):
         self._lib.seqik_stream_reset_carry(self._handle)
 
+    def set_carry(self, state, on_device: bool = False):
+        """Carried streams: the next slab continues from ``state`` (n_seq, n_legs, 7) -- a numpy array, or (with
+        ``on_device``) a raw device pointer / an object with ``data_ptr()`` on the stream's GPU together with
+        ``n_seq`` as ``state = (ptr, n_seq)``."""
+        if on_device:
+            ptr, n_seq = state
+            ptr = int(ptr.data_ptr()) if hasattr(ptr, "data_ptr") else int(ptr)
+            rc = self._lib.seqik_stream_set_carry(self._handle, ctypes.c_void_p(ptr), int(n_seq), 1)
+        else:
+            arr = np.ascontiguousarray(state, dtype=np.float64)
+            if arr.ndim != 3 or arr.shape[1:] != (self.n_legs, 7):
+                raise ValueError(f"state must have shape (n_seq, {self.n_legs}, 7)")
+            rc = self._lib.seqik_stream_set_carry(self._handle, ctypes.c_void_p(arr.ctypes.data), arr.shape[0], 0)
+        if rc != _lib.SEQIK_OK:
+            _lib._raise(rc)
+
     def close(self):
         if self._handle:
             self._lib.seqik_stream_close(self._handle)

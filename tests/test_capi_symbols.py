@@ -28,7 +28,7 @@ def test_header_declares_expected_entry_points():
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
                                            "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_stream_open", "seqik_stream_submit",
-                                           "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_close",
+                                           "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry", "seqik_stream_close",
                                            "seqik_align_stats_open", "seqik_align_stats_add", "seqik_align_stats_finish",
                                            "seqik_align_stats_reset", "seqik_align_stats_close"])
 

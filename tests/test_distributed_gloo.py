@@ -513,3 +513,73 @@ def test_bench_one_recording_frame_sharded_over_two_ranks(tmp_path):
     assert b["check"]["first_chunk_equals_serial_bit_for_bit"] and b["check"]["max_abs_vs_serial"] < 2e-5
     assert b["check"]["max_abs_vs_reference_first_1000_frames"] < 1e-4
     assert abs(b["value"] - 40000 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+
+
+def _config5_case():
+    """A recording of 4000 frames x 6 legs (the df3d fixture repeated) as RAW key points through a made-up camera frame,
+    in 8 pinned-style planar slabs of 500 frames, + the fused-alignment constants (scripts/stream_config5.py)."""
+    from seqikpy_amd import _lib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    L, T, n_slabs = len(legs), 500, 8
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    rng = np.random.default_rng(5)
+    scales, fixed = 1.0 + 0.4 * rng.random(L), rng.normal(0.0, 2.0, (L, 3))
+    base = np.stack([z[f"{l}_pose"] for l in legs])
+    al = np.tile(base, (1, 4, 1, 1))                                               # (L, 4000, 5, 3)
+    tcs = [base[i, 0, 0].copy() for i in range(L)]
+    affs = [_lib.make_affine(fixed[i], scales[i], tcs[i]) for i in range(L)]
+    raw = np.stack([(al[i] - tcs[i]) / scales[i] + fixed[i] for i in range(L)])    # (L, 4000, 5, 3)
+    slabs = [np.ascontiguousarray(raw[None, :, k * T:(k + 1) * T].transpose(0, 1, 3, 2, 4)) for k in range(n_slabs)]
+    return params, affs, slabs, T, L, n_slabs
+
+
+def _config5_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from seqikpy_amd import stream_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    params, affs, slabs, T, L, n_slabs = _config5_case()
+    outs = [(np.zeros((1, L, 7, T)), np.zeros((1, L, T, 9, 3))) for _ in range(n_slabs)]
+    st = {}
+    k0, k1 = stream_sharding.stream_recording_sharded(lambda k: slabs[k], lambda k: outs[k], n_slabs, T, params, affine=affs,
+                                                      want_fk=True, stats=st)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), span=np.array([k0, k1]), rounds=st["boundary_rounds"], restreams=st["restreams"],
+             angles=np.stack([outs[k][0] for k in range(k0, k1)]), fk=np.stack([outs[k][1] for k in range(k0, k1)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_config5_one_recording_streamed_over_ranks_equals_single_process_stream(tmp_path, hiplib, world):
+    """Round-2 review item 6: config 5 on N ranks -- rank r streams its contiguous slabs of ONE recording from host
+    buffers (carried warm start inside the rank, the first slab settled against the left neighbour's true end state) ==
+    the single-process carried stream over all slabs, bit for bit (angles and FK), RAW key points with fused alignment."""
+    from seqikpy_amd.streaming import SeqikStream
+    params, affs, slabs, T, L, n_slabs = _config5_case()
+    c, h, _ = hiplib.frame_chunk_plan(T)
+    ref = [(np.zeros((1, L, 7, T)), np.zeros((1, L, T, 9, 3))) for _ in range(n_slabs)]
+    with SeqikStream(params, 1, T, affine=affs, layout=hiplib.planar_layout(T), want_fk=True, carry=True, frame_chunk=c,
+                     frame_halo=h) as st:
+        for k in range(n_slabs):
+            st.submit(slabs[k], ref[k][0], ref[k][1])
+        st.wait()
+    mp.spawn(_config5_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    seen = 0
+    for r in range(world):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        k0, k1 = got["span"]
+        assert int(got["rounds"]) == 0 and int(got["restreams"]) == 0
+        for i, k in enumerate(range(k0, k1)):
+            assert np.array_equal(got["angles"][i], ref[k][0]), (r, k)
+            assert np.array_equal(got["fk"][i], ref[k][1]), (r, k)
+            seen += 1
+    assert seen == n_slabs
