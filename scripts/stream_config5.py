@@ -20,6 +20,39 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def launch_ranks_if_needed(argv):
+    """`--gpus N` without a rank environment: start `torch.distributed.run --nproc-per-node N <this script> ...` as a child
+    (before torch / the GPU are touched), relay its JSON line, exit with its code (same scheme as bench.py)."""
+    if "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, timeout=float(os.environ.get("SEQIK_BENCH_TIMEOUT", "1500")))
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(r.returncode if (r.returncode or lines) else 3)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed(sys.argv[1:])
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402,F401  (HIP runtime first, see _lib.load)
@@ -84,8 +117,90 @@ def one_recording(args):
                                 "frames_walked_serially": n}}))
 
 
+def one_recording_over_ranks(args):
+    """Config 5 on N ranks: ONE recording of --frames frames x 6 legs, rank r streams its contiguous slabs from its own
+    pinned buffers (seqikpy_amd.stream_sharding); pass 1 (alignment statistics from all RAW slabs) on every rank."""
+    import torch.distributed as dist
+    from seqikpy_amd import stream_sharding
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    n_dev = torch.cuda.device_count()
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
+    backend = "nccl" if n_dev >= world else "gloo"     # ranks that share a GPU (rehearsal) talk over gloo
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    coll = "cuda" if backend == "nccl" else "cpu"
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = [str(l) for l in z["legs"]]
+    L, T = len(legs), args.slab_frames
+    n_slabs = max(world, args.frames // T)
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    rng = np.random.default_rng(5)
+    scales, fixed = 1.0 + 0.4 * rng.random(L), rng.normal(0.0, 2.0, (L, 3))
+    want_fk = not args.no_fk
+    base = np.stack([z[f"{l}_pose"] for l in legs])
+    al = np.tile(base, (1, -(-T // base.shape[1]), 1, 1))[:, :T]
+    tcs = [base[i, 0, 0].copy() for i in range(L)]
+    affs = [_lib.make_affine(fixed[i], scales[i], tcs[i]) for i in range(L)]
+    raw = np.stack([(al[i] - tcs[i]) / scales[i] + fixed[i] for i in range(L)])
+    # every slab holds the same T frames (T is a multiple of the fixture's 1000 frames, so the recording is the fixture
+    # repeated end to end): one pinned input slab per rank, output buffers cycled -- host memory stays bounded
+    p = PinnedArray((1, L, 5, T, 3))
+    p.array[0] = raw.transpose(0, 2, 1, 3)
+    outs = [(PinnedArray((1, L, 7, T)), PinnedArray((1, L, T, 9, 3)) if want_fk else None) for _ in range(args.slots + 1)]
+
+    def get_out(k):
+        a, f = outs[k % len(outs)]
+        return a.array, (f.array if f else None)
+
+    stats_pass = None
+    if args.gpu_stats:
+        n_tot = n_slabs * T
+        ranks_q = [r for q in (0.45, 0.55) for r in (int(np.floor((n_tot - 1) * q)), min(int(np.floor((n_tot - 1) * q)) + 1, n_tot - 1))]
+        stream_sharding.align_stats_all_slabs(lambda k: p.array, 1, T, L, [0])      # warm-up
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        order = stream_sharding.align_stats_all_slabs(lambda k: p.array, n_slabs, T, L, ranks_q)
+        stats_pass = {"seconds_this_rank": time.perf_counter() - t0, "frames_per_leg": n_tot,
+                      "what": "every rank extracts and sorts the 7 series per leg of ALL RAW slabs over its own PCIe link (no "
+                              "exchange): the constants are whole-recording order statistics", "median_coxa_x_RF": float(order[0, 0, 0])}
+    st = {}
+    stream_sharding.stream_recording_sharded(lambda k: p.array, get_out, min(n_slabs, 2 * world), T, params, affine=affs,
+                                             want_fk=want_fk, n_slots=args.slots)   # warm-up
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    k0, k1 = stream_sharding.stream_recording_sharded(lambda k: p.array, get_out, n_slabs, T, params, affine=affs, want_fk=want_fk,
+                                                      n_slots=args.slots, stats=st)
+    torch.cuda.synchronize()
+    dist.barrier()
+    mine = time.perf_counter() - t0
+    t = torch.tensor([mine], dtype=torch.float64, device=coll)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "slabs": [int(k0), int(k1)], "seconds": st.get("seconds", 0.0),
+                                  "h2d_GBps": st.get("h2d_GBps", 0.0), "d2h_GBps": st.get("d2h_GBps", 0.0),
+                                  "boundary_rounds": st.get("boundary_rounds"), "restreams": st.get("restreams")})
+    if rank == 0:
+        # check: slab 0 of rank 0 against the direct chunked call of those frames, and the serial walk of its first frames
+        c, h, _ = _lib.frame_chunk_plan(T)
+        a0 = get_out(0)[0] if (k1 - k0) <= len(outs) else None
+        units = n_slabs * L * T
+        print(json.dumps({"metric": "leg-IK solves/s, ONE recording streamed from host memory, frames sharded over the ranks "
+                                    "(PCIe-inclusive)", "value": units / dt, "unit": "leg-frame solves/s", "n_gpus": world,
+                          "backend": backend, "seconds": dt, "leg_frames": units, "frames_total": n_slabs * T, "legs": L,
+                          "slabs": n_slabs, "slab_frames": T, "frames_per_chunk": c, "run_in_frames": h,
+                          "outputs": "7 angles" + (" + 9x3 FK" if want_fk else ""), "ranks": seen,
+                          "alignment_statistics_pass": stats_pass,
+                          "data": "df3d locomotion recording (fixture) repeated, RAW key points through a made-up camera frame, "
+                                  "AlignPose.align_leg fused into the kernels"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 launches them (--one-recording only)")
     ap.add_argument("--frames", type=int, default=10_000_000)
     ap.add_argument("--slab-frames", type=int, default=500_000)
     ap.add_argument("--frames-per-seq", type=int, default=64)
@@ -101,6 +216,11 @@ def main():
                          "(carried warm start), every slab cut into frame chunks on the device; real locomotion poses "
                          "(the df3d fixture repeated) instead of the synthetic sequences")
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        if not args.one_recording:
+            raise SystemExit("--gpus N > 1 needs --one-recording (independent sequences need no coordination: run one "
+                             "process per GPU on its share of the slabs)")
+        return one_recording_over_ranks(args)
     if args.one_recording:
         return one_recording(args)
 

@@ -62,7 +62,10 @@ class DeviceSlab:
         """``pose_slab`` (S, L, n, 5, 3), or with ``planar`` (S, L, 5, n, 3) (the device layout: no transpose)."""
         import torch
         self.torch = torch
-        if planar:
+        if isinstance(pose_slab, tuple):
+            self.S, self.L = pose_slab[1].shape[:2]
+            self.n = pose_slab[0].shape[3] + pose_slab[1].shape[3]
+        elif planar:
             self.S, self.L, _, self.n = pose_slab.shape[:4]
         else:
             self.S, self.L, self.n = pose_slab.shape[:3]
@@ -73,8 +76,14 @@ class DeviceSlab:
         # planar device layout (include/seqik.h, SeqikLayout): every key-point row and every joint is its own time series
         self.layout = _lib.planar_layout(self.n)
         with torch.cuda.device(self.dev):
-            host = pose_slab if planar else pose_slab.transpose(0, 1, 3, 2, 4)
-            self.d_pose = torch.from_numpy(np.ascontiguousarray(host)).to(self.dev)                               # [S][L][5][n][3]
+            if isinstance(pose_slab, tuple):    # planar (lead frames, slab frames): uploaded side by side, no host concatenation
+                lead_part, body = pose_slab        # (pinned host memory is DMA-copied: torch asks the driver about the pointer)
+                self.d_pose = torch.empty((self.S, self.L, 5, self.n, 3), dtype=torch.float64, device=self.dev)
+                self.d_pose[:, :, :, :lead_part.shape[3]].copy_(torch.from_numpy(lead_part), non_blocking=True)
+                self.d_pose[:, :, :, lead_part.shape[3]:].copy_(torch.from_numpy(body), non_blocking=True)
+            else:
+                host = pose_slab if planar else pose_slab.transpose(0, 1, 3, 2, 4)
+                self.d_pose = torch.from_numpy(np.ascontiguousarray(host)).to(self.dev)                           # [S][L][5][n][3]
             self.d_ang = torch.zeros((self.S, self.L, 7, self.n), dtype=torch.float64, device=self.dev)           # [S][L][7][n]
             self.d_fk = torch.zeros((self.S, self.L, self.n, 9, 3), dtype=torch.float64, device=self.dev) if want_fk else None
             self.d_states = torch.zeros((self.S, self.L, self.K, 7), dtype=torch.float64, device=self.dev)

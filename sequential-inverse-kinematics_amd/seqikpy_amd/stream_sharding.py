@@ -91,7 +91,7 @@ def stream_recording_sharded(get_slab: Callable[[int], np.ndarray], get_out: Cal
             stream_rest()
         else:
             lead = lead_frames(k0, h) if lead_frames else get_slab(k0 - 1)[:, :, :, T - h:]
-            first = DeviceSlab(np.concatenate([lead, get_slab(k0)], axis=3), legs, C, h, 1e-6, h, want_fk, affine, planar=True)
+            first = DeviceSlab((np.ascontiguousarray(lead), get_slab(k0)), legs, C, h, 1e-6, h, want_fk, affine, planar=True)
             first.speculate()
             end0 = first.end_state()
             stream_rest(end0)
@@ -123,9 +123,9 @@ def stream_recording_sharded(get_slab: Callable[[int], np.ndarray], get_out: Cal
             raise RuntimeError("sharded stream did not converge")
     if first is not None:   # the settled first slab goes to the host
         a, f = get_out(k0)
-        a[...] = first.d_ang[:, :, :, first.lead:].cpu().numpy()
+        torch.from_numpy(a).copy_(first.d_ang[:, :, :, first.lead:])
         if want_fk:
-            f[...] = first.fk().cpu().numpy()
+            torch.from_numpy(f).copy_(first.fk())
     if st is not None:
         st.close()
     dt = time.perf_counter() - t0
