@@ -432,6 +432,7 @@ struct ChunkArgs {
     ChunkCtrl *ctrl;       // [kMaxChunkRounds + 2]
     int32_t *stats;        // nullable device int32[16] (SeqikOptions.chunk_stats)
     uint8_t *flags;        // nullable device [n_chains][K] (SeqikOptions.chunk_flags)
+    int32_t *fail_count;   // [n_chains]: chunks that failed the first verification
     int32_t *chain_serial; // [n_chains]: 1 = the automatic mode's guard hands this chain to the serial walk
     int32_t *serial_list;  // [n_chains]
     int32_t guard;         // automatic mode: chains with more than one chunk in eight inconsistent are walked serially
@@ -463,36 +464,45 @@ __device__ __forceinline__ bool chunk_inconsistent(const KernelArgs &a, const Ch
     return bad;
 }
 
-// First verification, one wavefront per real chain: which chunks start from a state that is not the true one?  Fills the
-// per-chunk report, counts, and -- automatic mode -- decides PER CHAIN whether speculation is worth keeping: a chain with
-// more than one chunk in eight inconsistent (random poses with several equivalent leg configurations do that: a run-in
-// then lands in another configuration than the serial walk about half of the time) is put on the serial list; the scan /
-// repair / sweep kernels leave it alone and seqik_chunk_pipe_kernel<CHUNK_SERIAL> walks it frame by frame from its seeds,
-// which is the reference's result bit for bit.  Per chain, so the decision for a recording does not depend on what else
-// is in the call.
-__global__ void __launch_bounds__(64) seqik_chunk_verify_kernel(KernelArgs a, ChunkArgs ca)
+// First verification, one thread per chunk (chunk-major, so the lanes of a wavefront sit on one chain and one atomic per
+// wavefront counts its failures): which chunks start from a state that is not the true one?  Fills the per-chunk report and
+// counts per chain.  seqik_chunk_decide_kernel (one thread per chain) then decides -- automatic mode -- PER CHAIN whether
+// speculation is worth keeping: a chain with more than one chunk in eight inconsistent (random poses with several
+// equivalent leg configurations do that: a run-in then lands in another configuration than the serial walk about half of
+// the time) is put on the serial list; the scan / repair / sweep kernels leave it alone and
+// seqik_chunk_pipe_kernel<CHUNK_SERIAL> walks it frame by frame from its seeds, which is the reference's result bit for bit.
+// Per chain, so the decision for a recording does not depend on what else is in the call.
+__global__ void __launch_bounds__(256) seqik_chunk_verify_kernel(KernelArgs a, ChunkArgs ca)
 {
-    const int64_t c = blockIdx.x;
-    const int lane = threadIdx.x;
     const int64_t K = ca.n_chunks;
-    int fails = 0;
-    for (int64_t k0 = 0; k0 < K; k0 += 64) {
-        const int64_t k = k0 + lane;
-        const bool inc = k < K && k >= ca.k_first && chunk_inconsistent(a, ca, c, k);
-        if (ca.flags && k < K) ca.flags[c * K + k] = (ca.resume ? ca.flags[c * K + k] : 0) | (inc ? CHUNK_FLAG_FAILED_FIRST : 0);
-        fails += __popcll(__ballot(inc));
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < a.n_chains * K;
+    const int64_t c = live ? t / K : 0, k = live ? t - c * K : 0;
+    const bool inc = live && k >= ca.k_first && chunk_inconsistent(a, ca, c, k);
+    if (live && ca.flags) ca.flags[t] = (ca.resume ? ca.flags[t] : 0) | (inc ? CHUNK_FLAG_FAILED_FIRST : 0);
+    // one atomic per (wavefront, chain): the first failing lane's chain is counted by ballot, a lane of another chain (a
+    // wavefront that straddles a chain boundary) adds its own
+    const unsigned long long m = __ballot(inc);
+    if (m) {
+        const int first = __ffsll((long long)m) - 1;
+        const int64_t c0 = __shfl(c, first);
+        const unsigned long long same = __ballot(inc && c == c0);
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&ca.fail_count[c0], (int)__popcll(same));
+        else if (inc && c != c0) atomicAdd(&ca.fail_count[c], 1);
     }
-    const bool serial = ca.guard && (int64_t)fails * 8 > K;
-    if (lane == 0) {
-        if (ca.stats && fails) atomicAdd(&ca.stats[7], fails);
-        if (serial) {
-            ca.chain_serial[c] = 1;
-            ca.serial_list[atomicAdd(&ca.ctrl[kCtrlSerial].count, 1)] = (int32_t)c;
-            if (ca.stats) { atomicAdd(&ca.stats[8], 1); atomicAdd(&ca.stats[9], (int32_t)K); }
-        }
+}
+
+__global__ void __launch_bounds__(256) seqik_chunk_decide_kernel(KernelArgs a, ChunkArgs ca)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n_chains) return;
+    const int fails = ca.fail_count[c];
+    if (ca.stats && fails) atomicAdd(&ca.stats[7], fails);
+    if (ca.guard && (int64_t)fails * 8 > ca.n_chunks) {
+        ca.chain_serial[c] = 1;
+        ca.serial_list[atomicAdd(&ca.ctrl[kCtrlSerial].count, 1)] = (int32_t)c;
+        if (ca.stats) { atomicAdd(&ca.stats[8], 1); atomicAdd(&ca.stats[9], (int32_t)ca.n_chunks); }
     }
-    if (serial && ca.flags)
-        for (int64_t k = lane; k < K; k += 64) ca.flags[c * K + k] |= CHUNK_FLAG_SERIAL;
 }
 
 __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, ChunkArgs ca)
@@ -718,6 +728,8 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
                 const int64_t c = ca.serial_list[cursor];
                 leg = (int)(c % a.n_legs);
                 serial_io(a, c, io);
+                if (ca.flags && stage_wave == 0)   // (replicas write the same bytes)
+                    for (int64_t kk = lane; kk < ca.n_chunks; kk += 64) ca.flags[c * ca.n_chunks + kk] |= CHUNK_FLAG_SERIAL;
             } else {
                 const int64_t vc = ca.worklist[cursor];
                 leg = (int)(vc % a.n_legs);
@@ -1114,7 +1126,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     const size_t ws_frames = chunked ? (size_t)chunk + (size_t)(halo > lead ? halo : lead) : 0;  // hand-off frames per chunk
     if (chunked) {
         const size_t ws_bytes = sizeof(double) * (12 * ws_frames + 7) * n_vchains + 128 +
-                                sizeof(int32_t) * ((size_t)n_vchains + 2 * (size_t)a.n_chains);
+                                sizeof(int32_t) * ((size_t)n_vchains + 3 * (size_t)a.n_chains);
         if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     } else if (last_stage > first_stage && !piped) {
         const size_t ws_bytes = sizeof(double) * 12 * a.n_chains * n_frames;
@@ -1149,10 +1161,11 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         ca.ctrl = reinterpret_cast<ChunkCtrl *>(base + off); off += 128;
         ca.worklist = reinterpret_cast<int32_t *>(base + off); off += sizeof(int32_t) * (size_t)n_vchains;
         ca.chain_serial = reinterpret_cast<int32_t *>(base + off); off += sizeof(int32_t) * (size_t)a.n_chains;
+        ca.fail_count = reinterpret_cast<int32_t *>(base + off); off += sizeof(int32_t) * (size_t)a.n_chains;  // (zeroed with chain_serial)
         ca.serial_list = reinterpret_cast<int32_t *>(base + off);
         if (opt->stage_events) HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(opt->stage_events[0]), stream));
         hipLaunchKernelGGL(seqik_chunk_reset_kernel, dim3(1), dim3(64), 0, stream, ca, (int32_t)(n_chunks * a.n_chains));
-        HIP_TRY(hipMemsetAsync(ca.chain_serial, 0, sizeof(int32_t) * (size_t)a.n_chains, stream));
+        HIP_TRY(hipMemsetAsync(ca.chain_serial, 0, sizeof(int32_t) * 2 * (size_t)a.n_chains, stream));
         if (resume) {
             // nothing is solved speculatively: angles / chunk_states are a previous call's, d_init the true state
         } else if (piped) {
@@ -1164,7 +1177,8 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         } else if (fk) hipLaunchKernelGGL((seqik_chunk_kernel<true, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         else hipLaunchKernelGGL((seqik_chunk_kernel<false, CHUNK_SPEC>), grid, blk, 0, stream, a, ca);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(seqik_chunk_verify_kernel, dim3((unsigned)a.n_chains), dim3(64), 0, stream, a, ca);
+        hipLaunchKernelGGL(seqik_chunk_verify_kernel, dim3((unsigned)((n_vchains + 255) / 256)), dim3(256), 0, stream, a, ca);
+        hipLaunchKernelGGL(seqik_chunk_decide_kernel, dim3((unsigned)((a.n_chains + 255) / 256)), dim3(256), 0, stream, a, ca);
         const dim3 scan_grid((unsigned)((n_vchains + 255) / 256)), scan_blk(256);
         const int64_t rep_waves = n_waves < 4096 ? n_waves : 4096;  // the work list is walked grid-stride
         const dim3 rep_grid((unsigned)((rep_waves * 64 + block - 1) / block));
