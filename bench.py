@@ -688,38 +688,65 @@ def main():
                  "rank_ms_per_step": {"min": min(r["ms_per_step"] for r in seen), "max": max(r["ms_per_step"] for r in seen),
                                       "by_rank": [r["ms_per_step"] for r in seen]}}
         if not args.no_extras:
+            def guarded(name, fn):
+                """One extra leg.  The headline above is measured and must survive whatever happens here: a leg that
+                raises on any rank is dropped on ALL ranks (consensus by all-reduce, so nobody waits in a collective the
+                others never enter) and reported as an error string."""
+                err = None
+                try:
+                    res = fn()
+                except Exception as exc:  # noqa: BLE001
+                    res, err = None, f"{type(exc).__name__}: {exc}"
+                ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) < 0.5:
+                    multi[name] = {"error": err or "failed on another rank"}
+                else:
+                    multi[name] = res
+
             k_cmp = max(4, min(20, args.steps))
-            # the final joint-angle gather, both ways, same batch, same process group: copy-engine peer writes into
-            # rank 0's exported buffers vs grouped RCCL point-to-point (the north star's "RCCL over xGMI")
-            cmp_ = {"steps": k_cmp}
-            for how in ("peer", "rccl"):
-                g2, desc = peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, prefer=how)
-                tm, _ = timed_region(batch, d_ang, g2, k_cmp, min(2, args.warmup))
-                cmp_[how] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm, "ran_as": desc}
+
+            def leg_gather_compare():
+                # the final joint-angle gather, both ways, same batch, same process group: copy-engine peer writes into
+                # rank 0's exported buffers vs grouped RCCL point-to-point (the north star's "RCCL over xGMI")
+                cmp_ = {"steps": k_cmp}
+                for how in ("peer", "rccl"):
+                    g2, desc = peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, prefer=how)
+                    tm, _ = timed_region(batch, d_ang, g2, k_cmp, min(2, args.warmup))
+                    cmp_[how] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm, "ran_as": desc}
+                    if hasattr(g2, "close"):
+                        g2.close()
+                    del g2
+                tm, _ = timed_region(batch, d_ang, None, k_cmp, min(2, args.warmup))
+                cmp_["no_gather"] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm}
+                return cmp_
+
+            other_scaling = "strong" if args.scaling == "weak" else "weak"
+
+            def leg_other_scaling():
+                # the other scaling mode beside the headline: strong = config 3 literally (the fixed 1M-frame problem split
+                # over the ranks), weak = 1M frames per GPU
+                pose2, _, _, _, units_all2 = workload_for(other_scaling)
+                b2 = Batch(pose2, params, args, n_streams)
+                bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
+                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0)
+                k2 = max(4, min(40, args.steps))
+                tm, _ = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
+                res = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
+                       "steps": k2, "scaling": other_scaling, "sequences_per_gpu": int(pose2.shape[0]),
+                       "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc}
                 if hasattr(g2, "close"):
                     g2.close()
-                del g2
-            tm, _ = timed_region(batch, d_ang, None, k_cmp, min(2, args.warmup))
-            cmp_["no_gather"] = {"ms_per_step": tm / k_cmp * 1e3, "value": units_all * k_cmp / tm}
-            multi["gather_compare"] = cmp_
-            # the other scaling mode beside the headline: strong = config 3 literally (the fixed 1M-frame problem split
-            # over the ranks), weak = 1M frames per GPU
-            other_scaling = "strong" if args.scaling == "weak" else "weak"
-            pose2, _, _, _, units_all2 = workload_for(other_scaling)
-            b2 = Batch(pose2, params, args, n_streams)
-            bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
-            g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0)
-            k2 = max(4, min(40, args.steps))
-            tm, _ = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
-            multi[other_scaling] = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
-                                    "steps": k2, "scaling": other_scaling, "sequences_per_gpu": int(pose2.shape[0]),
-                                    "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc}
-            if hasattr(g2, "close"):
-                g2.close()
-            del g2, b2, bufs2, pose2
-            # config 3 read literally: ONE recording frame-sharded over the ranks (short leg; `--one-recording` runs it alone)
-            torch.cuda.empty_cache()
-            multi["one_recording"] = one_recording_leg(dist, world, rank, args.frames, max(3, min(10, args.steps)), 1, coll_dev)
+                return res
+
+            def leg_one_recording():
+                # config 3 read literally: ONE recording frame-sharded over the ranks (`--one-recording` runs it alone)
+                torch.cuda.empty_cache()
+                return one_recording_leg(dist, world, rank, args.frames, max(3, min(10, args.steps)), 1, coll_dev)
+
+            guarded("gather_compare", leg_gather_compare)
+            guarded(other_scaling, leg_other_scaling)
+            guarded("one_recording", leg_one_recording)
 
     if rank == 0:
         out = {
