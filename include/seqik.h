@@ -225,6 +225,12 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
  * above); d_fk is always [chain][frame][9][3], d_status / d_nfev [chain][frame][4].
  * This is the entry point the benchmark times.
  */
+/* Self-test of the floating-point contract: q[i] = a[i] / b[i] and r[i] = sqrt(a[i]) computed on the device by
+ * the kernels' own division / square root (the gfx950 expansions without the range-scaling steps).  Host buffers of n
+ * doubles each.  The GPU tests compare the results with IEEE division / square root over the operand range the
+ * contract states, and with the special values.  No reference counterpart. */
+int seqik_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, int64_t n);
+
 /* The frame chunks a call over recordings of n_frames frames would use with these options (frame_chunk / frame_halo /
  * frame_lead): frames per chunk, run-in frames, chunks per chain K -- all 0 when the call would be walked serially.
  * A function of n_frames and the options alone (not of the number of recordings or legs).  No GPU needed. */

@@ -1559,6 +1559,32 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     return SEQIK_OK;
 }
 
+// Self-test hook of the floating-point contract: q[i] = div_(a[i], b[i]), r[i] = sqrt_(a[i]) on the device.
+__global__ void seqik_selftest_div_sqrt_kernel(const double *a, const double *b, double *q, double *r, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { q[i] = seqik::div_(a[i], b[i]); r[i] = seqik::sqrt_(a[i]); }
+}
+
+int seqik_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, int64_t n)
+{
+    if (!a || !b || !q || !r || n < 0) return fail(SEQIK_ERR_BAD_ARG, "null pointer argument%s");
+    if (n == 0) return SEQIK_OK;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * 4 * n));
+    hipError_t e = hipMemcpy(d, a, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, b, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(seqik_selftest_div_sqrt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, d + 2 * n, d + 3 * n, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(q, d + 2 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(r, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SEQIK_ERR_HIP, "seqik_selftest_div_sqrt: %s", hipGetErrorString(e));
+    return SEQIK_OK;
+}
+
 int seqik_frame_chunk_plan(int64_t n_frames, const SeqikOptions *opt, int32_t *chunk, int32_t *halo, int64_t *n_chunks)
 {
     int32_t c = 0, h = 0, lead = 0;

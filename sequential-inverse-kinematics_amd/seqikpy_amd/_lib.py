@@ -61,6 +61,20 @@ def chunk_stats_dict(stats):
     return {k: int(v) for k, v in zip(CHUNK_STATS_FIELDS, stats)}
 
 
+def selftest_div_sqrt(a, b):
+    """(a / b, sqrt(a)) as the kernels compute them on the device (``seqik_selftest_div_sqrt``)."""
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    if a.shape != b.shape:
+        raise ValueError("a and b must have the same number of elements")
+    q, r = np.empty_like(a), np.empty_like(a)
+    rc = load().seqik_selftest_div_sqrt(a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), q.ctypes.data_as(_dp),
+                                        r.ctypes.data_as(_dp), a.size)
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return q, r
+
+
 def frame_chunk_plan(n_frames, frame_chunk=-1, frame_halo=0, frame_lead=0):
     """``seqik_frame_chunk_plan``: (frames per chunk, run-in frames, chunks per chain) a call over recordings of
     ``n_frames`` frames would use -- (0, 0, 0) when it would be walked serially.  No GPU needed."""
@@ -194,6 +208,8 @@ def load():
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_void_p, ctypes.POINTER(SeqikLayout), ctypes.POINTER(SeqikAffine),
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
+        L.seqik_selftest_div_sqrt.restype = ctypes.c_int
+        L.seqik_selftest_div_sqrt.argtypes = [_dp, _dp, _dp, _dp, ctypes.c_int64]
         L.seqik_frame_chunk_plan.restype = ctypes.c_int
         L.seqik_frame_chunk_plan.argtypes = [ctypes.c_int64, ctypes.POINTER(SeqikOptions), _ip, _ip,
                                              ctypes.POINTER(ctypes.c_int64)]
@@ -254,7 +270,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
-                    "seqik_validate_legs", "seqik_frame_chunk_plan",
+                    "seqik_validate_legs", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt",
                     "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
                     "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",

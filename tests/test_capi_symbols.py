@@ -27,7 +27,7 @@ def test_header_declares_expected_entry_points():
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
-                                           "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_stream_open", "seqik_stream_submit",
+                                           "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_stream_open", "seqik_stream_submit",
                                            "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry", "seqik_stream_close",
                                            "seqik_align_stats_open", "seqik_align_stats_add", "seqik_align_stats_finish",
                                            "seqik_align_stats_reset", "seqik_align_stats_close"])

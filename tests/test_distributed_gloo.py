@@ -583,3 +583,27 @@ def test_config5_one_recording_streamed_over_ranks_equals_single_process_stream(
             assert np.array_equal(got["fk"][i], ref[k][1]), (r, k)
             seen += 1
     assert seen == n_slabs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_frame_sharding_under_a_one_rank_rccl_group_with_the_default_device(hiplib):
+    """Advisor, round 2: `solve_frame_sharded` with its default `device=-1` under an "nccl" (= RCCL) process group used to
+    build `torch.device("cuda", -1)`.  One rank, default device: == the one-call chunked result, bit for bit."""
+    import torch
+    import torch.distributed as dist
+    from seqikpy_amd import frame_sharding
+    z = load_golden("df3d_1000")
+    legs = [str(l) for l in z["legs"]][:3]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    one = hiplib.solve_seq(pose, params, frame_chunk=16, frame_halo=8)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        st = {}
+        out = frame_sharding.solve_frame_sharded(pose, params, chunk=16, halo=8, stats=st)
+        assert st["slab"] == (0, 1000) and st["boundary_rounds"] == 0
+        assert np.array_equal(out["angles"], one["angles"]) and np.array_equal(out["fk"], one["fk"])
+    finally:
+        dist.destroy_process_group()

@@ -505,3 +505,36 @@ def test_host_calls_do_not_strand_device_memory(lib):
     assert np.array_equal(lib.solve_seq(pose[:2], params, device=0)["angles"], ref["angles"])
     assert torch.cuda.current_device() == dev
     lib.release_workspaces()
+
+
+def test_device_division_and_square_root_equal_ieee_on_the_contract_range(lib):
+    """DESIGN.md §2, floating-point contract: div_() / sqrt_() (the gfx950 expansions of `/` and `sqrt` without the
+    range-scaling steps) == IEEE division / square root, bit for bit, for operands within [2^-767, 2^767] -- 4 M random
+    pairs spread over the whole range, near-equal operands, powers of two, quotients close to rounding boundaries -- and
+    give the IEEE results for zero, infinite and NaN operands."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+
+    def spread(lo, hi, size):   # random doubles with exponents uniform in [lo, hi], random sign
+        return np.ldexp(1.0 + rng.random(size), rng.integers(lo, hi, size)) * rng.choice([-1.0, 1.0], size)
+
+    a = np.concatenate([spread(-380, 380, n), spread(-60, 60, n), spread(-10, 10, n), np.ldexp(1.0, rng.integers(-300, 300, n))])
+    b = np.concatenate([spread(-380, 380, n), spread(-60, 60, n), spread(-10, 10, n) , spread(-300, 300, n)])
+    b[2 * n:2 * n + n // 2] = a[2 * n:2 * n + n // 2] * (1.0 + rng.integers(-4, 5, n // 2) * 2.0 ** -52)   # quotients next to 1
+    q, r = lib.selftest_div_sqrt(a, b)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(q, a / b)
+        pos = np.abs(a)
+        _, r = lib.selftest_div_sqrt(pos, b)
+        assert np.array_equal(r, np.sqrt(pos))
+        wide = spread(-766, 766, n)                     # the whole stated range
+        q, r = lib.selftest_div_sqrt(wide, np.ones(n))
+        assert np.array_equal(q, wide) and np.array_equal(lib.selftest_div_sqrt(np.abs(wide), np.ones(n))[1], np.sqrt(np.abs(wide)))
+        sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 3.0, 1e-300, 1e300])
+        aa, bb = [x.ravel() for x in np.meshgrid(sp, sp)]
+        q, r = lib.selftest_div_sqrt(aa, bb)
+        want = aa / bb
+        assert np.array_equal(np.isnan(q), np.isnan(want)) and np.array_equal(q[~np.isnan(want)], want[~np.isnan(want)])
+        assert np.array_equal(np.signbit(q[~np.isnan(want)]), np.signbit(want[~np.isnan(want)]))
+        ws = np.sqrt(aa)
+        assert np.array_equal(np.isnan(r), np.isnan(ws)) and np.array_equal(r[~np.isnan(ws)], ws[~np.isnan(ws)])
