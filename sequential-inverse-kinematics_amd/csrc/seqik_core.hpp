@@ -1429,10 +1429,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         if (finished) {
             // ---- solve done: store, advance to the next frame -------------------------------
             const bool stored = !CHUNKED || t >= io.t_store;  // run-in frames leave nothing but the hand-off
-#ifndef SEQIK_WHATIF_NO_STORES   // (timing experiments only: 1 = stage 1 stores nothing; results are garbage)
-#define SEQIK_WHATIF_NO_STORES 0
-#endif
-            if (stored && !(SEQIK_WHATIF_NO_STORES && STAGE == 1)) {
+            if (stored) {
                 double *ang = io.angles + t * io.ang_frame;
                 ang[DOF0 * io.ang_dof] = x[0];
                 if constexpr (NA == 2) ang[(DOF0 + 1) * io.ang_dof] = x[1];
@@ -1455,7 +1452,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) w[(9 + i) * io.pipe.lane_stride] = after.t[i];
                     pipe_store(io.pipe.produced_out, fi + 1);
-                } else if constexpr (HANDOFF && !(SEQIK_WHATIF_NO_STORES && STAGE == 1)) {
+                } else if constexpr (HANDOFF) {
                     double *w = io.frames + (t - t_first) * 12;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) w[i] = after.r[i];
@@ -1495,23 +1492,6 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             new_solve = true;
         }
         SEQIK_BLK_END_OF(BLK_FINISHED);
-#if SEQIK_BLOCK_CYCLES == 2   // experiment: what does a stamp right behind a stamp cost?
-        if constexpr (!PIPED) SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
-#endif
-#if SEQIK_BLOCK_CYCLES >= 3 && defined(__HIP_DEVICE_COMPILE__)
-        // experiment: a short stretch of code that only SEQIK_BLOCK_CYCLES lanes execute (a handful of dependent
-        // multiply-adds), in front of the reconvergence at the loop edge -- with the replicated workload, where nothing
-        // else diverges, this isolates what a sparse-EXEC stretch costs the wave
-        if constexpr (!PIPED) {
-            if ((int)(threadIdx.x & 63) < SEQIK_BLOCK_CYCLES) {
-                double dummy = cost;
-#pragma unroll
-                for (int i = 0; i < 24; ++i) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(dummy));
-                asm volatile("" ::"v"(dummy));
-            }
-            SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
-        }
-#endif
     }
     SEQIK_BLK_END(STAGE);
 }
