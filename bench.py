@@ -766,6 +766,12 @@ def main():
                        "pipeline": f"{len(streams)} independent batches in flight (consecutive steps overlap); "
                                    "`single_job` is one launch at a time",
                        "launches_per_step": 4 if args.staged else 1,
+                       "parity_note": ("iid poses span several equivalent leg configurations: the reference itself moves 30 % of "
+                                       "such leg-frames by more than 1e-4 rad under a 1-ulp change of its input "
+                                       "(profiles/r02_perturbation_report.json), so on this variant parity means HIP == C restatement "
+                                       "bit for bit; `variants.smooth` is the realistic workload, `parity` the shipped recordings"
+                                       if args.variant == "iid" else
+                                       "temporally continuous poses (the realistic variant); `parity` holds the shipped recordings"),
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
                        **({"gather": gather_how} if gather_how else {})},
             "roofline": roofline,
