@@ -395,13 +395,14 @@ seqik_pipe_kernel(KernelArgs a)
 // A chain of N frames is cut into K = ceil(N / C) chunks; "virtual chain" vc = (seq * K + k) * n_legs + leg is chunk k
 // of real chain c = seq * n_legs + leg.  Launch sequence on the caller's stream, no host round trip:
 //     chunk kernel  (SPEC)     every virtual chain: chunk 0 from the seeds / init at frame 0, chunk k >= 1 from the
-//                              seeds at frame k C - h; the h run-in frames leave only start_state[vc] (7 angles)
-//     verify kernel            first verification, one wave per real chain: per-chunk report, statistics, and in
-//                              automatic mode the per-chain decision "speculation failed here: walk this chain serially"
+//                              seeds at frame k C - h; the h run-in frames leave only the chunk's start_state (7 angles)
+//     verify + decide kernels  first verification, one thread per chunk: per-chunk report, failures counted per chain;
+//                              then one thread per chain: statistics, and in automatic mode the per-chain decision
+//                              "speculation failed here: walk this chain serially"
 //     R x { scan kernel        which chunks are inconsistent (|start_state - true last frame of chunk k-1| > tol in
 //                              some joint)?  those whose predecessor is consistent go on the work list
 //           chunk kernel (REPAIR)  re-solves the listed chunks from the true state (init = the stored angles of frame
-//                              k C - 1; bit-identical to the serial continuation), start_state[vc] = that state }
+//                              k C - 1; bit-identical to the serial continuation), which becomes its start_state }
 //     scan kernel + chunk kernel (SWEEP)   one wave per real chain walks its chunks left to right and re-solves what is
 //                              still inconsistent: terminates after at most K steps with every chunk consistent
 //     pipe kernel (SERIAL)     automatic mode: the chains the verify kernel gave up on, frame by frame from their seeds

@@ -131,14 +131,27 @@ def _hipcc():
 KERNEL_SOURCES = ["seqik_core.hpp", "seqik_consts.hpp", "seqik_hip.hip"]   # what the solver kernels are compiled from
 
 
-def csrc_sha256(files=None) -> str:
-    """sha256 over the solver kernels' sources (in ``KERNEL_SOURCES`` order): ties a committed PMC summary
-    (profiles/traffic_rNN.json, written by scripts/summarize_profile.py) to the build it was measured on."""
+def _code_only(text: str) -> str:
+    """C++ source without comments and with white space collapsed (what the compiler sees, roughly)."""
+    import re
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return " ".join(text.split())
+
+
+def csrc_sha256(files=None, read=None) -> str:
+    """sha256 over the CODE of the solver kernels' sources (``KERNEL_SOURCES`` order; comments and white space do not
+    count): ties a committed PMC summary (profiles/traffic_rNN.json, written by scripts/summarize_profile.py) to the build
+    it was measured on.  ``read(name) -> str``: another source of the files (e.g. an older commit)."""
     import hashlib
     h = hashlib.sha256()
     for name in (files or KERNEL_SOURCES):
-        with open(os.path.join(CSRC, name), "rb") as f:
-            h.update(f.read())
+        if read is not None:
+            text = read(name)
+        else:
+            with open(os.path.join(CSRC, name), "r") as f:
+                text = f.read()
+        h.update(_code_only(text).encode())
     return h.hexdigest()
 
 
