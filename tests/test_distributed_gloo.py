@@ -170,7 +170,8 @@ def _frame_shard_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
     legs = ["RF", "LM", "RH"]
-    pose = np.stack([z[f"{l}_pose"][:610] for l in legs])[None]
+    n_frames = int(os.environ.get("SEQIK_TEST_FRAMES", "610"))
+    pose = np.stack([z[f"{l}_pose"][:n_frames] for l in legs])[None]
     res = {}
     for name, tol in (("spec", 1e-6), ("exact", 0.0)):
         st = {}
@@ -209,6 +210,26 @@ def test_one_recording_sharded_by_frame_over_ranks(tmp_path, oracle, world):
         assert int(got["spec_resumes"]) == (1 if r > 0 else 0)
         slabs.append(tuple(got["spec_slab"]))
     assert slabs[0][0] == 0 and slabs[-1][1] == 610 and all(slabs[i][1] == slabs[i + 1][0] for i in range(world - 1))
+
+
+@pytest.mark.timeout(600)
+def test_frame_sharding_with_more_ranks_than_chunks(tmp_path, oracle, monkeypatch):
+    """130 frames in chunks of 50 = 3 chunks over 4 ranks: one rank owns nothing, its right neighbour takes the state of
+    the nearest rank that does; every rank still ends up with the whole result == the one-rank chunked result."""
+    from chunk_model import chunked_oracle
+    monkeypatch.setenv("SEQIK_TEST_FRAMES", "130")
+    mp.spawn(_frame_shard_worker, args=(4, free_port(), str(tmp_path)), nprocs=4, join=True)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    legs = ["RF", "LM", "RH"]
+    one = [chunked_oracle(oracle, z[f"{l}_pose"][:130], z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"], 50, 8) for l in legs]
+    slabs = []
+    for r in range(4):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert got["spec_angles"].shape == (1, 3, 130, 7)
+        for li in range(3):
+            assert np.array_equal(got["spec_angles"][0, li], one[li]["angles"]) and np.array_equal(got["spec_fk"][0, li], one[li]["fk"])
+        slabs.append(tuple(int(v) for v in got["spec_slab"]))
+    assert sorted(b - a for a, b in slabs) == [0, 30, 50, 50] and slabs[0][0] == 0
 
 
 @pytest.mark.gpu

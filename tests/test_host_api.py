@@ -174,3 +174,28 @@ def test_package_import_asks_for_eight_hardware_queues():
             "import importlib; importlib.reload(seqikpy_amd); print(os.environ['GPU_MAX_HW_QUEUES'])") % PKG_PARENT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
     assert out == ["8", "2"]
+
+
+def test_frame_parallel_default_and_chunk_report(monkeypatch):
+    """The default of run_ik_and_fk is the reference's serial walk unless SEQIK_FRAME_PARALLEL says otherwise; the
+    per-leg report is built from the library's chunk statistics and per-chunk flags."""
+    from seqikpy_amd import _lib
+    from seqikpy_amd.leg_inverse_kinematics import chunk_report, default_frame_parallel
+    monkeypatch.delenv("SEQIK_FRAME_PARALLEL", raising=False)
+    assert default_frame_parallel() is False
+    monkeypatch.setenv("SEQIK_FRAME_PARALLEL", "auto")
+    assert default_frame_parallel() == "auto"
+    monkeypatch.setenv("SEQIK_FRAME_PARALLEL", "0")
+    assert default_frame_parallel() is False
+    flags = np.zeros((2, 2, 5), np.uint8)
+    flags[0, 0, 2] = _lib.CHUNK_FLAG_FAILED_FIRST | _lib.CHUNK_FLAG_REPAIRED
+    flags[0, 0, 4] = _lib.CHUNK_FLAG_SWEPT
+    flags[1, 1, :] = _lib.CHUNK_FLAG_SERIAL | _lib.CHUNK_FLAG_FAILED_FIRST
+    out = dict(angles=np.zeros((2, 2, 37, 7)), chunk_flags=flags,
+               chunk_stats=dict(chunks=20, frames_per_chunk=8, run_in_frames=4))
+    rep = chunk_report(out, ["RF", "LF"], 37)
+    assert rep[0]["RF"] == dict(frames_per_chunk=8, run_in_frames=4, failed_first_check=[16], frames_repaired=8 + 5,
+                                walked_serially=False)     # the last chunk holds 37 - 32 = 5 frames
+    assert rep[0]["LF"]["failed_first_check"] == [] and rep[1]["LF"]["walked_serially"] and not rep[1]["RF"]["walked_serially"]
+    assert rep[1]["LF"]["failed_first_check"] == [0, 8, 16, 24, 32]
+    assert chunk_report(dict(angles=np.zeros((3, 1, 4, 7)), chunk_flags=None, chunk_stats=dict(chunks=0)), ["RF"], 4) == [{}, {}, {}]
