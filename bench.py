@@ -393,6 +393,35 @@ def one_recording_leg(dist, world, rank, n_frames, steps, warmup, coll_dev="cpu"
             "check": chk}
 
 
+def measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step):
+    """The same issue floor priced with MEASURED issue costs per instruction class (scripts/microbench/valu_issue.hip ->
+    profiles/r03_valu_issue_costs.json, three wavefronts per SIMD): f64 add / mul / fma ~4.25 cycles per wavefront
+    instruction, v_rcp_f64 / v_rsq_f64 ~16.2, and of the remaining vector instructions the share that profiles/
+    r03_fused_isa.json finds to be f64-class / scalar-mask / 64-bit instructions (~4.25 cycles too) against plain 32-bit
+    ones (~2.7).  None when the files are absent."""
+    try:
+        costs = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue_costs.json")))["classes"]
+        isa = json.load(open(os.path.join(ROOT, "profiles", "r03_fused_isa.json")))["kernels"]["fused_kernel<fk=1>"]
+        share4 = isa["valu_not_f64_arith_issue_split"]["share_about_4.2_cycles"]
+    except (OSError, KeyError, ValueError):
+        return None
+    c = lambda name: costs[name]["waves_per_simd_3"]["cycles_per_inst"]  # noqa: E731
+    c_f64 = (c("v_fma_f64") + c("v_mul_f64") + c("v_add_f64")) / 3.0
+    c_trans = (c("v_rcp_f64") + c("v_rsq_f64")) / 2.0
+    c_other4 = (c("v_cmp_lt_f64") + c("v_max_f64") + c("v_mov_b64") + c("the same with the mask in an SGPR pair (VOP3)")) / 4.0
+    c_other2 = (c("v_mov_b32") + c("v_add_u32") + c("v_xor_b32")) / 3.0
+    n_arith = sum(mix["add"]) + sum(mix["mul"]) + sum(mix["fma"])
+    n_trans = sum(mix["trans"])
+    n_other = n_all - n_arith - n_trans
+    cycles = n_arith * c_f64 + n_trans * c_trans + n_other * (share4 * c_other4 + (1.0 - share4) * c_other2)
+    floor_ms = cycles / (simds * clock_hz) * 1e3
+    return {"cycles_per_inst": {"f64_add_mul_fma": c_f64, "f64_rcp_rsq": c_trans, "other_4_cycle_class": c_other4,
+                                "other_32_bit": c_other2, "share_of_other_in_4_cycle_class": share4},
+            "issue_floor_ms_per_step": floor_ms, "frac_of_valu_issue_floor": floor_ms / ms_per_step,
+            "source": "profiles/r03_valu_issue_costs.json (microbenchmark, 3 waves per SIMD) x PMC counts; "
+                      "profiles/r03_fused_isa.json for the split of the instructions the PMC classes do not cover"}
+
+
 def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index):
     """The VALU-side roofline figures from the newest committed PMC summary (profiles/traffic_rNN*.json, written by
     scripts/summarize_profile.py) that matches this workload -- used only if it was measured on THIS build: the summary
@@ -431,6 +460,7 @@ def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index
                     "cycles_per_inst": {"f64": 4, "other": 2},
                     "issue_floor_ms_per_step": floor_ms, "measured_ms_per_step": ms_per_step,
                     "frac_of_valu_issue_floor": floor_ms / ms_per_step,
+                    "measured_costs": measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step),
                     "lane_utilisation": utils_,
                     "source": "SQ_INSTS_VALU / SQ_INSTS_VALU_*_F64 / SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU per launch "
                               f"from profiles/{os.path.basename(tpath)} (rocprofv3 --pmc, own passes), timing live"}

@@ -128,13 +128,26 @@ def parse(asm_path):
     return kernels
 
 
+# 32-bit vector instructions that issue in ~2.5 cycles per wavefront (measured: scripts/microbench/valu_issue.hip ->
+# profiles/r03_valu_issue_costs.json); everything else -- all f64 instructions incl. compares / max / ldexp / fix-ups,
+# v_cndmask_b32 with its mask in a scalar register pair, compares that write a scalar mask, 64-bit moves / integer
+# instructions -- takes ~4.2 cycles, v_rcp_f64 / v_rsq_f64 ~16
+TWO_CYCLE_OPS = ("v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_xor_b32", "v_and_b32", "v_or_b32", "v_lshlrev_b32",
+                 "v_lshrrev_b32", "v_ashrrev_i32", "v_not_b32", "v_bfe_u32", "v_and_or_b32", "v_or3_b32", "v_add3_u32",
+                 "v_lshl_add_u32", "v_lshl_or_b32", "v_mul_u32_u24", "v_mad_u32_u24", "v_min_u32", "v_max_u32", "v_bfrev_b32")
+
+
 def summary(hist):
     cls = {k: v for k, v in hist.items() if not k.startswith("_ops:")}
     total = sum(cls.values())
     valu = sum(v for k, v in cls.items() if k.startswith("f64_") or k in ("cndmask", "mov", "int", "cmp_int"))
     f64_arith = sum(cls.get(k, 0) for k in ("f64_fma", "f64_mul", "f64_add", "f64_trans"))
     top = sorted(((k[5:], v) for k, v in hist.items() if k.startswith("_ops:")), key=lambda kv: -kv[1])[:40]
-    return {"total": total, "valu": valu, "f64_counted_by_pmc": f64_arith, "valu_not_f64_arith": valu - f64_arith,
+    two = sum(v for k, v in hist.items() if k.startswith("_ops:v_") and k[5:].split("_e")[0] in TWO_CYCLE_OPS)
+    other = valu - f64_arith
+    return {"total": total, "valu": valu, "f64_counted_by_pmc": f64_arith, "valu_not_f64_arith": other,
+            "valu_not_f64_arith_issue_split": {"about_2.5_cycles": two, "about_4.2_cycles": other - two,
+                                               "share_about_4.2_cycles": (other - two) / other if other else None},
             "classes": dict(sorted(cls.items(), key=lambda kv: -kv[1])), "top_opcodes": dict(top)}
 
 
