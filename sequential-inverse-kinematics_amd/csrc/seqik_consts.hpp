@@ -87,6 +87,9 @@ inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, Le
             } else {
                 sc.lb[j] = -1.0; sc.ub[j] = 1.0; sc.seed[j] = 0.0;
             }
+            // make_strictly_feasible's thresholds for rstep = 1e-10 (the same two operations the device function performs)
+            sc.thr_lb[j] = 1e-10 * fmax(1.0, fabs(sc.lb[j]));
+            sc.thr_ub[j] = 1e-10 * fmax(1.0, fabs(sc.ub[j]));
         }
         // inert entries of the start vector, made strictly feasible as scipy does, then the
         // partial sums of squares that ||x0 / sqrt(v)|| and ||x|| need (link order, from 0.0)

@@ -68,6 +68,19 @@ SEQIK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, 
 #define SEQIK_IEEE_DIV_SQRT 0
 #endif
 
+#ifndef SEQIK_FAST_PATHS
+#define SEQIK_FAST_PATHS 1   // wave-uniform fast paths, see "Wave-uniform fast paths" below; 0 = plain code (A/B)
+#endif
+// "does any active lane of this wavefront ...?" (one ballot; on the host: this lane)
+SEQIK_HD bool wave_any(bool c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(c) != 0ull;
+#else
+    return c;
+#endif
+}
+
 SEQIK_HD double div_(double a, double b)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !SEQIK_IEEE_DIV_SQRT
@@ -98,7 +111,9 @@ SEQIK_HD double sqrt_(double x)
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    return __builtin_amdgcn_class(x, 0x260) ? x : g;  // +-0 and +inf are their own square roots
+    // +-0 and +inf are their own square roots (the iteration makes NaN of them).  (A wave-uniform branch around the two
+    // selects was measured: 67 more branches split the blocks the scheduler works on, 12.15 -> 12.25 ms per step.)
+    return __builtin_amdgcn_class(x, 0x260) ? x : g;
 #else
     return sqrt(x);
 #endif
@@ -172,6 +187,8 @@ struct StageConst {
     double x_pre_sq;       // sum of squares of the (strictly feasible) seed entries in FRONT of the
                            // active links, accumulated in link order as acc = fma(x, x, acc) from 0.0
     double x_suf;          // (strictly feasible) seed entry of the last link
+    double thr_lb[2], thr_ub[2];  // 1e-10 * max(1, |lb|), 1e-10 * max(1, |ub|): make_strictly_feasible's thresholds at
+                                  // a frame start (constants of the leg; computed on the host with the same operations)
     int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
     int32_t pad_;
 };
@@ -273,6 +290,15 @@ SEQIK_HD double next_toward(double b, double toward)
 }
 
 SEQIK_HD bool is_finite(double x) { return (x - x) == 0.0; }
+
+// ---------------------------------------------------------------------------
+// Wave-uniform fast paths.  make_strictly_feasible and the finite-difference step of _numdiff spend most of their
+// instructions on what happens AT or BEYOND a bound (14 compares and 10 selects per strictly_feasible call); a point that
+// lies strictly inside its bounds comes back unchanged.  Since a wavefront issues an instruction whenever ANY of its lanes
+// needs it, the cheap test "is some lane of this wavefront not strictly inside?" (wave_any: one ballot) decides for the
+// whole wavefront whether the full logic runs; when it does, every lane runs it and gets the value it would have got
+// anyway.  Same values in both cases, so nothing changes in the bits.  SEQIK_FAST_PATHS=0 compiles the plain calls (A/B).
+// ---------------------------------------------------------------------------
 
 // out = in @ [R_axis(s, c) | (0, 0, tz)]   (one ikpy link frame appended on the right)
 template <int AXIS>
@@ -380,6 +406,22 @@ SEQIK_HD void cl_scaling(double x, double g, double lb, double ub, double &v, do
     v = 1.0; dv = 0.0;
     if (g < 0 && is_finite(ub)) { v = ub - x; dv = -1.0; }
     if (g > 0 && is_finite(lb)) { v = x - lb; dv = 1.0; }
+}
+
+// _numdiff.py: the nominal 2-point step, before _adjust_scheme_to_bounds
+SEQIK_HD double fd_step_nominal(double x)
+{
+    const double RSTEP = 1.4901161193847656e-08;
+    double sign = (x >= 0.0) ? 1.0 : -1.0;
+    return RSTEP * sign * fmax(1.0, fabs(x));
+}
+
+// does x + h leave [lb, ub]?  If not, _adjust_scheme_to_bounds('1-sided') leaves h alone: |h| <= the distance to the
+// bound it points at, hence `fitting` holds and `violated` does not (fd_step below returns the nominal step).
+SEQIK_HD bool fd_step_violates(double x, double h, double lb, double ub)
+{
+    const double xh = x + h;
+    return (xh < lb) || (xh > ub);
 }
 
 // _numdiff.py: 2-point step with _adjust_scheme_to_bounds('1-sided')
@@ -909,8 +951,17 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
                           const double *ub, double sa, double ca, double sb, double cb, double J[3][2])
 {
     using T = StageTraits<STAGE>;
+#if SEQIK_FAST_PATHS
+    double h_a = fd_step_nominal(x[0]), h_b = (T::NA == 2) ? fd_step_nominal(x[1]) : 0.0;
+    if (wave_any(fd_step_violates(x[0], h_a, lb[0], ub[0]) || (T::NA == 2 && fd_step_violates(x[1], h_b, lb[1], ub[1])))) {
+        h_a = fd_step(x[0], lb[0], ub[0]);
+        if constexpr (T::NA == 2) h_b = fd_step(x[1], lb[1], ub[1]);
+    }
+#else
+    double h_a = fd_step(x[0], lb[0], ub[0]), h_b = (T::NA == 2) ? fd_step(x[1], lb[1], ub[1]) : 0.0;
+#endif
     {
-        double h = fd_step(x[0], lb[0], ub[0]);
+        double h = h_a;
         double x1 = x[0] + h;
         double dx = x1 - x[0];
         double s1, c1, f1[3];
@@ -921,7 +972,7 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
         for (int i = 0; i < 3; ++i) J[i][0] = (f1[i] - f0[i]) * inv_dx;
     }
     if constexpr (T::NA == 2) {
-        double h = fd_step(x[1], lb[1], ub[1]);
+        double h = h_b;
         double x1 = x[1] + h;
         double dx = x1 - x[1];
         double s1, c1, f1[3];
@@ -984,7 +1035,13 @@ SEQIK_HD void fd_jacobian_pair(const StageProblem<STAGE> &P, const double *x, co
 {
     static_assert(StageTraits<STAGE>::NA == 2, "one active joint: nothing to split");
     const double xj = odd ? x[1] : x[0];
+#if SEQIK_FAST_PATHS
+    double h = fd_step_nominal(xj);
+    if (wave_any(fd_step_violates(xj, h, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0])))
+        h = fd_step(xj, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]);
+#else
     double h = fd_step(xj, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]);
+#endif
     double x1 = xj + h;
     double dx = x1 - xj;
     double s1, c1, f1[3];
@@ -1267,8 +1324,18 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 // accepted trial of the previous frame computed.  Unless make_strictly_feasible moves x (it sat
                 // within 1e-10 of a bound) the start residual is pe - new target -- the same operations on the same
                 // values as a fresh evaluation -- and the two sin/cos + the chain product are skipped.
+#if SEQIK_FAST_PATHS
+                // (further than the threshold from both bounds: make_strictly_feasible(rstep = 1e-10) returns x itself)
+                double xs0 = x[0], xs1 = x[1];
+                if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
+                               (x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))) {
+                    xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+                    xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                }
+#else
                 const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
                 const double xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+#endif
                 if (have_pe && xs0 == x[0] && xs1 == x[1]) {
 #pragma unroll
                     for (int i = 0; i < 3; ++i) f[i] = pe[i] - P.target[i];
@@ -1282,8 +1349,17 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 // sin / cos pairs (set by the trial that was accepted last, or by that solve's start evaluation);
                 // only the prefix frame has changed.  Unless make_strictly_feasible moves x the sin / cos need not be
                 // recomputed: the same function of the same argument gives the same bits.
+#if SEQIK_FAST_PATHS
+                double xs0 = x[0], xs1 = x[1];
+                if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
+                               (NA == 1 || ((x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))))) {
+                    xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
+                    if constexpr (NA == 2) xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                }
+#else
                 const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
                 const double xs1 = (NA == 2) ? strictly_feasible(x[1], lb[1], ub[1], 1e-10) : x[1];
+#endif
                 if (have_pe && xs0 == x[0] && xs1 == x[1]) {
                     residual_sc<STAGE>(P, sa, ca, sb, cb, f);
                 } else {
@@ -1378,8 +1454,19 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 }
                 SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                 double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n, pe_n[3] = {0.0, 0.0, 0.0};
+#if SEQIK_FAST_PATHS
+                // (a trial point strictly inside its bounds is what make_strictly_feasible(rstep = 0) returns for it)
+                x_new[0] = x[0] + step[0];
+                if constexpr (NA == 2) x_new[1] = x[1] + step[1];
+                if (wave_any(!((x_new[0] > lb[0]) && (x_new[0] < ub[0]) &&
+                               (NA == 1 || ((x_new[1] > lb[1]) && (x_new[1] < ub[1])))))) {
+                    x_new[0] = strictly_feasible(x_new[0], lb[0], ub[0], 0.0);
+                    if constexpr (NA == 2) x_new[1] = strictly_feasible(x_new[1], lb[1], ub[1], 0.0);
+                }
+#else
                 x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
                 if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);
+#endif
                 if constexpr (PAIRED)
                     eval_residual_pair<STAGE>(P, x_new[0], x_new[1], odd, f_new, sa_n, ca_n, sb_n, cb_n, (STAGE == 1) ? pe_n : nullptr);
                 else
