@@ -90,6 +90,9 @@ inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, Le
             // make_strictly_feasible's thresholds for rstep = 1e-10 (the same two operations the device function performs)
             sc.thr_lb[j] = 1e-10 * fmax(1.0, fabs(sc.lb[j]));
             sc.thr_ub[j] = 1e-10 * fmax(1.0, fabs(sc.ub[j]));
+            // ... and its replacement values for rstep = 0 (the device function's own next_toward)
+            sc.lb_in[j] = next_toward(sc.lb[j], sc.ub[j]);
+            sc.ub_in[j] = next_toward(sc.ub[j], sc.lb[j]);
         }
         // inert entries of the start vector, made strictly feasible as scipy does, then the
         // partial sums of squares that ||x0 / sqrt(v)|| and ||x|| need (link order, from 0.0)
@@ -144,6 +147,8 @@ inline void make_generic_consts(const SeqikLegParams &lp, GenericConst &gc)
     const double tz[GN] = {0.0, 0.0, 0.0, -lp.seg[0], 0.0, -lp.seg[1], -lp.seg[2]};
     for (int i = 0; i < GN; ++i) {
         generic_link_bounds(lp, i + 1, gc.lb[i], gc.ub[i]);
+        gc.lb_in[i] = next_toward(gc.lb[i], gc.ub[i]);
+        gc.ub_in[i] = next_toward(gc.ub[i], gc.lb[i]);
         gc.seed[i] = lp.seeds[18 + 1 + i];
         gc.tz[i] = tz[i];
     }

@@ -189,6 +189,8 @@ struct StageConst {
     double x_suf;          // (strictly feasible) seed entry of the last link
     double thr_lb[2], thr_ub[2];  // 1e-10 * max(1, |lb|), 1e-10 * max(1, |ub|): make_strictly_feasible's thresholds at
                                   // a frame start (constants of the leg; computed on the host with the same operations)
+    double lb_in[2], ub_in[2];    // next_toward(lb, ub), next_toward(ub, lb): where make_strictly_feasible(rstep = 0) puts
+                                  // a trial point that landed on / beyond a bound
     int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
     int32_t pad_;
 };
@@ -353,6 +355,34 @@ SEQIK_HD double strictly_feasible(double x, double lb, double ub, double rstep)
         xn = (rstep == 0.0) ? next_toward(lb, ub) : lb + rstep * fmax(1.0, fabs(lb));
     else if (active == 1)
         xn = (rstep == 0.0) ? next_toward(ub, lb) : ub - rstep * fmax(1.0, fabs(ub));
+    if (xn < lb || xn > ub) xn = 0.5 * (lb + ub);
+    return xn;
+}
+
+// make_strictly_feasible(rstep = 0) with the two replacement values precomputed (StageConst::lb_in / ub_in): 2 compares and
+// 4 selects instead of strictly_feasible()'s 28 instructions.  Same result: for lb < ub (validated before any launch) the
+// replacement values lie inside [lb, ub], so the final "outside the bounds -> midpoint" test of the general routine never
+// fires, and a NaN stays a NaN in both.
+SEQIK_HD double strictly_feasible0(double x, double lb, double ub, double lb_in, double ub_in)
+{
+    double xn = x;
+    if (x <= lb) xn = lb_in;
+    if (x >= ub) xn = ub_in;
+    return xn;
+}
+
+// make_strictly_feasible(rstep = 1e-10) with its thresholds precomputed (StageConst::thr_lb / thr_ub): the same operations
+// as strictly_feasible(x, lb, ub, 1e-10) minus the two max / multiply pairs
+SEQIK_HD double strictly_feasible_thr(double x, double lb, double ub, double thr_lb, double thr_ub)
+{
+    const double lower_dist = x - lb;
+    const double upper_dist = ub - x;
+    int active = 0;
+    if (is_finite(lb) && lower_dist <= fmin(upper_dist, thr_lb)) active = -1;
+    if (is_finite(ub) && upper_dist <= fmin(lower_dist, thr_ub)) active = 1;
+    double xn = x;
+    if (active == -1) xn = lb + thr_lb;
+    else if (active == 1) xn = ub - thr_ub;
     if (xn < lb || xn > ub) xn = 0.5 * (lb + ub);
     return xn;
 }
@@ -1329,8 +1359,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double xs0 = x[0], xs1 = x[1];
                 if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
                                (x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))) {
-                    xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
-                    xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                    xs0 = strictly_feasible_thr(x[0], lb[0], ub[0], sc.thr_lb[0], sc.thr_ub[0]);
+                    xs1 = strictly_feasible_thr(x[1], lb[1], ub[1], sc.thr_lb[1], sc.thr_ub[1]);
                 }
 #else
                 const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
@@ -1353,8 +1383,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double xs0 = x[0], xs1 = x[1];
                 if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
                                (NA == 1 || ((x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))))) {
-                    xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
-                    if constexpr (NA == 2) xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
+                    xs0 = strictly_feasible_thr(x[0], lb[0], ub[0], sc.thr_lb[0], sc.thr_ub[0]);
+                    if constexpr (NA == 2) xs1 = strictly_feasible_thr(x[1], lb[1], ub[1], sc.thr_lb[1], sc.thr_ub[1]);
                 }
 #else
                 const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
@@ -1455,14 +1485,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                 double x_new[2] = {0.0, 0.0}, f_new[3], sa_n, ca_n, sb_n, cb_n, pe_n[3] = {0.0, 0.0, 0.0};
 #if SEQIK_FAST_PATHS
-                // (a trial point strictly inside its bounds is what make_strictly_feasible(rstep = 0) returns for it)
-                x_new[0] = x[0] + step[0];
-                if constexpr (NA == 2) x_new[1] = x[1] + step[1];
-                if (wave_any(!((x_new[0] > lb[0]) && (x_new[0] < ub[0]) &&
-                               (NA == 1 || ((x_new[1] > lb[1]) && (x_new[1] < ub[1])))))) {
-                    x_new[0] = strictly_feasible(x_new[0], lb[0], ub[0], 0.0);
-                    if constexpr (NA == 2) x_new[1] = strictly_feasible(x_new[1], lb[1], ub[1], 0.0);
-                }
+                x_new[0] = strictly_feasible0(x[0] + step[0], lb[0], ub[0], sc.lb_in[0], sc.ub_in[0]);
+                if constexpr (NA == 2) x_new[1] = strictly_feasible0(x[1] + step[1], lb[1], ub[1], sc.lb_in[1], sc.ub_in[1]);
 #else
                 x_new[0] = strictly_feasible(x[0] + step[0], lb[0], ub[0], 0.0);
                 if constexpr (NA == 2) x_new[1] = strictly_feasible(x[1] + step[1], lb[1], ub[1], 0.0);

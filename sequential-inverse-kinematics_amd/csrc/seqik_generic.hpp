@@ -21,6 +21,7 @@ constexpr int GN = 7;  // active links
 
 struct GenericConst {
     double lb[GN], ub[GN];   // bounds in LINK order: roll, yaw, pitch, CTr_pitch, CTr_roll, FTi, TiTa
+    double lb_in[GN], ub_in[GN];  // next_toward(lb, ub), next_toward(ub, lb): make_strictly_feasible(rstep=0) replacements
     double seed[GN];         // initial_angles["stage_4"][1..7], applied positionally to the links
     double tz[GN];           // origin_translation z per link: 0, 0, 0, -coxa, 0, -femur, -tibia
     double tz_claw;          // -tarsus
@@ -523,13 +524,13 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h);
                 double x_new[GN], sn_n[GN], cs_n[GN], f_new[3];
                 if constexpr (GROUPED) {
-                    const double xj = strictly_feasible(pick7(x, jm) + pick7(step, jm), gc.lb[jm], gc.ub[jm], 0.0);
+                    const double xj = strictly_feasible0(pick7(x, jm) + pick7(step, jm), gc.lb[jm], gc.ub[jm], gc.lb_in[jm], gc.ub_in[jm]);
                     double s1, c1;
                     sincos_cw(xj, s1, c1);
                     group8_gather(xj, x_new); group8_gather(s1, sn_n); group8_gather(c1, cs_n);
                 } else {
                     for (int j = 0; j < GN; ++j) {
-                        x_new[j] = strictly_feasible(x[j] + step[j], gc.lb[j], gc.ub[j], 0.0);
+                        x_new[j] = strictly_feasible0(x[j] + step[j], gc.lb[j], gc.ub[j], gc.lb_in[j], gc.ub_in[j]);
                         sincos_cw(x_new[j], sn_n[j], cs_n[j]);
                     }
                 }
