@@ -118,6 +118,28 @@ SEQIK_HD double sqrt_(double x)
     return sqrt(x);
 #endif
 }
+// sqrt_ for arguments known to be positive, finite and normal (the Coleman-Li distances v = ub - x, x - lb or 1 of a strictly
+// feasible x): the iteration alone, without the two selects for +-0 / +inf.  Same bits as sqrt_ there (NaN stays NaN).
+#ifndef SEQIK_SQRT_POS
+#define SEQIK_SQRT_POS 1
+#endif
+SEQIK_HD double sqrt_pos_(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !SEQIK_IEEE_DIV_SQRT && SEQIK_SQRT_POS
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+#else
+    return sqrt_(x);
+#endif
+}
 enum : int { STATUS_NONE = -99 };
 
 // ---------------------------------------------------------------------------
@@ -1256,6 +1278,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     double coxa_end[3] = {0.0, 0.0, 0.0};  // stage 4 + FK only
     const int64_t t_first = CHUNKED ? io.t_begin : 0;
     int64_t t = t_first;
+    // (Tried and dropped: per-frame addresses as running pointers advanced with t instead of `base + t * stride` with
+    // run-time 64-bit strides -- 16 fewer vector instructions per stage, all v_mul_lo_u32 / v_mad_u64_u32 of the frame-start
+    // and frame-end blocks: 11.971 -> 11.967 ms per benchmark step.  Those blocks wait for memory; their arithmetic is free.)
     int pipe_spins = 0;  // PIPED: consecutive passes this lane sat out (watchdog only)
     double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
     bool have_pe = false;
@@ -1424,8 +1449,8 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             else { v[1] = 1.0; dv[1] = 0.0; }
             // d = sqrt_(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
             double d[2];
-            d[0] = sqrt_(v[0]);
-            d[1] = (NA == 2) ? sqrt_(v[1]) : 1.0;
+            d[0] = sqrt_pos_(v[0]);
+            d[1] = (NA == 2) ? sqrt_pos_(v[1]) : 1.0;
             if (first_pass) {
                 // Delta_0 = || x0 / sqrt_(v) || over ALL links (inert entries: v = 1)
                 double acc = sc.x_pre_sq;

@@ -494,7 +494,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             }
             if (first_pass) {
                 double acc = gc.x_pre_sq;
-                for (int j = 0; j < GN; ++j) { double tj = div_(x[j], sqrt_(v[j])); acc = fma_(tj, tj, acc); }
+                for (int j = 0; j < GN; ++j) { double tj = div_(x[j], sqrt_pos_(v[j])); acc = fma_(tj, tj, acc); }
                 acc = fma_(gc.x_suf, gc.x_suf, acc);
                 Delta = sqrt_(acc);
                 if (Delta == 0) Delta = 1.0;
@@ -508,9 +508,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 finished = true;
             } else {
                 double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
-                if constexpr (GROUPED) group8_gather(sqrt_(pick7(v, jm)) * 1.0, d);
+                if constexpr (GROUPED) group8_gather(sqrt_pos_(pick7(v, jm)) * 1.0, d);
                 for (int j = 0; j < GN; ++j) {
-                    if constexpr (!GROUPED) d[j] = sqrt_(v[j]) * 1.0;
+                    if constexpr (!GROUPED) d[j] = sqrt_pos_(v[j]) * 1.0;
                     diag_h[j] = g[j] * dv[j] * 1.0;
                     g_h[j] = d[j] * g[j];
                 }
