@@ -113,6 +113,33 @@
 #define L_SELS_6 L_SELS_2
 #define L_SELS_7 L_SELS_3
 
+// quarter-rate 32-bit integer multiply and the 64-bit multiply-add of address arithmetic
+#define L_MULLO(i) L_MULLO_##i
+#define L_MULLO_0 "v_mul_lo_u32 %8, %8, %9\n"
+#define L_MULLO_1 "v_mul_lo_u32 %9, %9, %10\n"
+#define L_MULLO_2 "v_mul_lo_u32 %10, %10, %11\n"
+#define L_MULLO_3 "v_mul_lo_u32 %11, %11, %12\n"
+#define L_MULLO_4 "v_mul_lo_u32 %12, %12, %13\n"
+#define L_MULLO_5 "v_mul_lo_u32 %13, %13, %14\n"
+#define L_MULLO_6 "v_mul_lo_u32 %14, %14, %15\n"
+#define L_MULLO_7 "v_mul_lo_u32 %15, %15, %8\n"
+// MIXED streams (2 instructions per line): does a 32-bit instruction issue in the shadow of an f64 one of the same wave /
+// of the other waves of the SIMD, or do the costs add?
+#define L_MIXADDU(i) L_FMA(i) L_ADDU(i)
+#define L_MIXCND(i) L_FMA(i) L_CND(i)
+#define L_MIXMOV64(i) L_FMA(i) L_MOV64X(i)
+#define L_MOV64X(i) L_MOV64X_##i
+#define L_MOV64X_0 "v_mov_b64 %1, %16\n"
+#define L_MOV64X_1 "v_mov_b64 %2, %16\n"
+#define L_MOV64X_2 "v_mov_b64 %3, %16\n"
+#define L_MOV64X_3 "v_mov_b64 %4, %16\n"
+#define L_MOV64X_4 "v_mov_b64 %5, %16\n"
+#define L_MOV64X_5 "v_mov_b64 %6, %16\n"
+#define L_MOV64X_6 "v_mov_b64 %7, %16\n"
+#define L_MOV64X_7 "v_mov_b64 %0, %16\n"
+#define L_MIXMULLO(i) L_FMA(i) L_MULLO(i)
+#define L_MIXCMP(i) L_FMA(i) L_CMP(i)
+
 DEFINE_KERNEL(k_fma, L_FMA)
 DEFINE_KERNEL(k_mul, L_MUL)
 DEFINE_KERNEL(k_add, L_ADD)
@@ -133,19 +160,31 @@ DEFINE_KERNEL(k_cmpu, L_CMPU)
 DEFINE_KERNEL(k_lshladd64, L_LSHLADD64)
 DEFINE_KERNEL(k_sel, L_SEL)
 DEFINE_KERNEL(k_sels, L_SELS)
+DEFINE_KERNEL(k_mullo, L_MULLO)
+DEFINE_KERNEL(k_mixaddu, L_MIXADDU)
+DEFINE_KERNEL(k_mixcnd, L_MIXCND)
+DEFINE_KERNEL(k_mixmov64, L_MIXMOV64)
+DEFINE_KERNEL(k_mixmullo, L_MIXMULLO)
+DEFINE_KERNEL(k_mixcmp, L_MIXCMP)
 
 typedef void (*kern_t)(double *, int, unsigned long long *);
 
 int main()
 {
-    struct { const char *name; kern_t k; } classes[] = {
-        {"v_fma_f64", k_fma}, {"v_mul_f64", k_mul}, {"v_add_f64", k_add}, {"v_rcp_f64", k_rcp}, {"v_rsq_f64", k_rsq},
-        {"v_max_f64", k_max}, {"v_cmp_lt_f64", k_cmp}, {"v_div_fixup_f64", k_fixup}, {"v_ldexp_f64", k_ldexp},
-        {"v_rndne_f64", k_rndne}, {"v_cmp_class_f64", k_class}, {"v_mov_b64", k_mov64}, {"v_mov_b32", k_mov32},
-        {"v_cndmask_b32", k_cnd}, {"v_add_u32", k_addu}, {"v_xor_b32", k_xor}, {"v_cmp_eq_u32", k_cmpu},
-        {"v_lshl_add_u64", k_lshladd64},
-        {"select of a double: v_cmp_lt_f64 vcc + 2 x v_cndmask_b32 (per instruction, 3 per select)", k_sel},
-        {"the same with the mask in an SGPR pair (VOP3)", k_sels}};
+    struct { const char *name; kern_t k; double per_line; } classes[] = {
+        {"v_fma_f64", k_fma, 1.0}, {"v_mul_f64", k_mul, 1.0}, {"v_add_f64", k_add, 1.0}, {"v_rcp_f64", k_rcp, 1.0}, {"v_rsq_f64", k_rsq, 1.0},
+        {"v_max_f64", k_max, 1.0}, {"v_cmp_lt_f64", k_cmp, 1.0}, {"v_div_fixup_f64", k_fixup, 1.0}, {"v_ldexp_f64", k_ldexp, 1.0},
+        {"v_rndne_f64", k_rndne, 1.0}, {"v_cmp_class_f64", k_class, 1.0}, {"v_mov_b64", k_mov64, 1.0}, {"v_mov_b32", k_mov32, 1.0},
+        {"v_cndmask_b32", k_cnd, 1.0}, {"v_add_u32", k_addu, 1.0}, {"v_xor_b32", k_xor, 1.0}, {"v_cmp_eq_u32", k_cmpu, 1.0},
+        {"v_lshl_add_u64", k_lshladd64, 1.0},
+        {"select of a double: v_cmp_lt_f64 vcc + 2 x v_cndmask_b32 (per instruction, 3 per select)", k_sel, 3.0},
+        {"the same with the mask in an SGPR pair (VOP3)", k_sels, 3.0},
+        {"v_mul_lo_u32", k_mullo, 1.0},
+        {"MIX v_fma_f64 + v_add_u32 (per instruction, 2 per line)", k_mixaddu, 2.0},
+        {"MIX v_fma_f64 + v_cndmask_b32 (per instruction)", k_mixcnd, 2.0},
+        {"MIX v_fma_f64 + v_mov_b64 (per instruction)", k_mixmov64, 2.0},
+        {"MIX v_fma_f64 + v_mul_lo_u32 (per instruction)", k_mixmullo, 2.0},
+        {"MIX v_fma_f64 + v_cmp_lt_f64 (per instruction)", k_mixcmp, 2.0}};
     hipDeviceProp_t prop;
     (void)hipGetDeviceProperties(&prop, 0);
     const int simds = prop.multiProcessorCount * 4;
@@ -173,7 +212,7 @@ int main()
                 (void)hipMemcpy(h_clk, d_clk, 16, hipMemcpyDeviceToHost);
                 if (ms < best) { best = ms; ghz = (double)h_clk[0] / (double)h_clk[1] * 0.1; }
             }
-            const double per_line = (c >= sizeof(classes) / sizeof(classes[0]) - 2) ? 3.0 : 1.0;
+            const double per_line = classes[c].per_line;
             const double cycles = best * 1e-3 * ghz * 1e9 * simds / ((double)waves * iters * 256.0 * per_line);
             printf("%s\"waves_per_simd_%d\": {\"cycles_per_inst\": %.2f, \"ms\": %.3f, \"clock_GHz\": %.3f}", wps > 1 ? ", " : "", wps, cycles, best, ghz);
         }
