@@ -93,6 +93,9 @@ inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, Le
             // ... and its replacement values for rstep = 0 (the device function's own next_toward)
             sc.lb_in[j] = next_toward(sc.lb[j], sc.ub[j]);
             sc.ub_in[j] = next_toward(sc.ub[j], sc.lb[j]);
+            // CL_scaling_vector's `isfinite(bound)` folded into the comparand of the gradient's sign test
+            sc.gate_lb[j] = is_finite(sc.lb[j]) ? 0.0 : __builtin_nan("");
+            sc.gate_ub[j] = is_finite(sc.ub[j]) ? 0.0 : __builtin_nan("");
         }
         // inert entries of the start vector, made strictly feasible as scipy does, then the
         // partial sums of squares that ||x0 / sqrt(v)|| and ||x|| need (link order, from 0.0)
@@ -149,6 +152,8 @@ inline void make_generic_consts(const SeqikLegParams &lp, GenericConst &gc)
         generic_link_bounds(lp, i + 1, gc.lb[i], gc.ub[i]);
         gc.lb_in[i] = next_toward(gc.lb[i], gc.ub[i]);
         gc.ub_in[i] = next_toward(gc.ub[i], gc.lb[i]);
+        gc.gate_lb[i] = is_finite(gc.lb[i]) ? 0.0 : __builtin_nan("");
+        gc.gate_ub[i] = is_finite(gc.ub[i]) ? 0.0 : __builtin_nan("");
         gc.seed[i] = lp.seeds[18 + 1 + i];
         gc.tz[i] = tz[i];
     }

@@ -213,6 +213,8 @@ struct StageConst {
                                   // a frame start (constants of the leg; computed on the host with the same operations)
     double lb_in[2], ub_in[2];    // next_toward(lb, ub), next_toward(ub, lb): where make_strictly_feasible(rstep = 0) puts
                                   // a trial point that landed on / beyond a bound
+    double gate_lb[2], gate_ub[2];  // 0.0 where the bound is finite, NaN where it is not: `g > gate_lb` is
+                                    // `g > 0 && isfinite(lb)` of CL_scaling_vector in one compare (cl_scaling_gated)
     int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
     int32_t pad_;
 };
@@ -458,6 +460,16 @@ SEQIK_HD void cl_scaling(double x, double g, double lb, double ub, double &v, do
     v = 1.0; dv = 0.0;
     if (g < 0 && is_finite(ub)) { v = ub - x; dv = -1.0; }
     if (g > 0 && is_finite(lb)) { v = x - lb; dv = 1.0; }
+}
+
+// the same with the finiteness of the bounds folded into the comparands (StageConst::gate_lb / gate_ub: a comparison with
+// NaN is false, as `isfinite(bound)` would make the conjunction): two compares instead of two compares, two subtractions
+// and two more compares
+SEQIK_HD void cl_scaling_gated(double x, double g, double lb, double ub, double gate_lb, double gate_ub, double &v, double &dv)
+{
+    v = 1.0; dv = 0.0;
+    if (g < gate_ub) { v = ub - x; dv = -1.0; }
+    if (g > gate_lb) { v = x - lb; dv = 1.0; }
 }
 
 // _numdiff.py: the nominal 2-point step, before _adjust_scheme_to_bounds
@@ -1444,8 +1456,13 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             for (int j = 0; j < 2; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], J[0][j] * f[0]));
             }
+#if SEQIK_FAST_PATHS
+            cl_scaling_gated(x[0], g[0], lb[0], ub[0], sc.gate_lb[0], sc.gate_ub[0], v[0], dv[0]);
+            if constexpr (NA == 2) cl_scaling_gated(x[1], g[1], lb[1], ub[1], sc.gate_lb[1], sc.gate_ub[1], v[1], dv[1]);
+#else
             cl_scaling(x[0], g[0], lb[0], ub[0], v[0], dv[0]);
             if constexpr (NA == 2) cl_scaling(x[1], g[1], lb[1], ub[1], v[1], dv[1]);
+#endif
             else { v[1] = 1.0; dv[1] = 0.0; }
             // d = sqrt_(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
             double d[2];

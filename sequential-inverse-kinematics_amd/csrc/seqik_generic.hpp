@@ -22,6 +22,7 @@ constexpr int GN = 7;  // active links
 struct GenericConst {
     double lb[GN], ub[GN];   // bounds in LINK order: roll, yaw, pitch, CTr_pitch, CTr_roll, FTi, TiTa
     double lb_in[GN], ub_in[GN];  // next_toward(lb, ub), next_toward(ub, lb): make_strictly_feasible(rstep=0) replacements
+    double gate_lb[GN], gate_ub[GN];  // 0.0 / NaN: isfinite(bound) folded into the sign test of the gradient (cl_scaling_gated)
     double seed[GN];         // initial_angles["stage_4"][1..7], applied positionally to the links
     double tz[GN];           // origin_translation z per link: 0, 0, 0, -coxa, 0, -femur, -tibia
     double tz_claw;          // -tarsus
@@ -490,7 +491,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             }
             for (int j = 0; j < GN; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
-                cl_scaling(x[j], g[j], gc.lb[j], gc.ub[j], v[j], dv[j]);
+                cl_scaling_gated(x[j], g[j], gc.lb[j], gc.ub[j], gc.gate_lb[j], gc.gate_ub[j], v[j], dv[j]);
             }
             if (first_pass) {
                 double acc = gc.x_pre_sq;
