@@ -12,8 +12,9 @@
 
 // OP(i): one instruction of the class on register set i.  d[i] are doubles (v[..:..]), u[i] 32-bit, dd are outputs.
 #define DEFINE_KERNEL(NAME, ASM_LINE)                                                                                   \
-    __global__ void __launch_bounds__(64) NAME(double *out, int iters, unsigned long long *clk)                        \
+    __global__ void __launch_bounds__(64) NAME(double *out, int iters, unsigned long long *clk, int active)           \
     {                                                                                                                   \
+        if ((int)threadIdx.x >= active) return;   /* sparse-EXEC runs: only lanes [0, active) execute */               \
         double d0 = 1.0 + threadIdx.x * 1e-9, d1 = 1.1, d2 = 1.2, d3 = 1.3, d4 = 1.4, d5 = 1.5, d6 = 1.6, d7 = 1.7;     \
         double e = 1.000000001 + blockIdx.x * 1e-12, f = 1e-9;                                                          \
         unsigned u0 = threadIdx.x, u1 = 1, u2 = 2, u3 = 3, u4 = 4, u5 = 5, u6 = 6, u7 = 7;                              \
@@ -167,7 +168,7 @@ DEFINE_KERNEL(k_mixmov64, L_MIXMOV64)
 DEFINE_KERNEL(k_mixmullo, L_MIXMULLO)
 DEFINE_KERNEL(k_mixcmp, L_MIXCMP)
 
-typedef void (*kern_t)(double *, int, unsigned long long *);
+typedef void (*kern_t)(double *, int, unsigned long long *, int);
 
 int main()
 {
@@ -204,7 +205,7 @@ int main()
             double ghz = 0.0;
             for (int rep = 0; rep < 3; ++rep) {
                 (void)hipEventRecord(e0);
-                hipLaunchKernelGGL(classes[c].k, dim3(waves), dim3(64), 0, 0, d_out, iters, d_clk);
+                hipLaunchKernelGGL(classes[c].k, dim3(waves), dim3(64), 0, 0, d_out, iters, d_clk, 64);
                 (void)hipEventRecord(e1);
                 (void)hipEventSynchronize(e1);
                 float ms;
@@ -217,6 +218,31 @@ int main()
             printf("%s\"waves_per_simd_%d\": {\"cycles_per_inst\": %.2f, \"ms\": %.3f, \"clock_GHz\": %.3f}", wps > 1 ? ", " : "", wps, cycles, best, ghz);
         }
         printf("}");
+    }
+    printf("}, \"sparse_exec_3_waves_per_simd\": {");
+    {   // does an instruction cost less when only some lanes are active?  (lanes [0, active) of every wave)
+        struct { const char *name; kern_t k; double per_line; } sp[] = {{"v_fma_f64", k_fma, 1.0}, {"v_mul_f64", k_mul, 1.0}, {"v_add_u32", k_addu, 1.0},
+                                                                      {"v_mov_b64", k_mov64, 1.0}, {"v_rcp_f64", k_rcp, 1.0}, {"v_cmp_lt_f64", k_cmp, 1.0}};
+        const int act[] = {1, 8, 16, 17, 32, 33, 48, 64};
+        for (size_t c = 0; c < sizeof(sp) / sizeof(sp[0]); ++c) {
+            printf("%s\"%s\": {", c ? ", " : "", sp[c].name);
+            for (size_t ai = 0; ai < sizeof(act) / sizeof(act[0]); ++ai) {
+                const int waves = simds * 3;
+                float best = 1e30f; double ghz = 0.0;
+                for (int rep = 0; rep < 3; ++rep) {
+                    (void)hipEventRecord(e0);
+                    hipLaunchKernelGGL(sp[c].k, dim3(waves), dim3(64), 0, 0, d_out, iters, d_clk, act[ai]);
+                    (void)hipEventRecord(e1);
+                    (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    (void)hipMemcpy(h_clk, d_clk, 16, hipMemcpyDeviceToHost);
+                    if (ms < best) { best = ms; ghz = (double)h_clk[0] / (double)h_clk[1] * 0.1; }
+                }
+                const double cycles = best * 1e-3 * ghz * 1e9 * simds / ((double)waves * iters * 256.0 * sp[c].per_line);
+                printf("%s\"active_%d\": %.2f", ai ? ", " : "", act[ai], cycles);
+            }
+            printf("}");
+        }
     }
     printf("}}\n");
     return 0;
