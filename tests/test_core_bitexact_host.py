@@ -113,3 +113,35 @@ def test_core_equals_oracle_on_random_legs_and_nasty_targets(oracle, host_harnes
         assert np.isfinite(o["angles"]).all() and np.isfinite(o["fk"]).all()
         assert (o["angles"] >= b[:, 0]).all() and (o["angles"] <= b[:, 1]).all()
         _cmp(host_harness.run(pose, seg, b, seeds), o)
+
+
+def _unbound_some_joints(rng, b):
+    """IKPy links without limits have bounds (-inf, inf) (`ikpy.link.URDFLink` default) and scipy treats one-sided
+    limits too: open some sides of some joints of a made-up leg."""
+    b = b.copy()
+    for j in range(7):
+        kind = rng.integers(0, 4)
+        if kind == 1:
+            b[j, 0] = -np.inf
+        elif kind == 2:
+            b[j, 1] = np.inf
+        elif kind == 3:
+            b[j] = (-np.inf, np.inf)
+    return b
+
+
+def test_core_equals_oracle_with_open_and_one_sided_limits(oracle, host_harness):
+    """Joints without limits / with a limit on one side only: the finiteness tests of CL_scaling_vector,
+    make_strictly_feasible and the finite-difference step (folded into per-leg constants in the kernel) against the
+    oracle's isfinite() calls."""
+    from conftest import random_leg_case
+    rng = np.random.default_rng(4711)
+    opened = 0
+    for _ in range(48):
+        pose, seg, b, seeds = random_leg_case(rng, 24)
+        b = _unbound_some_joints(rng, b)
+        opened += int(np.isinf(b).sum())
+        o = oracle.seq_leg(pose, seg, b, seeds)
+        assert np.isfinite(o["angles"]).all() and np.isfinite(o["fk"]).all()
+        _cmp(host_harness.run(pose, seg, b, seeds), o)
+    assert opened > 100

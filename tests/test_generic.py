@@ -27,6 +27,28 @@ def test_generic_core_equals_oracle_and_reaches_the_reference_claw(oracle, host_
     assert (got["angles"] >= b[:, 0]).all() and (got["angles"] <= b[:, 1]).all()
 
 
+def test_generic_core_equals_oracle_with_open_and_one_sided_limits(oracle, host_harness):
+    """Some joints without limits or with one limit only (IKPy's default bounds are (-inf, inf)): the kernel code folds
+    isfinite(bound) into per-leg constants (GenericConst::gate_lb / gate_ub), the oracle calls isfinite()."""
+    z = load_golden("generic_rf_100")
+    pose, seg, b, seeds = _leg(z, "RF")
+    rng = np.random.default_rng(99)
+    for _ in range(4):
+        bb = b.copy()
+        for j in rng.choice(7, 4, replace=False):
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                bb[j, 0] = -np.inf
+            elif kind == 1:
+                bb[j, 1] = np.inf
+            else:
+                bb[j] = (-np.inf, np.inf)
+        ref = oracle.generic_leg(pose[:30], seg, bb, seeds[18:27])
+        got = host_harness.run_generic(pose[:30], seg, bb, seeds)
+        for k in ("angles", "fk", "status", "nfev"):
+            assert np.array_equal(got[k], ref[k]), k
+
+
 def test_generic_continuation(oracle, host_harness):
     z = load_golden("generic_rf_100")
     pose, seg, b, seeds = _leg(z, "RF")

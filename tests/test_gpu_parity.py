@@ -280,6 +280,39 @@ def test_random_legs_and_nasty_targets_bit_for_bit(lib, oracle):
             assert (out["angles"][0, i] >= b[:, 0]).all() and (out["angles"][0, i] <= b[:, 1]).all()
 
 
+def test_open_and_one_sided_joint_limits_bit_for_bit(lib, oracle):
+    """Joints without limits (IKPy's default bounds are (-inf, inf)) or with a limit on one side only, 8 different legs
+    per launch, lane per chain and stage pipeline: HIP == oracle bit for bit.  The kernel folds isfinite(bound) into
+    per-leg constants (StageConst::gate_lb / gate_ub: NaN comparands); here those constants are NaN."""
+    from conftest import random_leg_case
+    rng = np.random.default_rng(1234)
+    for rep in range(6):
+        cases = []
+        for _ in range(8):
+            p, seg, b, seeds = random_leg_case(rng, 32)
+            b = b.copy()
+            for j in range(7):
+                kind = rng.integers(0, 4)
+                if kind == 1:
+                    b[j, 0] = -np.inf
+                elif kind == 2:
+                    b[j, 1] = np.inf
+                elif kind == 3:
+                    b[j] = (-np.inf, np.inf)
+            cases.append((p, seg, b, seeds))
+        pose = np.stack([c[0] for c in cases])[None]
+        params = [lib.leg_params_from_arrays(c[1], c[2], c[3]) for c in cases]
+        out = lib.solve_seq(pose, params, want_fk=True, want_diag=(rep % 2 == 0))
+        assert np.isfinite(out["angles"]).all() and np.isfinite(out["fk"]).all()
+        for i, (p, seg, b, seeds) in enumerate(cases):
+            ref = oracle.seq_leg(p, seg, b, seeds)
+            assert np.array_equal(out["angles"][0, i], ref["angles"])
+            assert np.array_equal(out["fk"][0, i], ref["fk"])
+            if rep % 2 == 0:
+                assert np.array_equal(out["status"][0, i], ref["status"])
+                assert np.array_equal(out["nfev"][0, i], ref["nfev"])
+
+
 @pytest.mark.parametrize("lanes", [1, 3, 5, 8, 9, 64])
 def test_lanes_per_wave_does_not_change_results(lib, lanes):
     """The lane -> chain mapping (SeqikOptions.reserved[0]) only decides where a chain runs: 23 sequences x 6
