@@ -24,6 +24,9 @@ import torch  # noqa: E402
 
 from seqikpy_amd import _lib, data, synthetic, utils  # noqa: E402
 
+# conditional parts of a pass whose executions the diagnostic build counts (seqik_core.hpp CNT_*)
+COUNTED = ["new_solve", "feasible_slow_path", "start_evaluation", "body", "first_pass_radius", "trust_region_and_trial", "reflective",
+           "accept", "finished"]
 BLOCKS = ["loop", "new_solve", "fd_jacobian", "scaling_gtol", "tr_step", "in_bounds", "reflective", "trial_eval", "post_trial",
           "finished", "pipe_wait"]
 
@@ -68,8 +71,14 @@ def main():
         torch.cuda.synchronize()
     run()
     lib.seqik_debug_block_cycles(None, 1)
+    have_entries = hasattr(lib, "seqik_debug_block_entries")
+    ebuf = (ctypes.c_ulonglong * (4 * 2 * len(COUNTED)))()
+    if have_entries:
+        lib.seqik_debug_block_entries(None, 1)
     run()
     lib.seqik_debug_block_cycles(buf, 1)
+    if have_entries:
+        lib.seqik_debug_block_entries(ebuf, 1)
     c = np.array(list(buf), dtype=np.float64).reshape(4, len(BLOCKS) + 1)
     total = c[:, :-1].sum()
     out = {"variant": a.variant, "fk": not a.no_fk, "staged": a.staged, "replicated": a.replicate, "leg_frames": S * 6 * T, "kernel": "fused lane per chain" if a.pipeline == 1 else "stage pipeline",
@@ -78,6 +87,13 @@ def main():
         cyc, passes = c[st, :-1], c[st, -1]
         out["stages"][str(st + 1)] = {"wave_passes": passes, "cycles_per_pass": cyc.sum() / max(passes, 1),
                                       "share": {b: round(float(v / cyc.sum()), 4) for b, v in zip(BLOCKS, cyc) if v}}
+    if have_entries:
+        e = np.array(list(ebuf), dtype=np.float64).reshape(4, 2, len(COUNTED))
+        for st in range(4):
+            passes = max(c[st, -1], 1)
+            out["stages"][str(st + 1)]["entries_per_pass"] = {n: round(float(e[st, 0, i] / passes), 4) for i, n in enumerate(COUNTED)}
+            out["stages"][str(st + 1)]["active_lanes_per_entry"] = {n: round(float(e[st, 1, i] / max(e[st, 0, i], 1)), 2)
+                                                                    for i, n in enumerate(COUNTED)}
     allc = c[:, :-1].sum(0)
     out["all_stages_share"] = {b: round(float(v / total), 4) for b, v in zip(BLOCKS, allc) if v}
     print(json.dumps(out))

@@ -96,6 +96,17 @@ inline void make_leg_consts(const SeqikLegParams &lp, const SeqikAffine *aff, Le
             // CL_scaling_vector's `isfinite(bound)` folded into the comparand of the gradient's sign test
             sc.gate_lb[j] = is_finite(sc.lb[j]) ? 0.0 : __builtin_nan("");
             sc.gate_ub[j] = is_finite(sc.ub[j]) ? 0.0 : __builtin_nan("");
+            // where make_strictly_feasible(rstep = 1e-10) puts a warm start that lies within the threshold of a limit
+            // (strictly_feasible_thr's operations, midpoint rule included), and the sin / cos there
+            sc.thr_lb_g[j] = is_finite(sc.lb[j]) ? sc.thr_lb[j] : __builtin_nan("");
+            sc.thr_ub_g[j] = is_finite(sc.ub[j]) ? sc.thr_ub[j] : __builtin_nan("");
+            double lo = sc.lb[j] + sc.thr_lb[j], hi = sc.ub[j] - sc.thr_ub[j];
+            if (lo < sc.lb[j] || lo > sc.ub[j]) lo = 0.5 * (sc.lb[j] + sc.ub[j]);
+            if (hi < sc.lb[j] || hi > sc.ub[j]) hi = 0.5 * (sc.lb[j] + sc.ub[j]);
+            sc.lb_out[j] = lo;
+            sc.ub_out[j] = hi;
+            sincos_cw(lo, sc.sc_lb[j][0], sc.sc_lb[j][1]);
+            sincos_cw(hi, sc.sc_ub[j][0], sc.sc_ub[j][1]);
         }
         // inert entries of the start vector, made strictly feasible as scipy does, then the
         // partial sums of squares that ||x0 / sqrt(v)|| and ||x|| need (link order, from 0.0)

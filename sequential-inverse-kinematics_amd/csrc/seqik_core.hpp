@@ -153,8 +153,30 @@ enum : int { STATUS_NONE = -99 };
 #endif
 enum : int { BLK_LOOP = 0, BLK_NEW_SOLVE, BLK_FD_JACOBIAN, BLK_SCALING, BLK_TR_STEP, BLK_IN_BOUNDS, BLK_REFLECTIVE,
              BLK_TRIAL_EVAL, BLK_POST_TRIAL, BLK_FINISHED, BLK_PIPE_WAIT, BLK_COUNT };
+// conditional parts of a pass whose executions are counted (wave level: how often a wavefront went through them; lane
+// level: how many lanes were active when it did)
+enum : int { CNT_NEW_SOLVE = 0, CNT_FEASIBLE_SLOW, CNT_START_EVAL, CNT_BODY, CNT_FIRST_PASS, CNT_TR, CNT_REFLECTIVE, CNT_ACCEPT,
+             CNT_FINISHED, CNT_COUNT };
 #if SEQIK_BLOCK_CYCLES && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long seqik_block_cycles[4][BLK_COUNT + 1];  // [..][BLK_COUNT] = passes (wave level)
+extern __device__ unsigned long long seqik_block_entries[4][2 * CNT_COUNT]; // [..][c] wave entries, [..][CNT_COUNT + c] lanes
+// per-wavefront tallies in LDS (a counter incremented inside a divergent branch would otherwise become one per lane)
+__device__ __forceinline__ unsigned long long *blk_tally()
+{
+    __shared__ unsigned long long tally[16][2 * CNT_COUNT];
+    return tally[threadIdx.x >> 6];
+}
+template <int C>
+__device__ __forceinline__ void blk_count()
+{
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)m) - 1) {
+        unsigned long long *t = blk_tally();
+        t[C] += 1;
+        t[CNT_COUNT + C] += (unsigned long long)__popcll(m);
+    }
+}
+#define SEQIK_BLK_COUNT(c) blk_count<c>()
 // (every stamp names the block that ENDS there, so each accumulator is indexed by a constant and lives in scalar
 // registers: an array indexed by a "current block" variable went to scratch memory, and the s_waitcnt vmcnt(0) of its
 // read-modify-write then charged the drain of the stores just issued to whatever stamp came next)
@@ -166,6 +188,11 @@ struct BlockClock {
 #pragma unroll
         for (int i = 0; i < BLK_COUNT; ++i) acc[i] = 0;
         passes = 0;
+        if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)__ballot(1)) - 1) {
+            unsigned long long *t = blk_tally();
+#pragma unroll
+            for (int i = 0; i < 2 * CNT_COUNT; ++i) t[i] = 0;
+        }
         last = __builtin_amdgcn_s_memtime();
     }
     template <int BLK>
@@ -184,6 +211,9 @@ struct BlockClock {
 #pragma unroll
             for (int i = 0; i < BLK_COUNT; ++i) atomicAdd(&seqik_block_cycles[stage - 1][i], acc[i]);
             atomicAdd(&seqik_block_cycles[stage - 1][BLK_COUNT], passes);
+            const unsigned long long *t = blk_tally();
+#pragma unroll
+            for (int i = 0; i < 2 * CNT_COUNT; ++i) atomicAdd(&seqik_block_entries[stage - 1][i], t[i]);
         }
     }
 };
@@ -196,6 +226,9 @@ struct BlockClock {
 #define SEQIK_BLK_END_OF(b) ((void)0)
 #define SEQIK_BLK_PASS() ((void)0)
 #define SEQIK_BLK_END(stage) ((void)0)
+#endif
+#ifndef SEQIK_BLK_COUNT
+#define SEQIK_BLK_COUNT(c) ((void)0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -215,6 +248,13 @@ struct StageConst {
                                   // a trial point that landed on / beyond a bound
     double gate_lb[2], gate_ub[2];  // 0.0 where the bound is finite, NaN where it is not: `g > gate_lb` is
                                     // `g > 0 && isfinite(lb)` of CL_scaling_vector in one compare (cl_scaling_gated)
+    // A warm start that lies within thr of a bound -- a joint the previous frame left pinned on its limit -- is moved by
+    // make_strictly_feasible(rstep = 1e-10) to a constant of the leg: lb + thr_lb or ub - thr_ub (the midpoint of tight
+    // limits).  That constant and its sin / cos (computed on the host with this file's sincos_cw) are kept here, so such
+    // a frame start costs selects instead of two sin / cos evaluations (strictly_feasible_pinned, run_stage).
+    double lb_out[2], ub_out[2];
+    double thr_lb_g[2], thr_ub_g[2];  // thr_lb / thr_ub, NaN where the bound is infinite (the comparison is then false)
+    double sc_lb[2][2], sc_ub[2][2];  // [joint][sin, cos] of lb_out / ub_out
     int32_t max_nfev;      // 100 * number of links of the stage chain (4, 6, 8, 9)
     int32_t pad_;
 };
@@ -408,6 +448,22 @@ SEQIK_HD double strictly_feasible_thr(double x, double lb, double ub, double thr
     if (active == -1) xn = lb + thr_lb;
     else if (active == 1) xn = ub - thr_ub;
     if (xn < lb || xn > ub) xn = 0.5 * (lb + ub);
+    return xn;
+}
+
+// The same result from the per-leg constants of StageConst (lb_out / ub_out hold the replacement values with the
+// midpoint rule applied; `a <= fmin(b, c)` is `a <= b && a <= c`; an infinite bound has a NaN threshold, which makes its
+// comparison false as `isfinite(bound) &&` does).  side: -1 / +1 = moved to the lower / upper replacement value, 0 = x
+// is returned as it is.  Only for x inside [lb, ub] (the general routine sends an x outside to the midpoint).
+SEQIK_HD double strictly_feasible_pinned(double x, double lb, double ub, double thr_lb_g, double thr_ub_g, double lb_out,
+                                         double ub_out, int &side)
+{
+    const double lower_dist = x - lb;
+    const double upper_dist = ub - x;
+    double xn = x;
+    side = 0;
+    if (lower_dist <= upper_dist && lower_dist <= thr_lb_g) { xn = lb_out; side = -1; }
+    if (upper_dist <= lower_dist && upper_dist <= thr_ub_g) { xn = ub_out; side = 1; }
     return xn;
 }
 
@@ -1352,6 +1408,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         }
         if constexpr (PIPED) SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
         if (new_solve) {
+            SEQIK_BLK_COUNT(CNT_NEW_SOLVE);
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + STAGE * io.pose_row;
             if constexpr (STAGE > 1) {
@@ -1386,56 +1443,69 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 P.target[1] = kp[1] - org[1];
                 P.target[2] = kp[2] - org[2];
             }
-            if constexpr (STAGE == 1) {
-                // Stage 1 has no frame-dependent prefix: the chain position at the warm start x is the one the last
-                // accepted trial of the previous frame computed.  Unless make_strictly_feasible moves x (it sat
-                // within 1e-10 of a bound) the start residual is pe - new target -- the same operations on the same
-                // values as a fresh evaluation -- and the two sin/cos + the chain product are skipped.
 #if SEQIK_FAST_PATHS
-                // (further than the threshold from both bounds: make_strictly_feasible(rstep = 1e-10) returns x itself)
-                double xs0 = x[0], xs1 = x[1];
-                if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
-                               (x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))) {
-                    xs0 = strictly_feasible_thr(x[0], lb[0], ub[0], sc.thr_lb[0], sc.thr_ub[0]);
-                    xs1 = strictly_feasible_thr(x[1], lb[1], ub[1], sc.thr_lb[1], sc.thr_ub[1]);
-                }
-#else
-                const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
-                const double xs1 = strictly_feasible(x[1], lb[1], ub[1], 1e-10);
-#endif
-                if (have_pe && xs0 == x[0] && xs1 == x[1]) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) f[i] = pe[i] - P.target[i];
-                } else {
-                    x[0] = xs0; x[1] = xs1;
-                    eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb, pe);
-                    have_pe = true;
-                }
+            // scipy makes the start point strictly feasible (make_strictly_feasible, rstep = 1e-10) and evaluates the
+            // residual there.  Three cases, same values in each:
+            //  * first frame of the chain (have_pe false, every lane of the wave at once): the general routine;
+            //  * the warm start lies further than the threshold from its limits: it is not moved, its sin / cos are the
+            //    ones the last accepted trial (or start evaluation) of the previous frame left in sa .. cb, and in stage 1,
+            //    which has no frame-dependent prefix, so is the chain position pe;
+            //  * a joint the previous frame left pinned on a limit: it is moved to a constant of the leg whose sin / cos
+            //    the host computed (StageConst::sc_lb / sc_ub) -- selects instead of sin / cos evaluations.  On the
+            //    benchmark's iid poses some lane of a wavefront is in this case in 30-60 % of its passes
+            //    (profiles/r03_block_entries_*.json).
+            if (!have_pe) {
+                SEQIK_BLK_COUNT(CNT_START_EVAL);
+                x[0] = strictly_feasible_thr(x[0], lb[0], ub[0], sc.thr_lb[0], sc.thr_ub[0]);
+                if constexpr (NA == 2) x[1] = strictly_feasible_thr(x[1], lb[1], ub[1], sc.thr_lb[1], sc.thr_ub[1]);
+                eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb, (STAGE == 1) ? pe : nullptr);
+                have_pe = true;  // (stages 2-4 use the flag for "sa .. cb belong to x")
             } else {
-                // Stages 2-4: the warm start x is the previous frame's solution and (sa, ca, sb, cb) are still its
-                // sin / cos pairs (set by the trial that was accepted last, or by that solve's start evaluation);
-                // only the prefix frame has changed.  Unless make_strictly_feasible moves x the sin / cos need not be
-                // recomputed: the same function of the same argument gives the same bits.
-#if SEQIK_FAST_PATHS
+                // (x is a result of this solver here: inside its limits)
                 double xs0 = x[0], xs1 = x[1];
+                int side0 = 0, side1 = 0;
                 if (wave_any(!((x[0] - lb[0] > sc.thr_lb[0]) && (ub[0] - x[0] > sc.thr_ub[0]) &&
                                (NA == 1 || ((x[1] - lb[1] > sc.thr_lb[1]) && (ub[1] - x[1] > sc.thr_ub[1])))))) {
-                    xs0 = strictly_feasible_thr(x[0], lb[0], ub[0], sc.thr_lb[0], sc.thr_ub[0]);
-                    if constexpr (NA == 2) xs1 = strictly_feasible_thr(x[1], lb[1], ub[1], sc.thr_lb[1], sc.thr_ub[1]);
+                    SEQIK_BLK_COUNT(CNT_FEASIBLE_SLOW);
+                    xs0 = strictly_feasible_pinned(x[0], lb[0], ub[0], sc.thr_lb_g[0], sc.thr_ub_g[0], sc.lb_out[0], sc.ub_out[0], side0);
+                    if constexpr (NA == 2)
+                        xs1 = strictly_feasible_pinned(x[1], lb[1], ub[1], sc.thr_lb_g[1], sc.thr_ub_g[1], sc.lb_out[1], sc.ub_out[1], side1);
                 }
+                const bool moved0 = xs0 != x[0], moved1 = (NA == 2) && xs1 != x[1];
+                if (moved0) { sa = (side0 < 0) ? sc.sc_lb[0][0] : sc.sc_ub[0][0]; ca = (side0 < 0) ? sc.sc_lb[0][1] : sc.sc_ub[0][1]; x[0] = xs0; }
+                if constexpr (NA == 2)
+                    if (moved1) { sb = (side1 < 0) ? sc.sc_lb[1][0] : sc.sc_ub[1][0]; cb = (side1 < 0) ? sc.sc_lb[1][1] : sc.sc_ub[1][1]; x[1] = xs1; }
+                if constexpr (STAGE == 1) {
+                    if (moved0 || moved1) {
+                        SEQIK_BLK_COUNT(CNT_START_EVAL);
+                        residual_sc<STAGE>(P, sa, ca, sb, cb, f, pe);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) f[i] = pe[i] - P.target[i];
+                    }
+                } else {
+                    residual_sc<STAGE>(P, sa, ca, sb, cb, f);  // the prefix frame is another one in every frame
+                }
+            }
 #else
+            {
                 const double xs0 = strictly_feasible(x[0], lb[0], ub[0], 1e-10);
                 const double xs1 = (NA == 2) ? strictly_feasible(x[1], lb[1], ub[1], 1e-10) : x[1];
-#endif
                 if (have_pe && xs0 == x[0] && xs1 == x[1]) {
-                    residual_sc<STAGE>(P, sa, ca, sb, cb, f);
+                    if constexpr (STAGE == 1) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) f[i] = pe[i] - P.target[i];
+                    } else {
+                        residual_sc<STAGE>(P, sa, ca, sb, cb, f);
+                    }
                 } else {
                     x[0] = xs0;
                     if constexpr (NA == 2) x[1] = xs1;
-                    eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb);
-                    have_pe = true;  // (stages 2-4 use the flag for "sa .. cb belong to x")
+                    eval_residual<STAGE>(P, x[0], x[1], f, sa, ca, sb, cb, (STAGE == 1) ? pe : nullptr);
+                    have_pe = true;
                 }
             }
+#endif
             cost = 0.5 * dot3(f, f);
             nfev = 1;
             alpha = 0.0;
@@ -1447,6 +1517,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         bool finished = false;
         SEQIK_BLK_END_OF(BLK_NEW_SOLVE);
         if (WANT_DIAG || status == STATUS_NONE) {
+            SEQIK_BLK_COUNT(CNT_BODY);
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
             double J[3][2], g[2], v[2], dv[2];
             if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
@@ -1469,6 +1540,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             d[0] = sqrt_pos_(v[0]);
             d[1] = (NA == 2) ? sqrt_pos_(v[1]) : 1.0;
             if (first_pass) {
+                SEQIK_BLK_COUNT(CNT_FIRST_PASS);
                 // Delta_0 = || x0 / sqrt_(v) || over ALL links (inert entries: v = 1)
                 double acc = sc.x_pre_sq;
                 // (x is still the start point x0 here: no step has been taken yet)
@@ -1487,6 +1559,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             if (status != STATUS_NONE || nfev == max_nfev) {
                 finished = true;
             } else {
+                SEQIK_BLK_COUNT(CNT_TR);
                 // ---- trust-region sub-problem -------------------------------------------
                 double diag_h[2], g_h[2], Jh[3][2];
 #pragma unroll
@@ -1520,6 +1593,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     step[0] = p[0]; step[1] = p[1]; step_h[0] = p_h[0]; step_h[1] = p_h[1];
                 } else {
                     SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
+                    SEQIK_BLK_COUNT(CNT_REFLECTIVE);
                     predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
                                                                      theta, step, step_h);
                     SEQIK_BLK_END_OF(BLK_REFLECTIVE);
@@ -1566,6 +1640,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                     Delta = Delta_new;
                 }
                 if (actual_reduction > 0) {
+                    SEQIK_BLK_COUNT(CNT_ACCEPT);
                     x[0] = x_new[0]; x[1] = x_new[1];
                     f[0] = f_new[0]; f[1] = f_new[1]; f[2] = f_new[2];
                     cost = cost_new;
@@ -1580,6 +1655,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 
         SEQIK_BLK_END_OF(BLK_POST_TRIAL);
         if (finished) {
+            SEQIK_BLK_COUNT(CNT_FINISHED);
             // ---- solve done: store, advance to the next frame -------------------------------
             const bool stored = !CHUNKED || t >= io.t_store;  // run-in frames leave nothing but the hand-off
             if (stored) {

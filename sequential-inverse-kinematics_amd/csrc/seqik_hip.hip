@@ -25,6 +25,18 @@ extern "C" int seqik_debug_block_cycles(unsigned long long *out, int reset)
     }
     return 0;
 }
+namespace seqik { __device__ unsigned long long seqik_block_entries[4][2 * CNT_COUNT]; }
+// [stage][c] = how often a wavefront went through conditional part c of a pass, [stage][CNT_COUNT + c] = active lanes summed
+extern "C" int seqik_debug_block_entries(unsigned long long *out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(seqik::seqik_block_entries), sizeof(unsigned long long) * 4 * 2 * seqik::CNT_COUNT) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zero[4 * 2 * seqik::CNT_COUNT] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(seqik::seqik_block_entries), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 
 namespace {
