@@ -156,7 +156,7 @@ enum : int { BLK_LOOP = 0, BLK_NEW_SOLVE, BLK_FD_JACOBIAN, BLK_SCALING, BLK_TR_S
 // conditional parts of a pass whose executions are counted (wave level: how often a wavefront went through them; lane
 // level: how many lanes were active when it did)
 enum : int { CNT_NEW_SOLVE = 0, CNT_FEASIBLE_SLOW, CNT_START_EVAL, CNT_BODY, CNT_FIRST_PASS, CNT_TR, CNT_REFLECTIVE, CNT_ACCEPT,
-             CNT_FINISHED, CNT_COUNT };
+             CNT_FINISHED, CNT_FD_SLOW, CNT_ROOT_ITER, CNT_ROOT_EVAL, CNT_GN_STEP, CNT_COUNT };
 #if SEQIK_BLOCK_CYCLES && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long seqik_block_cycles[4][BLK_COUNT + 1];  // [..][BLK_COUNT] = passes (wave level)
 extern __device__ unsigned long long seqik_block_entries[4][2 * CNT_COUNT]; // [..][c] wave entries, [..][CNT_COUNT + c] lanes
@@ -787,7 +787,7 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
         full_rank = lmin > 4.437342591868191e-31 * lmax;  // (3 eps)^2: s_min > eps * m * s_max
         if (full_rank) {
             tr2_apply(a + 0.0, b, c + 0.0, r, pp);
-            if (sqrt_(fma_(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { p[0] = -pp[0]; p[1] = -pp[1]; alpha_io = 0.0; return; }
+            if (sqrt_(fma_(pp[1], pp[1], pp[0] * pp[0])) <= Delta) { SEQIK_BLK_COUNT(CNT_GN_STEP); p[0] = -pp[0]; p[1] = -pp[1]; alpha_io = 0.0; return; }
         }
     }
     const double inv_Delta = div_(1.0, Delta);
@@ -824,10 +824,12 @@ SEQIK_HD void solve_tr_2x2(const double Jh[3][2], const double *diag_h, const do
     // benchmark data: in the last three of the ten iterations for 99.9 % of the solves -- so it is skipped.
     double aa_prev = __builtin_nan(""), cc_prev = __builtin_nan("");
     for (int it = 0; it < 10 && !shortcut; ++it) {
+        SEQIK_BLK_COUNT(CNT_ROOT_ITER);
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
         const double aa = a + alpha, cc = c + alpha;
         if (!(aa == aa_prev && cc == cc_prev)) {
+            SEQIK_BLK_COUNT(CNT_ROOT_EVAL);
             tr2_phi(aa, b, cc, r, Delta, pp, phi, ratio);
             aa_prev = aa;
             cc_prev = cc;
@@ -1074,6 +1076,7 @@ SEQIK_HD void fd_jacobian(const StageProblem<STAGE> &P, const double *x, const d
 #if SEQIK_FAST_PATHS
     double h_a = fd_step_nominal(x[0]), h_b = (T::NA == 2) ? fd_step_nominal(x[1]) : 0.0;
     if (wave_any(fd_step_violates(x[0], h_a, lb[0], ub[0]) || (T::NA == 2 && fd_step_violates(x[1], h_b, lb[1], ub[1])))) {
+        SEQIK_BLK_COUNT(CNT_FD_SLOW);
         h_a = fd_step(x[0], lb[0], ub[0]);
         if constexpr (T::NA == 2) h_b = fd_step(x[1], lb[1], ub[1]);
     }
@@ -1157,8 +1160,10 @@ SEQIK_HD void fd_jacobian_pair(const StageProblem<STAGE> &P, const double *x, co
     const double xj = odd ? x[1] : x[0];
 #if SEQIK_FAST_PATHS
     double h = fd_step_nominal(xj);
-    if (wave_any(fd_step_violates(xj, h, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0])))
+    if (wave_any(fd_step_violates(xj, h, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]))) {
+        SEQIK_BLK_COUNT(CNT_FD_SLOW);
         h = fd_step(xj, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]);
+    }
 #else
     double h = fd_step(xj, odd ? lb[1] : lb[0], odd ? ub[1] : ub[0]);
 #endif
