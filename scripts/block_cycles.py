@@ -26,7 +26,7 @@ from seqikpy_amd import _lib, data, synthetic, utils  # noqa: E402
 
 # conditional parts of a pass whose executions the diagnostic build counts (seqik_core.hpp CNT_*)
 COUNTED = ["new_solve", "feasible_slow_path", "start_evaluation", "body", "first_pass_radius", "trust_region_and_trial", "reflective",
-           "accept", "finished", "fd_step_slow_path", "root_search_iteration", "root_search_evaluation", "gauss_newton_step_inside_radius"]
+           "accept", "finished", "fd_step_slow_path", "root_search_iteration", "root_search_evaluation", "gauss_newton_step_inside_radius", "body_with_fewer_than_16_lanes", "body_with_fewer_than_32_lanes"]
 BLOCKS = ["loop", "new_solve", "fd_jacobian", "scaling_gtol", "tr_step", "in_bounds", "reflective", "trial_eval", "post_trial",
           "finished", "pipe_wait"]
 

@@ -156,7 +156,7 @@ enum : int { BLK_LOOP = 0, BLK_NEW_SOLVE, BLK_FD_JACOBIAN, BLK_SCALING, BLK_TR_S
 // conditional parts of a pass whose executions are counted (wave level: how often a wavefront went through them; lane
 // level: how many lanes were active when it did)
 enum : int { CNT_NEW_SOLVE = 0, CNT_FEASIBLE_SLOW, CNT_START_EVAL, CNT_BODY, CNT_FIRST_PASS, CNT_TR, CNT_REFLECTIVE, CNT_ACCEPT,
-             CNT_FINISHED, CNT_FD_SLOW, CNT_ROOT_ITER, CNT_ROOT_EVAL, CNT_GN_STEP, CNT_COUNT };
+             CNT_FINISHED, CNT_FD_SLOW, CNT_ROOT_ITER, CNT_ROOT_EVAL, CNT_GN_STEP, CNT_BODY_LT16, CNT_BODY_LT32, CNT_COUNT };
 #if SEQIK_BLOCK_CYCLES && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long seqik_block_cycles[4][BLK_COUNT + 1];  // [..][BLK_COUNT] = passes (wave level)
 extern __device__ unsigned long long seqik_block_entries[4][2 * CNT_COUNT]; // [..][c] wave entries, [..][CNT_COUNT + c] lanes
@@ -1523,6 +1523,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         SEQIK_BLK_END_OF(BLK_NEW_SOLVE);
         if (WANT_DIAG || status == STATUS_NONE) {
             SEQIK_BLK_COUNT(CNT_BODY);
+#if SEQIK_BLOCK_CYCLES && defined(__HIP_DEVICE_COMPILE__)
+            if (__popcll(__ballot(1)) < 16) SEQIK_BLK_COUNT(CNT_BODY_LT16);   // passes in which a wave is "thin"
+            if (__popcll(__ballot(1)) < 32) SEQIK_BLK_COUNT(CNT_BODY_LT32);
+#endif
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
             double J[3][2], g[2], v[2], dv[2];
             if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
