@@ -31,6 +31,12 @@ HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figure
   parity             HIP vs the committed reference fixtures (shipped anipose outputs, df3d reference-source run):
                      max |d theta|, leg-frames over 1e-4 rad and where, for the serial walk and for frame chunks
   cpu_baseline       the C oracle on the host cores, bounded sample of the same workload (+ Python/scipy pool)
+  value_single_job   = single_job.value, first class: what ONE 1M-frame x 6-leg job gets (no second batch to overlap with)
+  configs            every BASELINE.json config in this one driver-timed line: 1 / 2 / 4 through the reference-shaped
+                     Python API (default serial walk AND frame_parallel="auto": ms, leg-frames/s, max |d theta| vs the
+                     fixture, chunk statistics, latency_floor_frac), 4 with the head / antenna angles in the same
+                     submission, 3 = the headline, 5 streamed from pinned host slabs with the alignment fused
+                     (PCIe-inclusive, checked), and the generic chain on the shipped 6000-frame recording
 and, at N > 1, `multi_gpu`:
   ranks_seen, rank_ms_per_step   who took part (rank, host, device from the process group) and how even the ranks were
   gather_compare     the same batch with the angle gather as peer writes, as grouped RCCL point-to-point, and without
@@ -154,6 +160,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-python-baseline", action="store_true",
                     help="skip the Python + scipy process-pool leg of the CPU baseline (about 20 s)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` object (BASELINE configs 1 / 2 / 4 / 5 and the generic chain; about a minute)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip single_job / variants / single_recording / strong_projection / parity (profiling runs)")
     ap.add_argument("--cpu-sample-seqs", type=int, default=8192,
@@ -506,6 +514,178 @@ def parity_report():
                 entry[mode]["chunk_stats"] = {k: v for k, v in out["chunk_stats"].items() if v}
         rep[name] = entry
     return rep
+
+
+def best_ms(fn, reps=5):
+    """fn once untimed, then the fastest of `reps` runs, in ms (host clock: the whole call, transfers included)."""
+    fn()
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+
+
+def latency_floor(kernel_key):
+    """Committed PMC-derived issue floor of a latency-bound kernel (profiles/r04_latency_floor.json, written by
+    scripts/latency_floor.py from rocprofv3 --pmc / --kernel-trace runs): the VALU instructions ONE wavefront issues per
+    frame on the critical path, priced at the lone-wavefront issue cost per class.  None when absent / another build."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r04_latency_floor.json")))
+    except (OSError, ValueError):
+        return None
+    if j.get("csrc_sha256") != _lib.csrc_sha256(_lib.LATENCY_SOURCES):
+        return None
+    return j.get(kernel_key)
+
+
+def reference_configs(time_box_s=240.0):
+    """BASELINE.json configs 1, 2, 4, 5 and the generic chain, as a user of the reference would run them, timed in this
+    process (`configs` of the JSON line).  Reference shapes: examples/example_leg_inv_kinematics.py:23-62 (config 1 and
+    the generic chain), examples/example_leg_inv_kinematics_parallel.py:143-198 (config 2), examples/
+    example_entire_pipeline.py:48-106 (config 4).  Every entry carries its parity figure next to its time."""
+    import importlib.util
+    from seqikpy_amd.head_inverse_kinematics import ANGLE_NAMES
+    from seqikpy_amd.kinematic_chain import KinematicChainGeneric, KinematicChainSeq
+    from seqikpy_amd.leg_inverse_kinematics import LegInvKinGeneric, LegInvKinSeq
+    from seqikpy_amd.pipeline import run_body_ik
+    t_start = time.perf_counter()
+    DOFS = data.DOFS
+    za = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
+    zd = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
+    zh = np.load(os.path.join(ROOT, "tests", "golden", "anipose_head.npz"))
+    out = {"note": "ms = fastest of 5 whole calls on host arrays (upload, kernels, download, dict building); "
+                   "leg_frames_per_s = legs x frames / that; default = the reference's serial walk (bit-identical to the C "
+                   "restatement), frame_parallel_auto = verified frame chunks (opt-in); latency_floor_frac = issue floor of "
+                   "the critical wavefront (committed PMC instruction counts x lone-wavefront issue costs) / measured kernel "
+                   "time, for the kernels that are bound by the latency of one dependent chain, not by throughput"}
+
+    def leg_entry(z, legs, n, bounds, init, template, workload, mask_lf):
+        aligned = {f"{l}_leg": np.ascontiguousarray(z[f"{l}_pose"][:n]) for l in legs}
+        body = utils.calculate_body_size(template, legs)
+        chain = KinematicChainSeq(bounds_dof=bounds, legs_list=legs, body_size=body)
+        ref = np.stack([z[f"{l}_angles"][:n] for l in legs])                       # (L, n, 7)
+        ok = np.ones(ref.shape[:2], bool)
+        if mask_lf and "LF" in legs:
+            ok[legs.index("LF"), LF_WINDOW[0]:min(LF_WINDOW[1], n)] = False
+        entry = {"workload": workload, "legs": legs, "frames": n, "leg_frames": len(legs) * n}
+        got = {}
+        for key, mode in (("default", False), ("frame_parallel_auto", "auto")):
+            holder = {}
+
+            def call():
+                ik = LegInvKinSeq(aligned_pos=aligned, kinematic_chain_class=chain, initial_angles=init, log_level="ERROR")
+                holder["ang"], holder["fk"] = ik.run_ik_and_fk(export_path=None, frame_parallel=mode)
+                holder["ik"] = ik
+            ms = best_ms(call)
+            a = np.stack([np.stack([holder["ang"][f"Angle_{l}_{d}"] for d in DOFS], 1) for l in legs])   # (L, n, 7)
+            got[key] = a
+            err = np.abs(a - ref)
+            e = {"ms": ms, "leg_frames_per_s": len(legs) * n / ms * 1e3,
+                 "max_abs_dtheta_vs_fixture": float(err[ok].max()),
+                 "leg_frames_over_1e-4": int((err.max(-1) > 1e-4)[ok].sum())}
+            if mask_lf and "LF" in legs:
+                e["max_abs_dtheta_incl_lf_window"] = float(err.max())
+            if mode:
+                st = holder["ik"].frame_chunk_stats
+                e["chunk_stats"] = {k: v for k, v in st.items() if v}
+                dd = np.abs(a - got["default"])
+                e["max_abs_vs_default"] = float(dd[ok].max())
+                if mask_lf and "LF" in legs:
+                    e["max_abs_vs_default_incl_lf_window"] = float(dd.max())
+            entry[key] = e
+        return entry, aligned, chain
+
+    legs6 = [str(l) for l in zd["legs"]]
+    out["1"], _, _ = leg_entry(za, ["RF"], 100, data.BOUNDS, data.INITIAL_ANGLES, data.NMF_TEMPLATE,
+                               "config 1: single right-front leg, 100 frames of anipose_220525_aJO_Fly001_001 "
+                               "(LegInvKinSeq.run_ik_and_fk; fixture = the shipped leg_joint_angles.pkl)", False)
+    out["2"], _, _ = leg_entry(zd, legs6, 1000, data.BOUNDS_LOCOMOTION, data.INITIAL_ANGLES_LOCOMOTION,
+                               data.TEMPLATE_NMF_LOCOMOTION,
+                               "config 2: all 6 legs, df3d locomotion recording, 1000 frames (fixture = the reference's source run "
+                               "over real scipy, oracle/gen_golden.py)", False)
+    # ---- config 4: legs + head / antenna angles of the shipped 6000-frame recording in ONE submission ----------------
+    e4, aligned4, chain4 = leg_entry(za, ["RF", "LF"], 6000, data.BOUNDS, data.INITIAL_ANGLES, data.NMF_TEMPLATE,
+                                     "config 4: anipose_220525_aJO_Fly001_001 (6000 frames; stands in for the absent "
+                                     "anipose_220807_Fly002_002), legs RF + LF + the 7 head / antenna angles", True)
+    body_in = dict(aligned4, R_head=zh["R_head"], L_head=zh["L_head"], Neck=zh["Neck"])
+    e4["legs_and_head_one_submission"] = {}
+    for key, mode in (("default", False), ("frame_parallel_auto", "auto")):
+        holder = {}
+
+        def call():
+            holder["body"], holder["fk"] = run_body_ik(body_in, chain4, data.NMF_TEMPLATE, data.INITIAL_ANGLES, frame_parallel=mode)
+        ms = best_ms(call)
+        head = np.stack([holder["body"][k] for k in ANGLE_NAMES], 1)
+        legs_a = np.stack([np.stack([holder["body"][f"Angle_{l}_{d}"] for d in DOFS], 1) for l in ("RF", "LF")])
+        ref = np.stack([za[f"{l}_angles"] for l in ("RF", "LF")])
+        ok = np.ones(ref.shape[:2], bool)
+        ok[1, LF_WINDOW[0]:LF_WINDOW[1]] = False
+        e4["legs_and_head_one_submission"][key] = {
+            "ms": ms, "leg_frames_per_s": 2 * 6000 / ms * 1e3, "angles_per_frame": 21,
+            "max_abs_dtheta_legs_vs_fixture": float(np.abs(legs_a - ref)[ok].max()),
+            "max_abs_head_vs_shipped_head_joint_angles": float(np.abs(head - zh["shipped"]).max())}
+    out["4"] = e4
+    out["3"] = {"workload": "config 3: synthetic 1M frames x 6 legs", "see": "top level: value (3 batches in flight), "
+                "value_single_job, variants.smooth, single_recording (ONE recording), strong_projection"}
+    # ---- generic chain: the reference's LegInvKinGeneric example on the shipped recording ----------------------------
+    zg = np.load(os.path.join(ROOT, "tests", "golden", "generic_rf_100.npz"))
+    gen_aligned = {"RF_leg": np.ascontiguousarray(za["RF_pose"])}
+    gchain = KinematicChainGeneric(bounds_dof=data.BOUNDS, legs_list=["RF"],
+                                   body_size=utils.calculate_body_size(data.NMF_TEMPLATE, ["RF"]))
+    holder = {}
+
+    def gcall():
+        ik = LegInvKinGeneric(aligned_pos=gen_aligned, kinematic_chain_class=gchain, initial_angles=data.INITIAL_ANGLES, log_level="ERROR")
+        holder["ang"], holder["fk"] = ik.run_ik_and_fk()
+    g_ms = best_ms(gcall, reps=2)
+    g_ang = np.stack([holder["ang"][f"Angle_RF_{d}"] for d in DOFS], 1)
+    claw = holder["fk"]["RF_leg"][:, 8]
+    lo, hi = za["RF_bounds"][:, 0], za["RF_bounds"][:, 1]
+    d_ref = np.abs(np.diff(zg["RF_angles"], axis=0))
+    d_got = np.abs(np.diff(g_ang[:100], axis=0))
+    out["generic"] = {
+        "workload": "LegInvKinGeneric, RF, the shipped 6000-frame recording (example_leg_inv_kinematics.py:49-62)",
+        "frames": 6000, "ms": g_ms, "us_per_frame": g_ms * 1e3 / 6000, "frames_per_s": 6000 / g_ms * 1e3,
+        "max_abs_claw_vs_target": float(np.abs(claw - za["RF_pose"][:, 4]).max()),
+        "max_abs_claw_vs_reference_run_first_100": float(np.abs(claw[:100] - zg["RF_fk"][:, 8]).max()),
+        "all_angles_within_limits": bool((g_ang >= lo).all() and (g_ang <= hi).all()),
+        "max_abs_dtheta_vs_reference_run_first_100": float(np.abs(g_ang[:100] - zg["RF_angles"]).max()),
+        "frame_to_frame_step_p99_first_100": {"this": float(np.quantile(d_got, 0.99)), "reference_run": float(np.quantile(d_ref, 0.99))},
+        "parity_note": "7 unknowns, 3 equations: the reference's angles are not reproducible by the reference itself "
+                       "(profiles/r04_perturbation_generic.json: real scipy vs real scipy + 1 ulp), so the claw, the limits and "
+                       "the smoothness of the joint series are what can be pinned; HIP == C restatement bit for bit (tests)"}
+    # ---- latency floors of the two latency-bound kernels (item: "latency-bound" as a number) -------------------------
+    for key, entry, kernel_key, ms_key in (("4", out["4"], "config4_serial_walk", None), ("generic", out["generic"], "generic_rf_6000", None)):
+        fl = latency_floor(kernel_key)
+        if fl:
+            entry["latency_floor"] = fl
+    # ---- config 5: streamed from pinned host slabs, alignment fused, PCIe-inclusive ----------------------------------
+    spec = importlib.util.spec_from_file_location("stream_config5", os.path.join(ROOT, "scripts", "stream_config5.py"))
+    sc5 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc5)
+    from types import SimpleNamespace
+    c5 = {"workload": "config 5: 10M frames x 6 legs streamed from pinned host memory in slabs, RAW key points, "
+                      "AlignPose.align_leg fused into the kernel prologue; PCIe-inclusive (H2D 120 B, D2H 56 + 216 B per leg-frame)"}
+    left = time_box_s - (time.perf_counter() - t_start)
+    try:
+        a5 = SimpleNamespace(frames=10_000_000, slab_frames=1_000_000, slots=3, no_fk=False)
+        c5["one_recording"] = sc5.one_recording(a5)
+        left = time_box_s - (time.perf_counter() - t_start)
+        # the synthetic iid sequences of the headline (64 frames each): data generation costs ~6 s per distinct 1M-frame
+        # slab on the host, so ONE distinct slab is generated and cycled (the kernels cannot tell); sized to the time left
+        if left > 60:
+            a5s = SimpleNamespace(frames=10_000_000, slab_frames=500_000, frames_per_seq=64, unique=1, slots=3, no_fk=False,
+                                  pageable=False, check=True, gpu_stats=False)
+            c5["synthetic_sequences"] = sc5.synthetic_sequences(a5s)
+        else:
+            c5["synthetic_sequences"] = {"skipped": f"time box: {left:.0f} s left"}
+    except Exception as exc:  # noqa: BLE001  (pinned-memory limits of a box must not take the headline down)
+        c5["error"] = f"{type(exc).__name__}: {exc}"
+    out["5"] = c5
+    out["seconds"] = time.perf_counter() - t_start
+    return out
 
 
 def main():
@@ -863,6 +1043,13 @@ def main():
             out["single_recording"] = single_recording(args.frames)
             # ---- parity vs the committed reference fixtures ----------------------------------------------------
             out["parity"] = parity_report()
+            out["value_single_job"] = out["single_job"]["value"]
+            # ---- every BASELINE config, reference-shaped calls, in this one line -------------------------------
+            if not args.no_configs:
+                del batch, d_ang
+                torch.cuda.empty_cache()
+                out["configs"] = reference_configs()
+            _lib.check_faults()   # the device entry points do not synchronise: a kernel fault of any launch above raises here
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 3
+#define SEQIK_ABI_VERSION 4
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -230,6 +230,22 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
  * doubles each.  The GPU tests compare the results with IEEE division / square root over the operand range the
  * contract states, and with the special values.  No reference counterpart. */
 int seqik_selftest_div_sqrt(const double *a, const double *b, double *q, double *r, int64_t n);
+/* ABI 4.  r[i] = the select-free square root the kernels apply to the Coleman-Li distances v = x - lb | ub - x | 1 of a
+ * strictly feasible x (`sqrt_pos_`, csrc/seqik_core.hpp): positive finite operands only.  A joint limit of exactly 0 makes
+ * v the smallest subnormal (the trial point scipy's make_strictly_feasible(rstep = 0) pins next to the limit); the GPU tests
+ * check that value, the other subnormal powers of two and the per-leg values  lb_in - lb,  ub - ub_in  of the shipped
+ * limits against IEEE sqrt.  No reference counterpart. */
+int seqik_selftest_sqrt_pos(const double *a, double *r, int64_t n);
+
+/* ABI 4.  Device faults.  The reference reports every failure as a Python exception (IKPy raises on scipy status -1,
+ * seqikpy/leg_inverse_kinematics.py:62-69 -> ikpy); it never returns silent garbage.  The one failure a kernel of this
+ * library can detect by itself -- the stage pipeline's watchdog: a lane that waited 2^24 passes for its neighbour wave,
+ * impossible by construction -- fills the rest of that chain with NaN and sets a process-wide fault word in mapped host
+ * memory.  The blocking entry points (seqik_solve_seq, seqik_stream_wait) read and clear the word after they have
+ * synchronised and return SEQIK_ERR_HIP with a message; seqik_solve_seq_device, which does not synchronise, reports a
+ * fault left by EARLIER launches when it is entered.  Callers of the device entry point call seqik_check_faults() after
+ * synchronising their stream: SEQIK_OK, or SEQIK_ERR_HIP (message in seqik_last_error(); the word is cleared). */
+int seqik_check_faults(void);
 
 /* The frame chunks a call over recordings of n_frames frames would use with these options (frame_chunk / frame_halo /
  * frame_lead): frames per chunk, run-in frames, chunks per chain K -- all 0 when the call would be walked serially.

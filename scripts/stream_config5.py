@@ -100,10 +100,12 @@ def one_recording(args):
     n = min(T, 3000)
     direct = _lib.solve_seq(np.ascontiguousarray(raw[None, :, :T]), params, want_fk=False, affine=affs, frame_chunk=-1)
     serial = _lib.solve_seq(np.ascontiguousarray(raw[None, :, :n]), params, want_fk=False, affine=affs)
-    got = a.array[0].transpose(0, 2, 1)                                                 # (L, T, 7)
+    got = a.array[0].transpose(0, 2, 1).copy()                                          # (L, T, 7)
     units = n_slabs * L * T
     bytes_per = 120 + 56 + (216 if want_fk else 0)
-    print(json.dumps({"metric": "leg-IK solves/s, ONE recording streamed from host memory in time slabs (PCIe-inclusive)",
+    for arr in [p] + [x for pair in outs for x in pair if x is not None]:
+        arr.free()
+    return ({"metric": "leg-IK solves/s, ONE recording streamed from host memory in time slabs (PCIe-inclusive)",
                       "value": units / dt, "unit": "leg-frame solves/s", "n_gpus": 1, "seconds": dt, "leg_frames": units,
                       "frames_total": n_slabs * T, "legs": L, "slabs": n_slabs, "slab_frames": T, "slots": args.slots,
                       "data": "df3d locomotion recording (fixture) repeated, RAW key points through a made-up camera frame, "
@@ -114,7 +116,7 @@ def one_recording(args):
                       "pcie_GBps_total": units * bytes_per / dt / 1e9,
                       "check": {"streamed_slab_equals_direct_chunked_call_bitwise": bool(np.array_equal(got, direct["angles"][0])),
                                 "max_abs_vs_serial_walk_first_frames": float(np.abs(got[:, :n] - serial["angles"][0]).max()),
-                                "frames_walked_serially": n}}))
+                                "frames_walked_serially": n}})
 
 
 def one_recording_over_ranks(args):
@@ -222,8 +224,15 @@ def main():
                              "process per GPU on its share of the slabs)")
         return one_recording_over_ranks(args)
     if args.one_recording:
-        return one_recording(args)
+        print(json.dumps(one_recording(args)))
+        return
+    print(json.dumps(synthetic_sequences(args)))
 
+
+def synthetic_sequences(args):
+    """Config 5 as BASELINE.json words it: --frames synthetic frames x 6 legs (independent sequences of --frames-per-seq
+    frames, iid in-workspace poses) streamed from pinned slabs, RAW key points, alignment fused into the kernel prologue.
+    Returns the result line as a dict (bench.py calls this for its `configs["5"]` entry)."""
     legs = data.LEGS
     L, T = len(legs), args.frames_per_seq
     S = args.slab_frames // T
@@ -320,13 +329,13 @@ def main():
            "pcie_GBps_total": units * bytes_per / dt / 1e9, "h2d_GBps": units * 120 / dt / 1e9,
            "d2h_GBps": units * (bytes_per - 120) / dt / 1e9, "datagen_seconds": t_gen, "check": check,
            "alignment_statistics_pass": stats}
-    print(json.dumps(out))
     for p in slabs:
         p.free()
     for a, f in outs:
         a.free()
         if f:
             f.free()
+    return out
 
 
 if __name__ == "__main__":

@@ -36,9 +36,17 @@ inline void link_bounds(const SeqikLegParams &lp, int stage, int link, double &l
     else { lb = lp.bounds[dof][0]; ub = lp.bounds[dof][1]; }
 }
 
+// Limits the range-scaling-free square root of seqik_core.hpp cannot serve: a limit of exactly 0 is fine (the Coleman-Li
+// distance next to it is 2^-1074, whose root is exact), ordinary magnitudes are fine (the distance is at least one ulp of
+// the limit), a non-zero limit below 2^-600 in magnitude would put general subnormal distances under the root.  No joint
+// has such a limit; refusing it keeps the floating-point contract closed.
+inline bool limit_too_small(double b) { return b != 0.0 && fabs(b) < 0x1p-600; }
+
 // scipy least_squares argument checks, in scipy's order, for the stages that will run.
 inline int validate_leg(const SeqikLegParams &lp, int first_stage, int last_stage)
 {
+    for (int d = 0; d < 7; ++d)
+        if (limit_too_small(lp.bounds[d][0]) || limit_too_small(lp.bounds[d][1])) return SEQIK_ERR_BAD_ARG;
     for (int stage = first_stage; stage <= last_stage; ++stage) {
         int n = kStageLinks[stage - 1];
         for (int i = 0; i < n; ++i) {
@@ -142,6 +150,8 @@ inline void generic_link_bounds(const SeqikLegParams &lp, int link /*0..8*/, dou
 // applied positionally: seeds[18 + i] is the start value of link i.
 inline int validate_leg_generic(const SeqikLegParams &lp)
 {
+    for (int d = 0; d < 7; ++d)
+        if (limit_too_small(lp.bounds[d][0]) || limit_too_small(lp.bounds[d][1])) return SEQIK_ERR_BAD_ARG;
     for (int i = 0; i < 9; ++i) {
         double lb, ub;
         generic_link_bounds(lp, i, lb, ub);

@@ -62,6 +62,16 @@ SEQIK_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, 
 // between ~1e-100 and ~1e+20 for any key points a camera can produce (the smallest quantity, the Levenberg-Marquardt
 // multiplier after scipy's ten thousandfold reductions, is ~1e-50 and enters as its square).  The oracle divides and takes
 // roots with the host's IEEE operations; every parity test and the soak therefore also checks this equivalence.
+//   ONE quantity leaves that range: the Coleman-Li distance v = |x - bound| next to a joint limit of exactly 0 (the
+// shipped tables have three: CTr_pitch ub, FTi_pitch lb, TiTa_pitch ub).  A trial point that lands on such a limit is moved
+// to next_toward(0, .) = +-2^-1074 (strictly_feasible0), so the next pass takes sqrt_pos_(2^-1074).  For that operand -- and
+// for every even power of two down there -- the sequence is still exact: v_rsq_f64 returns the power of two 2^537, g = x y
+// = 2^-537 is normal and exact, h g = 1/2 exactly so the first correction is zero, and g g - x = 0 exactly so the others
+// are too.  The GPU tier checks this on the device (seqik_selftest_sqrt_pos: 2^-1074, the even powers of two up to
+// 2^-700, and lb_in - lb / ub - ub_in of every shipped limit).  A general subnormal operand would NOT be rounded correctly
+// (fma(-g, g, x) underflows); the solver cannot produce one from limits that are 0 or of ordinary size -- from x =
+// 2^-1074 the next iterate is x + d p_h with d = sqrt(v) = 2^-537 -- and seqik_validate_legs refuses non-zero limits below
+// 2^-600 in magnitude, the only other way to get there (limit_too_small, seqik_consts.hpp).
 // SEQIK_IEEE_DIV_SQRT=1 builds the kernels with the compiler's full expansions (A/B check, tests/tools/soak_parity.py).
 // ---------------------------------------------------------------------------
 #ifndef SEQIK_IEEE_DIV_SQRT
@@ -118,8 +128,9 @@ SEQIK_HD double sqrt_(double x)
     return sqrt(x);
 #endif
 }
-// sqrt_ for arguments known to be positive, finite and normal (the Coleman-Li distances v = ub - x, x - lb or 1 of a strictly
-// feasible x): the iteration alone, without the two selects for +-0 / +inf.  Same bits as sqrt_ there (NaN stays NaN).
+// sqrt_ for arguments known to be positive and finite (the Coleman-Li distances v = ub - x, x - lb or 1 of a strictly
+// feasible x; normal, or 2^-1074 next to a limit of exactly 0 -- see above): the iteration alone, without the two selects
+// for +-0 / +inf.  Same bits as sqrt_ there (NaN stays NaN).
 #ifndef SEQIK_SQRT_POS
 #define SEQIK_SQRT_POS 1
 #endif
@@ -1211,7 +1222,10 @@ SEQIK_HD void eval_residual_pair(const StageProblem<STAGE> &P, double xa, double
 // waits for nobody downstream, so the oldest unfinished frame can always advance; every wave leaves its loop when its
 // lanes have done all frames.
 constexpr int PIPE_DEPTH = 2;
-constexpr int PIPE_SPIN_LIMIT = 1 << 24;  // watchdog: ~1 s of waiting on one frame (a frame takes ~10-100 us)
+#ifndef SEQIK_PIPE_SPIN_LIMIT
+#define SEQIK_PIPE_SPIN_LIMIT (1 << 24)  // watchdog: ~1 s of waiting on one frame (a frame takes ~10-100 us)
+#endif
+constexpr int PIPE_SPIN_LIMIT = SEQIK_PIPE_SPIN_LIMIT;  // (-DSEQIK_PIPE_SPIN_LIMIT=1: the diagnostic build the watchdog test trips)
 struct PipeLane {
     // element k of slot j of this lane at ring[(j * 12 + k) * lane_stride]
     double *ring_in, *ring_out;     // LDS; null for the first / last stage
@@ -1220,6 +1234,7 @@ struct PipeLane {
     int lane_stride;                // lanes interleaved in LDS (bank-conflict free)
     int base;                       // frames this lane's four waves have put through the ring before this chain
                                     // (a lane that solves several chains in turn keeps counting)
+    int32_t *fault;                 // nullable: host-visible word the watchdog reports to (seqik_hip.hip "Device faults")
 };
 
 SEQIK_HD int pipe_load(const int *p)
@@ -1396,7 +1411,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             if (stall) {
                 if (++pipe_spins > PIPE_SPIN_LIMIT) {
                     // Cannot happen by construction (see PipeLane); should it ever, never hang the GPU: mark this
-                    // lane's remaining results NaN, release the neighbours, leave.
+                    // lane's remaining results NaN, release the neighbours, leave -- and say so: the word behind
+                    // io.pipe.fault lives in host memory, every host entry point turns it into SEQIK_ERR_HIP.
+                    if (io.pipe.fault) *(volatile int32_t *)io.pipe.fault = STAGE;
                     const double nan = __builtin_nan("");
                     for (int64_t tt = t; tt < io.n_frames; ++tt) {
                         if (CHUNKED && tt < io.t_store) continue;

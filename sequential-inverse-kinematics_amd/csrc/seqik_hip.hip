@@ -74,6 +74,48 @@ int fail(int code, const char *fmt, const char *detail = "")
         if (e_ != hipSuccess) return fail(SEQIK_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device faults.  The reference reports every failure as a Python exception and never returns silent garbage
+// (seqikpy/leg_inverse_kinematics.py:232-236: IKPy raises when scipy's status is -1).  The one condition a kernel of
+// this library can detect by itself is the stage pipeline's watchdog (run_stage, PIPED: a lane that waited 2^24 passes
+// for its neighbour wave -- impossible by construction, so if it happens something is broken).  The lane then fills the
+// rest of its chain with NaN, frees its neighbours AND writes the stage number into one 32-bit word in pinned,
+// device-mapped HOST memory (one word per process, visible to every GPU).  No launch pays for it: the store sits in the
+// branch that never runs.  Every host entry point that synchronises reads and clears the word afterwards and returns
+// SEQIK_ERR_HIP with a message; the asynchronous device entry points report a fault left by EARLIER launches when they
+// are entered, and seqik_check_faults() is there for callers that synchronise themselves.
+// ---------------------------------------------------------------------------------------------------------------
+std::once_flag g_fault_once;
+int32_t *g_fault_host = nullptr;    // host address
+int32_t *g_fault_device = nullptr;  // the same word as the GPUs address it
+
+int32_t *fault_word()
+{
+    std::call_once(g_fault_once, [] {
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
+        memset(h, 0, 64);
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_fault_host = static_cast<int32_t *>(h);
+        g_fault_device = static_cast<int32_t *>(d);
+    });
+    return g_fault_device;  // null: no mapped host memory on this system -- the watchdog then only leaves its NaN
+}
+
+// reads and clears the fault word; SEQIK_OK or SEQIK_ERR_HIP with the message set
+int check_faults(const char *where)
+{
+    if (!g_fault_host) return SEQIK_OK;
+    const int32_t v = __atomic_exchange_n(g_fault_host, 0, __ATOMIC_ACQ_REL);
+    if (v == 0) return SEQIK_OK;
+    snprintf(g_err, sizeof(g_err),
+             "%s: stage pipeline watchdog: a lane of stage %d waited more than %d passes for its neighbour wave; the "
+             "remaining frames of its chain hold NaN -- the results of the calls since the last check are invalid",
+             where, (int)v, (int)seqik::PIPE_SPIN_LIMIT);
+    return SEQIK_ERR_HIP;
+}
+
 struct LegOrder {  // dispatch order of the legs, see chain_of_lane()
     uint8_t leg[8];
 };
@@ -94,6 +136,7 @@ struct KernelArgs {
     int32_t lanes_per_wave;       // W: chains a wavefront carries (1..64), see chain_of_lane()
     LegOrder leg_order;           // dispatch order of the legs
     int32_t lane_pairs;           // stage pipeline: thin waves split a pass over lane pairs (0 = off, for measurements)
+    int32_t *fault;               // host-visible fault word ("Device faults" below); the stage pipeline's watchdog writes it
     // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
     int64_t pose_chain, pose_row, pose_frame;
     int64_t ang_chain, ang_dof, ang_frame;
@@ -340,11 +383,12 @@ struct PipeShared {
 // passes of the stages with two active joints between them
 template <bool WANT_FK, bool CHUNK_SPEC_MODE>
 __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane,
-                                         bool pairs, int base = 0)
+                                         bool pairs, int32_t *fault, int base = 0)
 {
     seqik::PipeLane &pl = io.pipe;
     pl.lane_stride = 64;
     pl.base = base;
+    pl.fault = fault;
     pl.ring_in = stage_wave > 0 ? &sh.ring[stage_wave - 1][0][0][lane] : nullptr;
     pl.produced_in = stage_wave > 0 ? &sh.produced[stage_wave - 1][lane] : nullptr;
     pl.consumed_in = stage_wave > 0 ? &sh.consumed[stage_wave - 1][lane] : nullptr;
@@ -398,7 +442,7 @@ seqik_pipe_kernel(KernelArgs a)
     io.init = a.init ? a.init + c * 7 : nullptr;
     io.frames = nullptr;
     io.n_frames = a.n_frames;
-    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a));
+    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -724,7 +768,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
         seqik::ChainIO io;
         chunk_io(a, ca, vc, leg, true, io);
         // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
-        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a));
+        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
     } else {
         // the work list of round ca.round (SERIAL: the serial list), spread over the workgroups as thinly as possible; the
         // four stage waves of a workgroup walk the same entries in the same order (the ring counters of a lane keep
@@ -748,7 +792,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
                 leg = (int)(vc % a.n_legs);
                 chunk_io(a, ca, vc, leg, false, io, CHUNK_FLAG_REPAIRED);
             }
-            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), base);
+            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), a.fault, base);
             base += (int)(io.n_frames - io.t_begin);
         }
     }
@@ -1081,6 +1125,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
 {
     KernelArgs a;
     a.init = d_init;
+    a.fault = fault_word();
     if (layout) {
         if (layout->pose_chain < 0 || layout->pose_row <= 0 || layout->pose_frame <= 0 || layout->ang_chain < 0 ||
             layout->ang_dof <= 0 || layout->ang_frame <= 0)
@@ -1357,6 +1402,8 @@ int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clo
 // used by the other translation units of the library (seqik_head.hip)
 void seqik_set_error(int code, const char *msg) { (void)fail(code, "%s", msg); }
 
+int seqik_check_faults(void) { return check_faults("seqik_check_faults"); }
+
 int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage)
 {
     if (!legs || n_legs <= 0) return fail(SEQIK_ERR_BAD_ARG, "null legs%s");
@@ -1368,6 +1415,8 @@ int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t firs
             return fail(rc, "Each lower bound must be strictly less than each upper bound.%s");
         if (rc == SEQIK_ERR_X0_OUT_OF_BOUNDS)
             return fail(rc, "Initial guess is outside of provided bounds%s");
+        if (rc == SEQIK_ERR_BAD_ARG)
+            return fail(rc, "a joint limit is non-zero but smaller than 2^-600 in magnitude: not supported (DESIGN.md, floating-point contract)%s");
     }
     return SEQIK_OK;
 }
@@ -1380,6 +1429,8 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
 {
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
     if (rc != SEQIK_OK) return rc;
+    // asynchronous: a fault of THIS launch cannot be known yet; one an earlier launch left behind is reported now
+    if ((rc = check_faults("seqik_solve_seq_device (fault of an earlier launch)")) != SEQIK_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const seqik::LegConst *d_legs = nullptr;
     rc = device_leg_table(legs, affine, n_legs, &d_legs);
@@ -1397,6 +1448,8 @@ int seqik_validate_legs_generic(const SeqikLegParams *legs, int32_t n_legs)
             return fail(rc, "Each lower bound must be strictly less than each upper bound.%s");
         if (rc == SEQIK_ERR_X0_OUT_OF_BOUNDS)
             return fail(rc, "Initial guess is outside of provided bounds%s");
+        if (rc == SEQIK_ERR_BAD_ARG)
+            return fail(rc, "a joint limit is non-zero but smaller than 2^-600 in magnitude: not supported (DESIGN.md, floating-point contract)%s");
     }
     return SEQIK_OK;
 }
@@ -1569,7 +1622,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipStreamSynchronize(stream));
-    return SEQIK_OK;
+    return check_faults("seqik_solve_seq");
 }
 
 // Self-test hook of the floating-point contract: q[i] = div_(a[i], b[i]), r[i] = sqrt_(a[i]) on the device.
@@ -1595,6 +1648,30 @@ int seqik_selftest_div_sqrt(const double *a, const double *b, double *q, double 
     if (e == hipSuccess) e = hipMemcpy(r, d + 3 * n, sizeof(double) * n, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(SEQIK_ERR_HIP, "seqik_selftest_div_sqrt: %s", hipGetErrorString(e));
+    return SEQIK_OK;
+}
+
+// r[i] = sqrt_pos_(a[i]): the select-free square root the Coleman-Li distances go through (run_stage, run_generic)
+__global__ void seqik_selftest_sqrt_pos_kernel(const double *a, double *r, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = seqik::sqrt_pos_(a[i]);
+}
+
+int seqik_selftest_sqrt_pos(const double *a, double *r, int64_t n)
+{
+    if (!a || !r || n < 0) return fail(SEQIK_ERR_BAD_ARG, "null pointer argument%s");
+    if (n == 0) return SEQIK_OK;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(double) * 2 * n));
+    hipError_t e = hipMemcpy(d, a, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(seqik_selftest_sqrt_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, d, d + n, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(r, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SEQIK_ERR_HIP, "seqik_selftest_sqrt_pos: %s", hipGetErrorString(e));
     return SEQIK_OK;
 }
 

@@ -280,7 +280,7 @@ int seqik_stream_wait(SeqikStream *s)
     STRY(scope.enter(s->device));
     for (Slot &q : s->slots)
         if (q.in_flight) { STRY(hipEventSynchronize(q.done)); q.in_flight = false; }
-    return SEQIK_OK;
+    return seqik_check_faults();  // every slab is back: a watchdog fault in one of them must not pass silently
 }
 
 int seqik_stream_reset_carry(SeqikStream *s)

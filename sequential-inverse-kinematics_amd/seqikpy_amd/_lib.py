@@ -36,7 +36,7 @@ class SeqikLegParams(ctypes.Structure):
 
 
 class SeqikOptions(ctypes.Structure):
-    """Mirror of ``struct SeqikOptions`` (include/seqik.h, ABI 2)."""
+    """Mirror of ``struct SeqikOptions`` (include/seqik.h; unchanged since ABI 3)."""
     _fields_ = [("device", ctypes.c_int32), ("block_size", ctypes.c_int32),
                 ("stage_events", ctypes.POINTER(ctypes.c_void_p)), ("reserved", ctypes.c_int32 * 4),
                 ("frame_chunk", ctypes.c_int32), ("frame_halo", ctypes.c_int32), ("chunk_tol", ctypes.c_double),
@@ -46,7 +46,7 @@ class SeqikOptions(ctypes.Structure):
                 ("chunk_resume", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 N_CHUNK_STATS = 16
 CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
                       "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check",
@@ -73,6 +73,24 @@ def selftest_div_sqrt(a, b):
     if rc != SEQIK_OK:
         _raise(rc)
     return q, r
+
+
+def selftest_sqrt_pos(a):
+    """sqrt(a) as the kernels compute it for the Coleman-Li distances (``sqrt_pos_``: no zero / infinity selects)."""
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    r = np.empty_like(a)
+    rc = load().seqik_selftest_sqrt_pos(a.ctypes.data_as(_dp), r.ctypes.data_as(_dp), a.size)
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return r
+
+
+def check_faults():
+    """``seqik_check_faults``: raises ``SeqikLibraryError`` when a kernel launched through the asynchronous device entry
+    points reported a fault (the stage pipeline's watchdog) since the last check.  Call it after synchronising."""
+    rc = load().seqik_check_faults()
+    if rc != SEQIK_OK:
+        _raise(rc)
 
 
 def frame_chunk_plan(n_frames, frame_chunk=-1, frame_halo=0, frame_lead=0):
@@ -129,6 +147,7 @@ def _hipcc():
 
 
 KERNEL_SOURCES = ["seqik_core.hpp", "seqik_consts.hpp", "seqik_hip.hip"]   # what the solver kernels are compiled from
+LATENCY_SOURCES = KERNEL_SOURCES + ["seqik_generic.hpp"]   # ... and the generic-chain kernel (profiles/r04_latency_floor.json)
 
 
 def _code_only(text: str) -> str:
@@ -168,6 +187,23 @@ def build(force: bool = False) -> str:
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, u) for u in COMPILE_UNITS]
         subprocess.check_call(cmd, cwd=CSRC)
     return LIB_PATH
+
+
+WATCHDOG_LIB_PATH = os.path.join(CSRC, "libseqik_hip_watchdog.so")
+
+
+def build_watchdog_variant(force: bool = False) -> str:
+    """DIAGNOSTIC build for tests/test_gpu_parity.py::test_pipeline_watchdog_is_reported: the same sources with the stage
+    pipeline's watchdog limit set to ONE pass (``-DSEQIK_PIPE_SPIN_LIMIT=1``), so that the fault path -- NaN in the
+    chain, fault word, ``SEQIK_ERR_HIP`` from the entry points -- can be exercised.  Never loaded by the package itself
+    (only through ``SEQIK_LIB`` in a child process of that test)."""
+    stale = (not os.path.exists(WATCHDOG_LIB_PATH) or
+             any(os.path.getmtime(os.path.join(CSRC, s)) > os.path.getmtime(WATCHDOG_LIB_PATH) for s in SOURCES))
+    if force or stale:
+        cmd = ([_hipcc()] + HIPCC_FLAGS + ["-DSEQIK_PIPE_SPIN_LIMIT=1", "-o", WATCHDOG_LIB_PATH] +
+               [os.path.join(CSRC, u) for u in COMPILE_UNITS])
+        subprocess.check_call(cmd, cwd=CSRC)
+    return WATCHDOG_LIB_PATH
 
 
 def load():
@@ -223,6 +259,10 @@ def load():
                                              ctypes.POINTER(SeqikOptions), ctypes.c_void_p]
         L.seqik_selftest_div_sqrt.restype = ctypes.c_int
         L.seqik_selftest_div_sqrt.argtypes = [_dp, _dp, _dp, _dp, ctypes.c_int64]
+        L.seqik_selftest_sqrt_pos.restype = ctypes.c_int
+        L.seqik_selftest_sqrt_pos.argtypes = [_dp, _dp, ctypes.c_int64]
+        L.seqik_check_faults.restype = ctypes.c_int
+        L.seqik_check_faults.argtypes = []
         L.seqik_frame_chunk_plan.restype = ctypes.c_int
         L.seqik_frame_chunk_plan.argtypes = [ctypes.c_int64, ctypes.POINTER(SeqikOptions), _ip, _ip,
                                              ctypes.POINTER(ctypes.c_int64)]
@@ -283,7 +323,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
-                    "seqik_validate_legs", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt",
+                    "seqik_validate_legs", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_selftest_sqrt_pos", "seqik_check_faults",
                     "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
                     "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",

@@ -101,6 +101,7 @@ class DeviceSlab:
                                   layout=self.layout, stream=torch.cuda.current_stream(self.dev).cuda_stream, **kw)
 
     def speculate(self):
+        self.repaired = 0   # statistics describe ONE solve (speculate + its resume calls), not a benchmark loop
         self._call()
 
     def resume(self, left_state, exact: bool = False):

@@ -314,7 +314,10 @@ class LegInvKinSeq(LegInvKinBase):
           library guards the speculation per leg: a leg of which more than one chunk in eight fails its first
           verification (poses with several equivalent leg configurations, kinematic singularities) is walked
           serially instead (``frame_chunk_report[leg]["walked_serially"]``).
-        * ``True`` or a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters (no guard).
+        * ``True``: the same automatic geometry and per-leg guard as ``"auto"``, but a run that cannot be chunked (stage
+          subsets, diagnostics) raises instead of silently walking serially.
+        * a dict with any of ``chunk``, ``halo``, ``tol``, ``rounds``: explicit chunk parameters; an explicit ``chunk`` > 0
+          runs WITHOUT the guard (the guard belongs to the automatic geometry, ``SeqikOptions.frame_chunk = -1``).
 
         After a chunked run ``self.frame_chunk_stats`` holds the statistics of the last launch and
         ``self.frame_chunk_report[leg]`` says where the recording was hard: ``frames_per_chunk``, ``run_in_frames``,
@@ -339,6 +342,7 @@ class LegInvKinSeq(LegInvKinBase):
             raise ValueError("Maximum stage number is 4 and the list should be strictly incremental.")
         first_stage, last_stage = stages[0], stages[-1]
         forward_kinematics_dict = {}
+        self.frame_chunk_stats, self.frame_chunk_report = {}, {}   # describe THIS run only (empty after a serial walk)
         self.logger.info("Computing joint angles and forward kinematics...")
 
         segments = self._leg_segments()

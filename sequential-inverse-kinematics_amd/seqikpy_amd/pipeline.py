@@ -48,9 +48,11 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
         d_pose = torch.from_numpy(pose).cuda(non_blocking=True)
         d_ang = torch.zeros((1, len(segs), n, 7), dtype=torch.float64, device="cuda")
         d_fk = torch.zeros((1, len(segs), n, 9, 3), dtype=torch.float64, device="cuda")
+        # (allocated and zero-filled on the current stream BEFORE leg_stream waits for it: the kernels of the chunked call
+        # write these statistics on leg_stream)
+        d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
         cur = torch.cuda.current_stream()
         leg_stream.wait_stream(cur)
-        d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device="cuda")
         _lib.solve_seq_device(d_pose.data_ptr(), 1, len(segs), n, legs, d_ang.data_ptr(), d_fk.data_ptr(),
                               stream=leg_stream.cuda_stream, frame_chunk=-1 if frame_parallel else 0,
                               d_chunk_stats=d_stats.data_ptr())
@@ -70,6 +72,7 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
                 _lib._raise(rc)
         leg_stream.synchronize()
         head_stream.synchronize()
+        _lib.check_faults()   # the device entry points do not synchronise: a kernel fault is reported here
         ang, fk = d_ang.cpu().numpy(), d_fk.cpu().numpy()
         head = d_head.cpu().numpy() if with_head else None
         if stats is not None:

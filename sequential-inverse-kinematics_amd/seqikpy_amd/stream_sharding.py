@@ -20,7 +20,10 @@ has finished.  So a rank > 0
 
 No data-path collective: per rank H2D 120 B + D2H 56 B (+ 216 B FK) per leg-frame over its own link.  The result equals
 the single-process stream bit for bit unless a repair cascade crosses a rank boundary (module docstring of
-``frame_sharding``).  The alignment constants of the fused prologue are whole-recording order statistics
+``frame_sharding``) or the library's per-chain guard (more than one chunk in eight of a chain failing its first
+verification: the chain is walked serially) fires in a rank's FIRST slab in the single-process stream -- that slab is the
+only one solved here without the guard (it has a run-in in front of it); the carried slabs behind it are opened with the
+automatic geometry and the guard, exactly as the single-process stream opens them.  The alignment constants of the fused prologue are whole-recording order statistics
 (``AlignPose.get_fixed_pos`` / ``get_mean_length``); ``align_stats_all_slabs`` computes them on every rank from all RAW
 slabs (each rank reads them over its own link, so this pass costs what it costs on one GPU and needs no exchange).
 
@@ -71,8 +74,11 @@ def stream_recording_sharded(get_slab: Callable[[int], np.ndarray], get_out: Cal
     st = None
     rounds, restreams = 0, 0
     if k1 > k0:
+        # automatic geometry (a function of T alone, == (C, h) above), as the single-process stream opens it: the carried
+        # slabs then run WITH the library's per-chain guard, like there (advisor, round 3); only this rank's first slab,
+        # which has a run-in in front of its chunk 0 (DeviceSlab below), is outside the guard
         st = SeqikStream(legs, 1, T, affine=affine, layout=layout, want_fk=want_fk, n_slots=n_slots, carry=True,
-                         frame_chunk=C, frame_halo=h)
+                         frame_chunk=-1)
 
     def stream_rest(start_state=None):
         """slabs k0 + 1 .. k1 - 1 (k0 .. on a rank without a left neighbour) behind the given state"""
@@ -103,11 +109,15 @@ def stream_recording_sharded(get_slab: Callable[[int], np.ndarray], get_out: Cal
             return first.end_state()
         return torch.from_numpy(np.ascontiguousarray(get_out(k1 - 1)[0][:, :, :, T - 1]))
 
+    last_left = None
     while world > 1:
         ends = [torch.empty((1, L, 7), dtype=torch.float64, device=coll_dev) for _ in range(world)]
         dist.all_gather(ends, my_end().to(coll_dev).contiguous(), group=group)
         changed = 0
-        if first is not None:
+        # (a left state that is the one this rank resumed from last round needs no second verification: it would cost a
+        # launch and a blocking read of the statistics per exchange round)
+        if first is not None and (last_left is None or not torch.equal(last_left, ends[left_of])):
+            last_left = ends[left_of].clone()
             before = first.end_state().clone()
             first.resume(ends[left_of], exact=True)
             if not torch.equal(before, first.end_state()):   # the repair ran through the whole first slab: stream the rest again

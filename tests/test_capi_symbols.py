@@ -27,7 +27,8 @@ def test_header_declares_expected_entry_points():
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
-                                           "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_stream_open", "seqik_stream_submit",
+                                           "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_selftest_sqrt_pos",
+                                           "seqik_check_faults", "seqik_stream_open", "seqik_stream_submit",
                                            "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry", "seqik_stream_close",
                                            "seqik_align_stats_open", "seqik_align_stats_add", "seqik_align_stats_finish",
                                            "seqik_align_stats_reset", "seqik_align_stats_close"])
@@ -38,7 +39,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 3 == hiplib.ABI_VERSION
+    assert lib.seqik_abi_version() == 4 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):
@@ -67,6 +68,13 @@ def test_validate_legs_error_codes(hiplib):
         hiplib.validate_legs([hiplib.leg_params_from_arrays(seg, bb, seeds)])
     with pytest.raises(ValueError, match="Maximum stage number is 4"):
         hiplib.validate_legs([good], 2, 5)
+    # floating-point contract (csrc/seqik_core.hpp): a limit of exactly 0 is served (the shipped tables have three), a
+    # non-zero limit below 2^-600 in magnitude is refused
+    tiny = b.copy()
+    tiny[3] = (tiny[3][0], 1e-250)
+    with pytest.raises(ValueError, match="smaller than 2\\^-600"):
+        hiplib.validate_legs([hiplib.leg_params_from_arrays(seg, tiny, seeds)])
+    assert any(0.0 in (lo, hi) for lo, hi in b)
 
 
 def test_solve_rejects_bad_arguments_before_touching_the_gpu(hiplib):

@@ -3,11 +3,13 @@
 BASELINE.json's full sizes."""
 import os
 import pickle
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from conftest import DOFS, good_frames, leg_arrays, load_golden
+from conftest import DOFS, GOLDEN, PKG_PARENT, ROOT, good_frames, leg_arrays, load_golden
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4  # rad -- BASELINE.json north star
@@ -571,3 +573,93 @@ def test_device_division_and_square_root_equal_ieee_on_the_contract_range(lib):
         assert np.array_equal(np.signbit(q[~np.isnan(want)]), np.signbit(want[~np.isnan(want)]))
         ws = np.sqrt(aa)
         assert np.array_equal(np.isnan(r), np.isnan(ws)) and np.array_equal(r[~np.isnan(ws)], ws[~np.isnan(ws)])
+
+
+def test_coleman_li_square_root_at_limits_of_exactly_zero(lib):
+    """Advisor finding of round 3.  The shipped limits contain exact zeros (CTr_pitch ub, FTi_pitch lb, TiTa_pitch ub): a
+    trial point that lands on such a limit is put at next_toward(0, .) = +-2^-1074 by make_strictly_feasible(rstep = 0), and
+    the Coleman-Li distance v = |x - bound| of the next pass is the smallest subnormal -- outside the [2^-767, 2^767] range
+    the range-scaling-free sqrt_ / sqrt_pos_ are stated for.  What the kernels rely on, checked on the device:
+      * sqrt_pos_ and sqrt_ of 2^-1074 and of every subnormal / tiny EVEN power of two are exact (the results are powers of
+        two; the hardware seed v_rsq_f64 is exact there and the Newton corrections vanish);
+      * the values that occur with the shipped limits -- lb_in - lb, ub - ub_in for every joint of every leg of both
+        bounds tables, i.e. 2^-1074 next to a zero limit and one ulp of the limit otherwise -- come out as IEEE sqrt;
+      * normal operands down to 2^-767 come out as IEEE sqrt (the stated range, select-free variant).
+    Subnormals that are not powers of two cannot be produced by the solver from limits that are 0 or of ordinary
+    magnitude (the next iterate after 2^-1074 is x + d p_h with d = sqrt(v) = 2^-537); seqik_validate_legs rejects limits
+    whose magnitude is positive but below 2^-600, which is the only way to get there."""
+    from seqikpy_amd import data
+    with np.errstate(all="ignore"):
+        even = np.ldexp(1.0, np.arange(-1074, -700, 2))
+        assert np.array_equal(lib.selftest_sqrt_pos(even), np.sqrt(even))
+        assert np.array_equal(lib.selftest_div_sqrt(even, np.ones_like(even))[1], np.sqrt(even))
+        vals = []
+        for table in (data.BOUNDS, data.BOUNDS_LOCOMOTION):
+            for lb, ub in table.values():
+                vals += [np.nextafter(lb, ub) - lb, ub - np.nextafter(ub, lb)]
+        vals = np.array(sorted(set(vals)))
+        assert vals.min() == 2.0 ** -1074           # the case the finding is about is in the shipped tables
+        assert np.array_equal(lib.selftest_sqrt_pos(vals), np.sqrt(vals))
+        rng = np.random.default_rng(5)
+        wide = np.ldexp(1.0 + rng.random(1 << 18), rng.integers(-767, 767, 1 << 18))
+        assert np.array_equal(lib.selftest_sqrt_pos(wide), np.sqrt(wide))
+        # where the iteration stops being exact (documentation of the boundary, not a requirement): subnormal operands
+        # that are not powers of two
+        sub = np.ldexp(1.0 + rng.random(4096), rng.integers(-1074, -1023, 4096))
+        sub = sub[sub > 0]
+        frac_exact = float(np.mean(lib.selftest_sqrt_pos(sub) == np.sqrt(sub)))
+        print(f"sqrt_pos_ on random subnormals: {100 * frac_exact:.1f} % equal to IEEE")
+
+
+def test_pipeline_watchdog_is_reported(lib):
+    """The stage pipeline's watchdog (run_stage, PIPED: a lane that sits out more than PIPE_SPIN_LIMIT passes) cannot trip
+    by construction; if it ever does the result must not pass silently (the reference raises, never returns garbage:
+    seqikpy/leg_inverse_kinematics.py:62-69 -> IKPy raises on scipy status -1).  A DIAGNOSTIC build of the same sources
+    with the limit set to one pass (csrc/libseqik_hip_watchdog.so, built by __graft_entry__.build()) trips it at once:
+    the blocking entry point returns SEQIK_ERR_HIP with a message, the asynchronous one leaves the fault for
+    seqik_check_faults() / the next call, every launch still terminates, and the product build reports nothing."""
+    from seqikpy_amd import _lib
+    if not os.path.exists(_lib.WATCHDOG_LIB_PATH):
+        _lib.build_watchdog_variant()
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from seqikpy_amd import _lib
+z = np.load(%r)
+legs = [str(l) for l in z["legs"]]
+pose = np.stack([z[f"{l}_pose"][:40] for l in legs])[None]
+params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+try:
+    _lib.solve_seq(pose, params, pipeline=2)
+    print("HOST: no error")
+except _lib.SeqikLibraryError as e:
+    print("HOST:", e)
+_lib.check_faults()                       # the blocking call has consumed the fault
+print("CLEARED")
+d_pose = torch.from_numpy(pose).cuda(); d_ang = torch.zeros((1, len(legs), 40, 7), dtype=torch.float64, device="cuda")
+_lib.solve_seq_device(d_pose.data_ptr(), 1, len(legs), 40, params, d_ang.data_ptr(), pipeline=2)
+torch.cuda.synchronize()
+print("NAN" if bool(torch.isnan(d_ang).any()) else "NO NAN")
+try:
+    _lib.check_faults()
+    print("DEVICE: no error")
+except _lib.SeqikLibraryError as e:
+    print("DEVICE:", e)
+out = _lib.solve_seq(pose, params, pipeline=1)   # lane-per-chain kernels have no pipeline: clean
+print("SERIAL OK" if np.isfinite(out["angles"]).all() else "SERIAL BAD")
+''' % (PKG_PARENT, ROOT, os.path.join(GOLDEN, "df3d_100.npz"))
+    env = dict(os.environ, SEQIK_LIB=_lib.WATCHDOG_LIB_PATH)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "HOST: seqik: HIP error: seqik_solve_seq: stage pipeline watchdog" in out, out
+    assert "CLEARED" in out and "NAN" in out and "NO NAN" not in out, out
+    assert "DEVICE: seqik: HIP error: seqik_check_faults: stage pipeline watchdog" in out, out
+    assert "SERIAL OK" in out, out
+    # the product build: same calls, no fault
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    pose = np.stack([z[f"{l}_pose"][:40] for l in legs])[None]
+    params = [lib.leg_params_from_arrays(*leg_arrays(z, l)[1:]) for l in legs]
+    assert np.isfinite(lib.solve_seq(pose, params, pipeline=2)["angles"]).all()
+    lib.check_faults()
