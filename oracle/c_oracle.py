@@ -169,12 +169,15 @@ def sincos(x):
 
 
 # --- test hooks: algorithm variants kept in the C file for comparison (defaults in brackets) -----------------------
-def set_variant(tr2_shortcut=None, closed_form_2x2=None, generic_svd=None, analytic_jacobian=None):
+def set_variant(tr2_shortcut=None, closed_form_2x2=None, generic_svd=None, analytic_jacobian=None, generic_rtl=None,
+                woodbury_form=None):
     """tr2_shortcut [True]: shortcut of scipy's ten-iteration root search when the Gauss-Newton step is inside the
     trust region (False = the loop verbatim); closed_form_2x2 [True]: closed-form trust-region step for two
     unknowns (False = one-sided Jacobi SVD); generic_svd [False]: SVD-based step for the generic chain (default:
     3 x 3 push-through form); analytic_jacobian [False]: geometric Jacobian instead of scipy's 2-point differences
-    (rejected, see the C file)."""
+    (rejected, see the C file); generic_rtl [True]: the generic chain's claw position as a vector pushed through the
+    links right to left (False = last column of the left-to-right matrix product, as the sequential stages);
+    woodbury_form [1]: 0 = the round-3 form of the 3 x 3 step (two general solves per evaluation)."""
     L = lib()
     if tr2_shortcut is not None:
         L.oracle_set_tr2_shortcut(1 if tr2_shortcut else 0)
@@ -184,7 +187,12 @@ def set_variant(tr2_shortcut=None, closed_form_2x2=None, generic_svd=None, analy
         L.oracle_set_generic_mode(0 if generic_svd else 2)
     if analytic_jacobian is not None:
         L.oracle_set_analytic_jacobian(1 if analytic_jacobian else 0)
+    if generic_rtl is not None:
+        L.oracle_set_generic_rtl(1 if generic_rtl else 0)
+    if woodbury_form is not None:
+        L.oracle_set_woodbury_form(int(woodbury_form))
 
 
 def reset_variants():
-    set_variant(tr2_shortcut=True, closed_form_2x2=True, generic_svd=False, analytic_jacobian=False)
+    set_variant(tr2_shortcut=True, closed_form_2x2=True, generic_svd=False, analytic_jacobian=False, generic_rtl=True,
+                woodbury_form=1)

@@ -173,6 +173,7 @@ typedef struct {
     double axis[MAXN][3];    /* rotation axis (un-normalised, may be 0) */
     double lb[MAXN], ub[MAXN];
     double base[MAXN][16];   /* T(trans) . H(RPY) -- filled by chain_prepare */
+    int rtl;                 /* residual(): end-effector position by the right-to-left VECTOR recursion (generic chain) */
 } oracle_chain;
 
 static void mat4_identity(double *m)
@@ -283,9 +284,48 @@ static void chain_fk(const oracle_chain *ch, const double *q, double *last, doub
     if (last) memcpy(last, frame, sizeof(frame));
 }
 
+/* The end-effector position FK(x)[:3,3] = (M_0 M_1 ... M_{n-1}) e_4 evaluated RIGHT TO LEFT as a vector,
+ *     v = e_4;  v <- M_i v  for i = n-1 .. 0,
+ * instead of as the last column of the left-to-right matrix product of chain_fk: 12 multiply-adds per link instead of 64,
+ * the same real number, another association order, so the last bits differ.  Used for the GENERIC chain only
+ * (oracle_chain.rtl, set by build_generic_chain): its seven joint angles cannot be pinned against the reference anyway
+ * -- the reference does not reproduce them itself (profiles/r04_perturbation_generic.json) -- while its claw is pinned to
+ * 1e-6 (tests/test_generic.py).  The sequential stages keep chain_fk, which the shipped outputs pin.  Each row runs
+ *     acc = M[r][3];  acc = FMA(M[r][2], v[2], acc);  acc = FMA(M[r][1], v[1], acc);  acc = FMA(M[r][0], v[0], acc)
+ * (translation first, column index descending): with the exact zeros and ones of an axis rotation dropped this is what
+ * csrc/seqik_generic.hpp writes out per axis (link_apply), two multiply-adds per changed coordinate.
+ * oracle_set_generic_rtl(0) restores the matrix product (test hook, tests/test_oracle_golden.py). */
+static int g_generic_rtl = 1;
+void oracle_set_generic_rtl(int on) { g_generic_rtl = on; }
+static void chain_end_effector_rtl(const oracle_chain *ch, const double *q, double *pos)
+{
+    double v[3] = {0.0, 0.0, 0.0}, m[16];
+    for (int i = ch->n - 1; i >= 0; --i) {
+        link_frame_matrix(ch, i, q[i], m);
+        double w[3];
+        for (int r = 0; r < 3; ++r) {
+            double acc = m[4 * r + 3];
+            acc = FMA(m[4 * r + 2], v[2], acc);
+            acc = FMA(m[4 * r + 1], v[1], acc);
+            acc = FMA(m[4 * r + 0], v[0], acc);
+            w[r] = acc;
+        }
+        v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+    }
+    pos[0] = v[0]; pos[1] = v[1]; pos[2] = v[2];
+}
+
 /* residual of Chain.inverse_kinematics: FK(x)[:3,3] - target */
 static void residual(const oracle_chain *ch, const double *x, const double *target, double *f)
 {
+    if (ch->rtl) {
+        double pos[3];
+        chain_end_effector_rtl(ch, x, pos);
+        f[0] = pos[0] - target[0];
+        f[1] = pos[1] - target[1];
+        f[2] = pos[2] - target[2];
+        return;
+    }
     double frame[16];
     chain_fk(ch, x, frame, NULL);
     f[0] = frame[3] - target[0];
@@ -598,8 +638,17 @@ static void woodbury_solve(int n, double Jh[NRES][MAXN], const double *W, const 
     }
 }
 
-/* p(alpha) (un-negated: pp = (B + J_h^T J_h)^-1 J_h^T f), phi and the Newton ratio phi / phi' */
-static void woodbury_phi(int n, double Jh[NRES][MAXN], const double *diag_h, const double *rhs /* J_h^T f */,
+/* p(alpha) (un-negated: pp = (B + J_h^T J_h)^-1 J_h^T f), phi and the Newton ratio phi / phi'.
+ * Two algebraically identical forms.  form 0 (round 3): two general solves with woodbury_solve, one for J_h^T f and one for
+ * pp.  form 1 (default): the push-through identity applied once more,
+ *     pp = W J_h^T y,  y = (I + J_h W J_h^T)^-1 f            (the right-hand side IS J_h^T f: no 7-vector product in front)
+ *     pp^T (B + J_h^T J_h)^-1 pp = pp^T W pp - u^T (I + J_h W J_h^T)^-1 u,  u = J_h W pp
+ * -- 37 + 54 multiply-adds instead of 65 + 72 per evaluation.  The angles of the generic chain are not pinned by the reference
+ * (see chain_end_effector_rtl), so the form is this restatement's to choose; the kernel mirrors form 1 operation for
+ * operation.  oracle_set_woodbury_form(0) restores form 0 (test hook). */
+static int g_woodbury_form = 1;
+void oracle_set_woodbury_form(int form) { g_woodbury_form = form; }
+static void woodbury_phi(int n, double Jh[NRES][MAXN], const double *diag_h, const double *rhs /* J_h^T f */, const double *f,
                          double alpha, double Delta, double *pp, double *phi, double *ratio)
 {
     double W[MAXN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6], q[MAXN];
@@ -610,11 +659,40 @@ static void woodbury_phi(int n, double Jh[NRES][MAXN], const double *diag_h, con
         M[3] = FMA(w1, Jh[1][c], M[3]); M[4] = FMA(w1, Jh[2][c], M[4]); M[5] = FMA(w2, Jh[2][c], M[5]);
     }
     sym3_inverse(M, Minv);
-    woodbury_solve(n, Jh, W, Minv, rhs, pp);
+    if (g_woodbury_form == 0) {
+        woodbury_solve(n, Jh, W, Minv, rhs, pp);
+        if (phi) {
+            double p_norm = vnorm(pp, n);
+            woodbury_solve(n, Jh, W, Minv, pp, q);
+            double acc = vdot(pp, q, n);
+            *phi = p_norm - Delta;
+            *ratio = -(*phi * p_norm) / acc;
+        }
+        return;
+    }
+    double y[3];
+    y[0] = FMA(Minv[2], f[2], FMA(Minv[1], f[1], Minv[0] * f[0]));
+    y[1] = FMA(Minv[4], f[2], FMA(Minv[3], f[1], Minv[1] * f[0]));
+    y[2] = FMA(Minv[5], f[2], FMA(Minv[4], f[1], Minv[2] * f[0]));
+    for (int c = 0; c < n; ++c) {
+        double z = FMA(Jh[2][c], y[2], FMA(Jh[1][c], y[1], Jh[0][c] * y[0]));
+        pp[c] = W[c] * z;
+    }
     if (phi) {
         double p_norm = vnorm(pp, n);
-        woodbury_solve(n, Jh, W, Minv, pp, q);
-        double acc = vdot(pp, q, n);
+        double wa[MAXN], u[3], t[3];
+        for (int c = 0; c < n; ++c) wa[c] = W[c] * pp[c];
+        double s1 = vdot(wa, pp, n);
+        for (int k = 0; k < 3; ++k) {
+            double acc = 0.0;
+            for (int c = 0; c < n; ++c) acc = FMA(Jh[k][c], wa[c], acc);
+            u[k] = acc;
+        }
+        t[0] = FMA(Minv[2], u[2], FMA(Minv[1], u[1], Minv[0] * u[0]));
+        t[1] = FMA(Minv[4], u[2], FMA(Minv[3], u[1], Minv[1] * u[0]));
+        t[2] = FMA(Minv[5], u[2], FMA(Minv[4], u[1], Minv[2] * u[0]));
+        double s2 = FMA(u[2], t[2], FMA(u[1], t[1], u[0] * t[0]));
+        double acc = s1 - s2;
         *phi = p_norm - Delta;
         *ratio = -(*phi * p_norm) / acc;
     }
@@ -638,7 +716,7 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
             if (it < 9) a_k = -1.0;
         }
         double phi, ratio;
-        woodbury_phi(n, Jh, diag_h, rhs, a_k, Delta, pp, &phi, &ratio);
+        woodbury_phi(n, Jh, diag_h, rhs, f, a_k, Delta, pp, &phi, &ratio);
         if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
             alpha = a_k - (phi + Delta) * ratio * inv_Delta;
             goto final_step;
@@ -648,14 +726,14 @@ static void solve_tr_woodbury(int n, double Jh[NRES][MAXN], const double *diag_h
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
         double phi, ratio;
-        woodbury_phi(n, Jh, diag_h, rhs, alpha, Delta, pp, &phi, &ratio);
+        woodbury_phi(n, Jh, diag_h, rhs, f, alpha, Delta, pp, &phi, &ratio);
         if (phi < 0) alpha_upper = alpha;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
 final_step:
-    woodbury_phi(n, Jh, diag_h, rhs, alpha, Delta, pp, NULL, NULL);
+    woodbury_phi(n, Jh, diag_h, rhs, f, alpha, Delta, pp, NULL, NULL);
     double scale = Delta / vnorm(pp, n);
     for (int c = 0; c < n; ++c) p[c] = -(pp[c] * scale);
     *alpha_io = alpha;
@@ -1213,6 +1291,7 @@ static void build_generic_chain(oracle_chain *ch, const double *seg, const doubl
     REV(7, -seg[2], AX_Y, D_TITA);
     set_link(ch, 8, -seg[3], NULL, AX_0, -PI, PI);
     chain_prepare(ch);
+    ch->rtl = g_generic_rtl;
 #undef FIXED
 #undef REV
 }

@@ -87,9 +87,9 @@ def demangle_hint(name):
     m = re.search(r"seqik_chunk_kernelILb(\d)ELi(\d)E", name)
     if m:
         return f"chunk_kernel<fk={m.group(1)},mode={m.group(2)}>"
-    m = re.search(r"seqik_generic_kernelILb(\d)E", name)
+    m = re.search(r"seqik_generic_kernelILb(\d)ELb(\d)E", name)
     if m:
-        return f"generic_kernel<diag={m.group(1)}>"
+        return f"generic_kernel<diag={m.group(1)},grouped={m.group(2)}>"
     return name
 
 
@@ -169,7 +169,7 @@ def main():
     want = ("fused_kernel<fk=1>", "stage_kernel<1,fk=0,diag=0,from_angles=0,handoff=1>",
             "stage_kernel<2,fk=1,diag=0,from_angles=0,handoff=1>", "stage_kernel<3,fk=1,diag=0,from_angles=0,handoff=1>",
             "stage_kernel<4,fk=1,diag=0,from_angles=0,handoff=0>", "pipe_kernel<fk=1,wpe=3>", "pipe_kernel<fk=1,wpe=2>",
-            "chunk_kernel<fk=1,mode=0>", "generic_kernel<diag=0>")
+            "chunk_kernel<fk=1,mode=0>", "generic_kernel<diag=0,grouped=1>", "generic_kernel<diag=0,grouped=0>")
     for name, k in kernels.items():
         tag = demangle_hint(name)
         if tag in want:

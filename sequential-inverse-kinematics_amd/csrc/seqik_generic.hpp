@@ -9,9 +9,16 @@
 //
 // The problem is rank-deficient by construction (7 unknowns, 3 equations).  In the reference the
 // step inside the null space is decided by LAPACK round-off, so only the claw position
-// -- not the individual angles -- can be compared with the reference.  What IS exact: this file
-// mirrors the generic code path of oracle/seqik_oracle.c (oracle_generic_leg) operation for
+// -- not the individual angles -- can be compared with the reference (the reference does not reproduce its
+// own angles under a 1-ulp change of its input: profiles/r04_perturbation_generic.json).  What IS exact:
+// this file mirrors the generic code path of oracle/seqik_oracle.c (oracle_generic_leg) operation for
 // operation, so kernel == oracle bit for bit, as for the sequential stages.
+//
+// Since the angles are not pinned, the association order of the forward kinematics is the restatement's to choose
+// (round-3 review): the claw position is evaluated RIGHT TO LEFT as a 3-vector pushed through the seven links
+// (generic_claw: 30 instructions) instead of as the last column of the left-to-right product of 3 x 4 frames
+// (generic_chain: 150, now only used once per frame for the stored joint positions), and the trust-region step uses
+// the push-through identity twice (woodbury_phi).  A pass is ~30 % shorter; oracle_generic_leg makes the same choices.
 #pragma once
 #include "seqik_core.hpp"
 
@@ -50,12 +57,90 @@ SEQIK_HD void generic_chain(const GenericConst &gc, const double *sn, const doub
     frame_mul_link<AXIS_Y>(out, a, sn[6], cs[6], gc.tz[6]);
 }
 
-SEQIK_HD void generic_residual(const GenericConst &gc, const double *sn, const double *cs, const double *target, double *f)
+// v <- [R_axis(s, c) | (0, 0, tz)] v : one link applied to a position vector.  Row r of the oracle's general form
+//     acc = M[r][3]; acc = fma(M[r][2], v[2], acc); acc = fma(M[r][1], v[1], acc); acc = fma(M[r][0], v[0], acc)
+// (chain_end_effector_rtl) with the exact zeros and ones of the axis rotation dropped.
+template <int AXIS>
+SEQIK_HD void link_apply(double s, double c, double tz, double *v)
 {
-    Frame e;
-    generic_chain(gc, sn, cs, e, nullptr, nullptr);
+    const double x = v[0], y = v[1], z = v[2];
+    if constexpr (AXIS == AXIS_X) {          // [1 0 0 | 0] [0 c -s | 0] [0 s c | tz]
+        v[1] = fma_(c, y, (-s) * z);
+        v[2] = fma_(s, y, fma_(c, z, tz));
+    } else if constexpr (AXIS == AXIS_Y) {   // [c 0 s | 0] [0 1 0 | 0] [-s 0 c | tz]
+        v[0] = fma_(c, x, s * z);
+        v[2] = fma_(-s, x, fma_(c, z, tz));
+    } else {                                 // [c -s 0 | 0] [s c 0 | 0] [0 0 1 | tz]
+        v[0] = fma_(c, x, (-s) * y);
+        v[1] = fma_(s, x, c * y);
+        v[2] = z + tz;
+    }
+}
+
+// link I of the generic chain: roll(Z) yaw(X) pitch(Y) CTr_pitch(Y) CTr_roll(Z) FTi(Y) TiTa(Y)
+template <int I>
+SEQIK_HD void generic_link_apply(const GenericConst &gc, double s, double c, double *v)
+{
+    constexpr int AXIS = (I == 0 || I == 4) ? AXIS_Z : (I == 1 ? AXIS_X : AXIS_Y);
+    link_apply<AXIS>(s, c, gc.tz[I], v);
+}
+
+// links FROM - 1 .. 0 applied to v (the part of the chain in FRONT of link FROM)
+template <int FROM>
+SEQIK_HD void generic_links_below(const GenericConst &gc, const double *sn, const double *cs, double *v)
+{
+    if constexpr (FROM > 0) {
+        generic_link_apply<FROM - 1>(gc, sn[FROM - 1], cs[FROM - 1], v);
+        generic_links_below<FROM - 1>(gc, sn, cs, v);
+    }
+}
+
+// Claw position relative to the origin: v = (0, 0, tz_claw) (the claw link), then links 6 .. 0.
+// suf (nullable, [GN][3]): suf[k] = the vector after links 6 .. k have been applied, k = 1 .. 6, and suf[0]... is not
+// kept (it is the result); used by the finite-difference columns, which share the part behind the perturbed link.
+SEQIK_HD void generic_claw(const GenericConst &gc, const double *sn, const double *cs, double *v, double (*suf)[3] = nullptr)
+{
+    v[0] = 0.0; v[1] = 0.0; v[2] = gc.tz_claw;
+#define SEQIK_GEN_STEP(I)                                                     \
+    generic_link_apply<I>(gc, sn[I], cs[I], v);                               \
+    if (suf) { suf[I][0] = v[0]; suf[I][1] = v[1]; suf[I][2] = v[2]; }
+    SEQIK_GEN_STEP(6) SEQIK_GEN_STEP(5) SEQIK_GEN_STEP(4) SEQIK_GEN_STEP(3) SEQIK_GEN_STEP(2) SEQIK_GEN_STEP(1)
+#undef SEQIK_GEN_STEP
+    generic_link_apply<0>(gc, sn[0], cs[0], v);
+}
+
+// the same with joint jm's sin / cos replaced by (s1, c1): one finite-difference column per lane of a group
+SEQIK_HD void generic_claw_perturbed(const GenericConst &gc, const double *sn, const double *cs, int jm, double s1, double c1, double *v)
+{
+    v[0] = 0.0; v[1] = 0.0; v[2] = gc.tz_claw;
+#define SEQIK_GEN_STEP(I) generic_link_apply<I>(gc, (jm == I) ? s1 : sn[I], (jm == I) ? c1 : cs[I], v);
+    SEQIK_GEN_STEP(6) SEQIK_GEN_STEP(5) SEQIK_GEN_STEP(4) SEQIK_GEN_STEP(3) SEQIK_GEN_STEP(2) SEQIK_GEN_STEP(1) SEQIK_GEN_STEP(0)
+#undef SEQIK_GEN_STEP
+}
+
+SEQIK_HD void generic_residual(const GenericConst &gc, const double *sn, const double *cs, const double *target, double *f,
+                               double (*suf)[3] = nullptr)
+{
+    double v[3];
+    generic_claw(gc, sn, cs, v, suf);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) f[i] = (e.r[3 * i + 2] * gc.tz_claw + e.t[i]) - target[i];
+    for (int i = 0; i < 3; ++i) f[i] = v[i] - target[i];
+}
+
+// column J of the finite-difference Jacobian's perturbed residual, from the shared suffix: links 6 .. J + 1 at the base
+// angles (suf[J + 1], or the claw link alone for J = 6), link J at (s1, c1), links J - 1 .. 0 at the base angles -- the same
+// operations on the same values as generic_claw_perturbed(jm = J)
+template <int J>
+SEQIK_HD void generic_residual_column(const GenericConst &gc, const double *sn, const double *cs, const double (*suf)[3],
+                                      double s1, double c1, const double *target, double *f1)
+{
+    double v[3];
+    if constexpr (J == GN - 1) { v[0] = 0.0; v[1] = 0.0; v[2] = gc.tz_claw; }
+    else { v[0] = suf[J + 1][0]; v[1] = suf[J + 1][1]; v[2] = suf[J + 1][2]; }
+    generic_link_apply<J>(gc, s1, c1, v);
+    generic_links_below<J>(gc, sn, cs, v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f1[i] = v[i] - target[i];
 }
 
 SEQIK_HD double vnorm7(const double *a)
@@ -160,33 +245,12 @@ SEQIK_HD void sym3_inverse(const double *m /* 00 01 02 11 12 22 */, double *inv)
     inv[0] = c00 * r; inv[1] = c01 * r; inv[2] = c02 * r; inv[3] = c11 * r; inv[4] = c12 * r; inv[5] = c22 * r;
 }
 
-// q = (B + J_h^T J_h)^-1 r  given W = 1 / (diag_h + alpha) and Minv = (I + J_h W J_h^T)^-1
-SEQIK_HD void woodbury_solve(const double Jh[3][GN], const double *W, const double *Minv, const double *r, double *q)
-{
-    double wr[GN], t[3], y[3];
-#pragma unroll
-    for (int c = 0; c < GN; ++c) wr[c] = W[c] * r[c];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < GN; ++c) acc = fma_(Jh[k][c], wr[c], acc);
-        t[k] = acc;
-    }
-    y[0] = fma_(Minv[2], t[2], fma_(Minv[1], t[1], Minv[0] * t[0]));
-    y[1] = fma_(Minv[4], t[2], fma_(Minv[3], t[1], Minv[1] * t[0]));
-    y[2] = fma_(Minv[5], t[2], fma_(Minv[4], t[1], Minv[2] * t[0]));
-#pragma unroll
-    for (int c = 0; c < GN; ++c) {
-        double jy = fma_(Jh[2][c], y[2], fma_(Jh[1][c], y[1], Jh[0][c] * y[0]));
-        q[c] = fma_(-W[c], jy, wr[c]);
-    }
-}
-
-// pp = (B + J_h^T J_h)^-1 J_h^T f (the un-negated step), and -- when WANT_PHI -- phi and the Newton ratio phi / phi'
+// pp = (B + J_h^T J_h)^-1 J_h^T f (the un-negated step), and -- when WANT_PHI -- phi and the Newton ratio phi / phi'.
+// Push-through twice (oracle woodbury_phi, form 1):  pp = W J_h^T y  with  y = (I + J_h W J_h^T)^-1 f,  and
+//     pp^T (B + J_h^T J_h)^-1 pp = pp^T W pp - u^T (I + J_h W J_h^T)^-1 u,   u = J_h W pp.
 // jm >= 0: lane group, this lane divides for joint jm only (the seven quotients are the same code on different data)
 template <bool WANT_PHI>
-SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const double *rhs, double alpha, double Delta,
+SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const double *f, double alpha, double Delta,
                            double *pp, double &phi, double &ratio, int jm = -1)
 {
     double W[GN], M[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0}, Minv[6];
@@ -203,12 +267,27 @@ SEQIK_HD void woodbury_phi(const double Jh[3][GN], const double *diag_h, const d
         M[3] = fma_(w1, Jh[1][c], M[3]); M[4] = fma_(w1, Jh[2][c], M[4]); M[5] = fma_(w2, Jh[2][c], M[5]);
     }
     sym3_inverse(M, Minv);
-    woodbury_solve(Jh, W, Minv, rhs, pp);
+    double y[3];
+    y[0] = fma_(Minv[2], f[2], fma_(Minv[1], f[1], Minv[0] * f[0]));
+    y[1] = fma_(Minv[4], f[2], fma_(Minv[3], f[1], Minv[1] * f[0]));
+    y[2] = fma_(Minv[5], f[2], fma_(Minv[4], f[1], Minv[2] * f[0]));
+#pragma unroll
+    for (int c = 0; c < GN; ++c) {
+        double z = fma_(Jh[2][c], y[2], fma_(Jh[1][c], y[1], Jh[0][c] * y[0]));
+        pp[c] = W[c] * z;
+    }
     if constexpr (WANT_PHI) {
-        double q[GN];
         double p_norm = vnorm7(pp);
-        woodbury_solve(Jh, W, Minv, pp, q);
-        double acc = vdot7(pp, q);
+        double wa[GN], u[3], t[3];
+#pragma unroll
+        for (int c = 0; c < GN; ++c) wa[c] = W[c] * pp[c];
+        double s1 = vdot7(wa, pp);
+        matvec37(Jh, wa, u);
+        t[0] = fma_(Minv[2], u[2], fma_(Minv[1], u[1], Minv[0] * u[0]));
+        t[1] = fma_(Minv[4], u[2], fma_(Minv[3], u[1], Minv[1] * u[0]));
+        t[2] = fma_(Minv[5], u[2], fma_(Minv[4], u[1], Minv[2] * u[0]));
+        double s2 = fma_(u[2], t[2], fma_(u[1], t[1], u[0] * t[0]));
+        double acc = s1 - s2;
         phi = p_norm - Delta;
         ratio = div_(-(phi * p_norm), acc);
     }
@@ -238,7 +317,7 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
             if (it < 9) a_k = -1.0;
         }
         double phi, ratio;
-        woodbury_phi<true>(Jh, diag_h, rhs, a_k, Delta, pp, phi, ratio, jm);
+        woodbury_phi<true>(Jh, diag_h, f, a_k, Delta, pp, phi, ratio, jm);
         if (phi < 0 && !(fabs(phi) < 0.01 * Delta)) {
             alpha = a_k - (phi + Delta) * ratio * inv_Delta;
             shortcut = true;
@@ -248,38 +327,51 @@ SEQIK_HD void solve_tr_woodbury(const double Jh[3][GN], const double *diag_h, co
         if (alpha < alpha_lower || alpha > alpha_upper)
             alpha = fmax(0.001 * alpha_upper, sqrt_(alpha_lower * alpha_upper));
         double phi, ratio;
-        woodbury_phi<true>(Jh, diag_h, rhs, alpha, Delta, pp, phi, ratio, jm);
+        woodbury_phi<true>(Jh, diag_h, f, alpha, Delta, pp, phi, ratio, jm);
         if (phi < 0) alpha_upper = alpha;
         alpha_lower = fmax(alpha_lower, alpha - ratio);
         alpha -= (phi + Delta) * ratio * inv_Delta;
         if (fabs(phi) < 0.01 * Delta) break;
     }
     double unused_phi, unused_ratio;
-    woodbury_phi<false>(Jh, diag_h, rhs, alpha, Delta, pp, unused_phi, unused_ratio, jm);
+    woodbury_phi<false>(Jh, diag_h, f, alpha, Delta, pp, unused_phi, unused_ratio, jm);
     double scale = div_(Delta, vnorm7(pp));
 #pragma unroll
     for (int c = 0; c < GN; ++c) p[c] = -(pp[c] * scale);
     alpha_io = alpha;
 }
 
-SEQIK_HD double step_size_to_bound7(const double *x, const double *s, const double *lb, const double *ub, int *hits)
+// _lsq/common.py:step_size_to_bound.  Written WITHOUT branches: the reference-shaped call is one wavefront walking one
+// chain, its time is the latency of its dependent operations, and seven divisions inside seven `if (s[i] != 0)` blocks run one
+// after the other (a basic block is the scheduler's horizon), while seven unconditional ones overlap.  Same values: for
+// s[i] == 0 the quotient (+-inf or NaN) is discarded by the select, as the branch skipped it.  (Measured with the s_memtime
+// stamps, scripts/generic_block_cycles.py: select_step7 was 44 % of a pass of the shipped recording before this.)
+// hit (nullable): this joint's step equals the minimum and its direction is not 0 (scipy's `hits` as a flag).
+// jm >= 0: lane group -- this lane forms the quotients of joint jm only and the group exchanges the seven step lengths.
+SEQIK_HD double step_size_to_bound7(const double *x, const double *s, const double *lb, const double *ub, bool *hit, int jm = -1)
 {
     const double INF = __builtin_huge_val();
     double steps[GN];
-    double min_step = INF;
-    for (int i = 0; i < GN; ++i) {
-        steps[i] = INF;
-        if (s[i] != 0.0) {
-            double inv_s = div_(1.0, s[i]);
-            steps[i] = fmax((lb[i] - x[i]) * inv_s, (ub[i] - x[i]) * inv_s);
-        }
-        if (steps[i] < min_step) min_step = steps[i];
-    }
-    if (hits)
+    if (jm >= 0) {
+        const double sj = pick7(s, jm), xj = pick7(x, jm);
+        const double inv_s = div_(1.0, sj);
+        const double st = fmax((lb[jm] - xj) * inv_s, (ub[jm] - xj) * inv_s);
+        group8_gather((sj != 0.0) ? st : INF, steps);
+    } else {
+#pragma unroll
         for (int i = 0; i < GN; ++i) {
-            int sg = (s[i] > 0) - (s[i] < 0);
-            hits[i] = (steps[i] == min_step) ? sg : 0;
+            const double inv_s = div_(1.0, s[i]);
+            const double st = fmax((lb[i] - x[i]) * inv_s, (ub[i] - x[i]) * inv_s);
+            steps[i] = (s[i] != 0.0) ? st : INF;
         }
+    }
+    // the minimum is exact in any order: a tree instead of a chain
+    const double m01 = fmin(steps[0], steps[1]), m23 = fmin(steps[2], steps[3]), m45 = fmin(steps[4], steps[5]);
+    const double min_step = fmin(fmin(m01, m23), fmin(m45, steps[6]));
+    if (hit) {
+#pragma unroll
+        for (int i = 0; i < GN; ++i) hit[i] = (steps[i] == min_step) && (s[i] != 0.0);
+    }
     return min_step;
 }
 
@@ -292,70 +384,93 @@ SEQIK_HD double evaluate_quadratic7(const double Jh[3][GN], const double *g, con
     return fma_(0.5, q, vdot7(s, g));
 }
 
-// _lsq/trf.py:select_step (in-bounds case included); p, p_h are clobbered
+// _lsq/trf.py:select_step (in-bounds case included); p, p_h are clobbered.
+// The three candidates -- the interior step scaled by theta, the step reflected at the first bound it hits, the
+// constrained Cauchy step -- are scipy's, operation for operation (oracle select_step).  What is specific to this file is the
+// ORDER the independent pieces are written in: everything that does not depend on the strides (the seven-term dot
+// products, the three J_h products, the three bound distances with their 21 divisions) comes first, in one basic block,
+// so that the scheduler can overlap the chains; the scalar stride logic follows.  No value changes.
 SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const double *diag_h, const double *g_h, double *p,
                              double *p_h, const double *d, double Delta, const double *lb, const double *ub, double theta,
-                             double *step, double *step_h)
+                             double *step, double *step_h, int jm = -1)
 {
     const double INF = __builtin_huge_val();
     bool inb = true;
+#pragma unroll
     for (int i = 0; i < GN; ++i) {
         double xp = x[i] + p[i];
         if (!(xp >= lb[i] && xp <= ub[i])) inb = false;
     }
     if (inb) {
         double p_value = evaluate_quadratic7(Jh, g_h, p_h, diag_h);
+#pragma unroll
         for (int i = 0; i < GN; ++i) { step[i] = p[i]; step_h[i] = p_h[i]; }
         return -p_value;
     }
-    int hits[GN];
-    double p_stride = step_size_to_bound7(x, p, lb, ub, hits);
-    double r_h[GN], r[GN], x_on_bound[GN];
+    // ---- stride-independent part of all three candidates ----------------------------------------------------------
+    bool hit[GN];
+    const double p_stride = step_size_to_bound7(x, p, lb, ub, hit, jm);
+    double r_h[GN], r[GN], x_on_bound[GN], pt_h[GN], ag_h[GN], ag[GN];
+#pragma unroll
     for (int i = 0; i < GN; ++i) {
-        r_h[i] = p_h[i];
-        if (hits[i] != 0) r_h[i] = r_h[i] * -1.0;
+        r_h[i] = hit[i] ? p_h[i] * -1.0 : p_h[i];
         r[i] = d[i] * r_h[i];
-    }
-    for (int i = 0; i < GN; ++i) {
         p[i] = p[i] * p_stride;
         p_h[i] = p_h[i] * p_stride;
         x_on_bound[i] = x[i] + p[i];
+        pt_h[i] = p_h[i] * theta;      // the interior step, kept strictly inside
+        ag_h[i] = -g_h[i];
+        ag[i] = d[i] * ag_h[i];
     }
+    // reflected step: distance to the trust-region boundary (the quadratic's coefficients) and to the bounds
+    const double a_tr = vdot7(r_h, r_h);
+    const double b_tr = vdot7(p_h, r_h);
+    const double c_tr = fma_(-Delta, Delta, vdot7(p_h, p_h));
+    const double to_bound_r = step_size_to_bound7(x_on_bound, r, lb, ub, nullptr, jm);
+    // ... and its 1-d model along r_h from p_h (build_quadratic_1d with s0 = p_h)
+    double v[3], u[3], w[3];
+    matvec37(Jh, r_h, v);
+    matvec37(Jh, p_h, u);
+    double a_q = dot3(v, v);
+    a_q = a_q + diag_form7(r_h, diag_h, r_h);
+    a_q = a_q * 0.5;
+    double b_q = vdot7(g_h, r_h);
+    b_q = b_q + dot3(u, v);
+    double c_q = fma_(0.5, dot3(u, u), vdot7(g_h, p_h));
+    b_q = b_q + diag_form7(p_h, diag_h, r_h);
+    c_q = fma_(0.5, diag_form7(p_h, diag_h, p_h), c_q);
+    // interior step scaled by theta
+    const double p_value = evaluate_quadratic7(Jh, g_h, pt_h, diag_h);
+    // anti-gradient (constrained Cauchy) step
+    const double to_tr_ag = div_(Delta, vnorm7(ag_h));
+    const double to_bound_ag = step_size_to_bound7(x, ag, lb, ub, nullptr, jm);
+    matvec37(Jh, ag_h, w);
+    double a_ag = dot3(w, w);
+    a_ag = a_ag + diag_form7(ag_h, diag_h, ag_h);
+    a_ag = a_ag * 0.5;
+    const double b_ag = vdot7(g_h, ag_h);
+    // ---- strides ---------------------------------------------------------------------------------------------------
     double to_tr;
     {
-        double a = vdot7(r_h, r_h);
-        double b = vdot7(p_h, r_h);
-        double c = fma_(-Delta, Delta, vdot7(p_h, p_h));
-        double dd = sqrt_(fma_(b, b, -(a * c)));
-        double q = -(b + copysign(dd, b));
-        double t1 = div_(q, a);
-        double t2 = div_(c, q);
+        double dd = sqrt_(fma_(b_tr, b_tr, -(a_tr * c_tr)));
+        double q = -(b_tr + copysign(dd, b_tr));
+        double t1 = div_(q, a_tr);
+        double t2 = div_(c_tr, q);
         to_tr = (t1 < t2) ? t2 : t1;
     }
-    double to_bound = step_size_to_bound7(x_on_bound, r, lb, ub, nullptr);
-    double r_stride = fmin(to_bound, to_tr);
+    double r_stride = fmin(to_bound_r, to_tr);
     double r_stride_l, r_stride_u;
     if (r_stride > 0) {
         r_stride_l = div_((1 - theta) * p_stride, r_stride);
-        r_stride_u = (r_stride == to_bound) ? theta * to_bound : to_tr;
+        r_stride_u = (r_stride == to_bound_r) ? theta * to_bound_r : to_tr;
     } else {
         r_stride_l = 0;
         r_stride_u = -1;
     }
     double r_value;
     if (r_stride_l <= r_stride_u) {
-        double v[3], u[3];
-        matvec37(Jh, r_h, v);
-        double a = dot3(v, v);
-        a = a + diag_form7(r_h, diag_h, r_h);
-        a = a * 0.5;
-        double b = vdot7(g_h, r_h);
-        matvec37(Jh, p_h, u);
-        b = b + dot3(u, v);
-        double c = fma_(0.5, dot3(u, u), vdot7(g_h, p_h));
-        b = b + diag_form7(p_h, diag_h, r_h);
-        c = fma_(0.5, diag_form7(p_h, diag_h, p_h), c);
-        r_stride = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c, r_value);
+        r_stride = minimize_quadratic_1d(a_q, b_q, r_stride_l, r_stride_u, c_q, r_value);
+#pragma unroll
         for (int i = 0; i < GN; ++i) {
             r_h[i] = r_h[i] * r_stride;
             r_h[i] = r_h[i] + p_h[i];
@@ -364,33 +479,37 @@ SEQIK_HD double select_step7(const double *x, const double Jh[3][GN], const doub
     } else {
         r_value = INF;
     }
-    for (int i = 0; i < GN; ++i) { p[i] = p[i] * theta; p_h[i] = p_h[i] * theta; }
-    double p_value = evaluate_quadratic7(Jh, g_h, p_h, diag_h);
-
-    double ag_h[GN], ag[GN];
-    for (int i = 0; i < GN; ++i) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
-    to_tr = div_(Delta, vnorm7(ag_h));
-    to_bound = step_size_to_bound7(x, ag, lb, ub, nullptr);
-    double ag_stride = (to_bound < to_tr) ? theta * to_bound : to_tr;
+    double ag_stride = (to_bound_ag < to_tr_ag) ? theta * to_bound_ag : to_tr_ag;
     double ag_value;
-    {
-        double v[3];
-        matvec37(Jh, ag_h, v);
-        double a = dot3(v, v);
-        a = a + diag_form7(ag_h, diag_h, ag_h);
-        a = a * 0.5;
-        double b = vdot7(g_h, ag_h);
-        ag_stride = minimize_quadratic_1d(a, b, 0.0, ag_stride, 0.0, ag_value);
-    }
+    ag_stride = minimize_quadratic_1d(a_ag, b_ag, 0.0, ag_stride, 0.0, ag_value);
+#pragma unroll
     for (int i = 0; i < GN; ++i) { ag_h[i] = ag_h[i] * ag_stride; ag[i] = ag[i] * ag_stride; }
 
     const bool take_p = p_value < r_value && p_value < ag_value;
     const bool take_r = !take_p && r_value < p_value && r_value < ag_value;
+#pragma unroll
     for (int i = 0; i < GN; ++i) {  // value selects, no pointer select: the candidates stay in registers
-        step[i] = take_p ? p[i] : (take_r ? r[i] : ag[i]);
-        step_h[i] = take_p ? p_h[i] : (take_r ? r_h[i] : ag_h[i]);
+        // (p * theta is formed again here instead of being kept since the top: 14 multiplications against 56 register copies)
+        step[i] = take_p ? p[i] * theta : (take_r ? r[i] : ag[i]);
+        step_h[i] = take_p ? p_h[i] * theta : (take_r ? r_h[i] : ag_h[i]);
     }
     return -(take_p ? p_value : (take_r ? r_value : ag_value));
+}
+
+// finite-difference column J of the one-lane code (_numdiff.py 2-point scheme, as fd_jacobian of the sequential stages)
+template <int J>
+SEQIK_HD void fd_column(const GenericConst &gc, const double *x, const double *sn, const double *cs, const double (*suf)[3],
+                        const double *target, const double *f, double Jm[3][GN])
+{
+    double h = fd_step(x[J], gc.lb[J], gc.ub[J]);
+    double x1 = x[J] + h;
+    double dx = x1 - x[J];
+    double s1, c1, f1[3];
+    sincos_cw(x1, s1, c1);
+    generic_residual_column<J>(gc, sn, cs, suf, s1, c1, target, f1);
+    double inv_dx = div_(1.0, dx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Jm[k][J] = (f1[k] - f[k]) * inv_dx;
 }
 
 struct GenericIO {
@@ -427,7 +546,14 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
     bool first_pass = true, new_solve = true;
     int64_t t = 0;
 
+    // (diagnostic build only, -DSEQIK_BLOCK_CYCLES=1: the s_memtime stamps of run_stage, scripts/generic_block_cycles.py;
+    // block names as used here: new_solve, fd_jacobian = step + sin / cos + chain + gather of the columns, scaling_gtol =
+    // gradient, Coleman-Li scaling, radius, d, J_h, tr_step = solve_tr_woodbury, in_bounds = select_step7, reflective =
+    // trial point + its sin / cos + gather, trial_eval = chain + cost, post_trial, finished)
+    SEQIK_BLK_DECL
     while (t < io.n_frames) {
+        SEQIK_BLK_PASS();
+        SEQIK_BLK_END_OF(BLK_LOOP);
         if (new_solve) {
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + 4 * io.pose_row;  // the claw is the end effector (:587)
@@ -460,6 +586,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
         }
 
         bool finished = false;
+        SEQIK_BLK_END_OF(BLK_NEW_SOLVE);
         if (WANT_DIAG || status == STATUS_NONE) {
             // ---- 2-point finite-difference Jacobian: column j perturbs joint j only ---------------
             double J[3][GN], g[GN], v[GN], dv[GN];
@@ -468,27 +595,22 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double h = fd_step(xj, gc.lb[jm], gc.ub[jm]);
                 double x1 = xj + h;
                 double dx = x1 - xj;
-                double s1, c1, sp[GN], cp[GN], f1[3];
+                double s1, c1, v1[3];
                 sincos_cw(x1, s1, c1);
-#pragma unroll
-                for (int i = 0; i < GN; ++i) { sp[i] = (i == jm) ? s1 : sn[i]; cp[i] = (i == jm) ? c1 : cs[i]; }
-                generic_residual(gc, sp, cp, target, f1);
+                generic_claw_perturbed(gc, sn, cs, jm, s1, c1, v1);
                 double inv_dx = div_(1.0, dx);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) group8_gather((f1[k] - f[k]) * inv_dx, J[k]);
+                for (int k = 0; k < 3; ++k) group8_gather(((v1[k] - target[k]) - f[k]) * inv_dx, J[k]);
             } else {
-                for (int j = 0; j < GN; ++j) {
-                    double h = fd_step(x[j], gc.lb[j], gc.ub[j]);
-                    double x1 = x[j] + h;
-                    double dx = x1 - x[j];
-                    double s_keep = sn[j], c_keep = cs[j], f1[3];
-                    sincos_cw(x1, sn[j], cs[j]);
-                    generic_residual(gc, sn, cs, target, f1);
-                    sn[j] = s_keep; cs[j] = c_keep;
-                    double inv_dx = div_(1.0, dx);
-                    for (int k = 0; k < 3; ++k) J[k][j] = (f1[k] - f[k]) * inv_dx;
-                }
+                // the columns share the part of the chain behind the perturbed link (suf, at the base angles)
+                double suf[GN][3], vb[3];
+                generic_claw(gc, sn, cs, vb, suf);
+                fd_column<0>(gc, x, sn, cs, suf, target, f, J); fd_column<1>(gc, x, sn, cs, suf, target, f, J);
+                fd_column<2>(gc, x, sn, cs, suf, target, f, J); fd_column<3>(gc, x, sn, cs, suf, target, f, J);
+                fd_column<4>(gc, x, sn, cs, suf, target, f, J); fd_column<5>(gc, x, sn, cs, suf, target, f, J);
+                fd_column<6>(gc, x, sn, cs, suf, target, f, J);
             }
+            SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
             for (int j = 0; j < GN; ++j) {
                 g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
                 cl_scaling_gated(x[j], g[j], gc.lb[j], gc.ub[j], gc.gate_lb[j], gc.gate_ub[j], v[j], dv[j]);
@@ -501,8 +623,11 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 if (Delta == 0) Delta = 1.0;
                 first_pass = false;
             }
-            double g_norm = 0.0;
-            for (int j = 0; j < GN; ++j) { double a = fabs(g[j] * v[j]); if (a > g_norm) g_norm = a; }
+            // ||g * v||_inf: the maximum is exact in any order (the products are >= +0 after fabs), so a tree of fmax gives
+            // the oracle's running `if (a > g_norm) g_norm = a` value with a third of the dependent steps
+            double ga[GN];
+            for (int j = 0; j < GN; ++j) ga[j] = fabs(g[j] * v[j]);
+            double g_norm = fmax(fmax(fmax(ga[0], ga[1]), fmax(ga[2], ga[3])), fmax(fmax(ga[4], ga[5]), fmax(ga[6], 0.0)));
             if (g_norm < gtol) status = 1;
 
             if (status != STATUS_NONE || nfev == gc.max_nfev) {
@@ -520,9 +645,12 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 double theta = fmax(0.995, 1 - g_norm);
 
                 double p_h[GN], p[GN], step[GN], step_h[GN];
+                SEQIK_BLK_END_OF(BLK_SCALING);
                 solve_tr_woodbury(Jh, diag_h, f, Delta, alpha, p_h, GROUPED ? jm : -1);
+                SEQIK_BLK_END_OF(BLK_TR_STEP);
                 for (int j = 0; j < GN; ++j) p[j] = d[j] * p_h[j];
-                double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h);
+                double predicted_reduction = select_step7(x, Jh, diag_h, g_h, p, p_h, d, Delta, gc.lb, gc.ub, theta, step, step_h, GROUPED ? jm : -1);
+                SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                 double x_new[GN], sn_n[GN], cs_n[GN], f_new[3];
                 if constexpr (GROUPED) {
                     const double xj = strictly_feasible0(pick7(x, jm) + pick7(step, jm), gc.lb[jm], gc.ub[jm], gc.lb_in[jm], gc.ub_in[jm]);
@@ -535,13 +663,18 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                         sincos_cw(x_new[j], sn_n[j], cs_n[j]);
                     }
                 }
+                SEQIK_BLK_END_OF(BLK_REFLECTIVE);
                 generic_residual(gc, sn_n, cs_n, target, f_new);
                 nfev += 1;
-                double step_h_norm = vnorm7(step_h);
                 double cost_new = 0.5 * dot3(f_new, f_new);
+                SEQIK_BLK_END_OF(BLK_TRIAL_EVAL);
+                double step_h_norm = vnorm7(step_h);
                 double actual_reduction = cost - cost_new;
+                // (the quotient is formed unconditionally and selected: a division inside a branch cannot overlap with the
+                // norms next to it; same value wherever scipy uses it)
+                const double ar_over_pr = div_(actual_reduction, predicted_reduction);
                 double ratio;
-                if (predicted_reduction > 0) ratio = div_(actual_reduction, predicted_reduction);
+                if (predicted_reduction > 0) ratio = ar_over_pr;
                 else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
                 else ratio = 0;
                 double Delta_new = Delta;
@@ -557,8 +690,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 if (ftol_ok && xtol_ok) status = 4;
                 else if (ftol_ok) status = 2;
                 else if (xtol_ok) status = 3;
+                const double alpha_scaled = alpha * div_(Delta, Delta_new);
                 if (status == STATUS_NONE) {
-                    alpha = alpha * div_(Delta, Delta_new);
+                    alpha = alpha_scaled;
                     Delta = Delta_new;
                 }
                 if (actual_reduction > 0) {
@@ -572,6 +706,7 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             finished = true;
         }
 
+        SEQIK_BLK_END_OF(BLK_POST_TRIAL);
         if (finished) {
             double *ang = io.angles + t * io.ang_frame;
             for (int j = 0; j < GN; ++j) ang[generic_link_dof(j) * io.ang_dof] = x[j];
@@ -599,7 +734,9 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
             t += 1;
             new_solve = true;
         }
+        SEQIK_BLK_END_OF(BLK_FINISHED);
     }
+    SEQIK_BLK_END(1);
 }
 
 }  // namespace seqik

@@ -861,7 +861,10 @@ struct GenericKernelArgs {
 #ifndef SEQIK_GENERIC_WAVES_PER_EU
 #define SEQIK_GENERIC_WAVES_PER_EU 1
 #endif
-template <bool WANT_DIAG>
+// GROUPED: the thin-wave instantiation (every chain on a group of 8 lanes, seqik_generic.hpp "Lane groups") is a kernel of
+// its own, so that its registers are allocated for it alone: compiled together with the one-lane code it inherited that
+// code's demand (256 VGPRs + 92 AGPRs) and spent 7 % of a pass on v_accvgpr copies.
+template <bool WANT_DIAG, bool GROUPED>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_GENERIC_WAVES_PER_EU, SEQIK_GENERIC_WAVES_PER_EU)))
 seqik_generic_kernel(GenericKernelArgs a)
 {
@@ -884,9 +887,7 @@ seqik_generic_kernel(GenericKernelArgs a)
     io.nfev = a.nfev ? a.nfev + c * a.n_frames : nullptr;
     io.init = a.init ? a.init + c * 7 : nullptr;
     io.n_frames = a.n_frames;
-    const int W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
-    if (a.lane_groups != 0 && lane_groups(W)) seqik::run_generic<WANT_DIAG, true>(s_legs[leg].gc, s_legs[leg].aff, io);  // wave-uniform
-    else seqik::run_generic<WANT_DIAG, false>(s_legs[leg].gc, s_legs[leg].aff, io);
+    seqik::run_generic<WANT_DIAG, GROUPED>(s_legs[leg].gc, s_legs[leg].aff, io);
 }
 
 // Device copies of the per-leg constant tables.  Callers almost always pass the same legs on every call, so the
@@ -1490,8 +1491,13 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     }
     const dim3 grid((unsigned)((n_waves * 64 + block - 1) / block)), blk(block);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    if (d_status || d_nfev) hipLaunchKernelGGL(seqik_generic_kernel<true>, grid, blk, 0, stream, a);
-    else hipLaunchKernelGGL(seqik_generic_kernel<false>, grid, blk, 0, stream, a);
+    const int W_abs = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
+    const bool grouped = a.lane_groups != 0 && W_abs <= 8;  // lane_groups(W): the replication is then a multiple of 8
+    if (d_status || d_nfev) {
+        if (grouped) hipLaunchKernelGGL((seqik_generic_kernel<true, true>), grid, blk, 0, stream, a);
+        else hipLaunchKernelGGL((seqik_generic_kernel<true, false>), grid, blk, 0, stream, a);
+    } else if (grouped) hipLaunchKernelGGL((seqik_generic_kernel<false, true>), grid, blk, 0, stream, a);
+    else hipLaunchKernelGGL((seqik_generic_kernel<false, false>), grid, blk, 0, stream, a);
     HIP_TRY(hipGetLastError());
     return SEQIK_OK;
 }

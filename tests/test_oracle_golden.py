@@ -123,5 +123,15 @@ def test_algorithm_variants_kept_as_hooks(oracle):
         oracle.set_variant(generic_svd=False)
         b = oracle.generic_leg(zg["RF_pose"], zg["RF_seg"], zg["RF_bounds"], zg["RF_seeds"][18:27])
         assert np.abs(a["fk"][:, 8] - b["fk"][:, 8]).max() < 1e-6
+        # round 4: the generic chain's forward kinematics evaluated right to left as a vector and the 3 x 3 step in its
+        # second push-through form are other association orders of the same numbers: same claw (1e-6), comparable
+        # evaluation counts; the angles -- which the reference itself does not reproduce -- may differ
+        for kw in (dict(generic_rtl=False), dict(woodbury_form=0), dict(generic_rtl=False, woodbury_form=0)):
+            oracle.set_variant(**kw)
+            a = oracle.generic_leg(zg["RF_pose"], zg["RF_seg"], zg["RF_bounds"], zg["RF_seeds"][18:27])
+            oracle.reset_variants()
+            assert np.abs(a["fk"][:, 8] - b["fk"][:, 8]).max() < 1e-6, kw
+            assert np.abs(a["fk"][:, 8] - zg["RF_fk"][:, 8]).max() < 1e-6, kw
+            assert 0.8 < a["nfev"].mean() / b["nfev"].mean() < 1.25, kw
     finally:
         oracle.reset_variants()

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- bound, IN ISSUE CYCLES, of what a chain queue could give the lane-per-chain kernel (round-3 review,
+item 5): "a lane that finishes its chain pulls the next chain of its leg; per-wave tails become one per stage per GPU".
+
+Inputs
+  * the oracle's per-solve evaluation counts on the benchmark data (synthetic iid / smooth, 64-frame sequences): a lane's
+    passes in a stage = sum over its frames of (nfev - 1), one trial evaluation per pass, + 1 pass per solve that scipy
+    ends with status 1 (the gtol test sits at the top of the NEXT pass);
+  * the diagnostic build's measurements of the final round-3 kernels (profiles/r03_block_entries_*.json): for every
+    conditional block of a pass its share of the wave cycles, how often a wavefront enters it per pass and with how
+    many active lanes.  From them a cost model of ONE wave pass as a function of the number of active lanes n:
+        cost(n) = sum over blocks b of  P_b(n) x cycles_per_entry(b),   P_b(n) = 1 - (1 - q_b)^n,
+    q_b = the per-lane probability of needing block b in a pass (lane entries of b / lane passes), cycles_per_entry(b) =
+    share(b) x cycles per pass / entries per pass.  A pass costs the UNION of its lanes' paths: a tail pass with 3 lanes
+    is cheaper than a full one, which is exactly why a bound in passes overstates the gain.
+
+Schedules compared (stage-major, as the kernel: a wave finishes stage s for all its chains before stage s + 1)
+  now        64 chains per wave, one per lane (what seqik_fused_kernel does)
+  queue m    the same 64 lanes own a pool of 64 m chains of their leg; a lane that finishes a chain pulls the next one
+             (greedy list scheduling, the best a work queue can do without knowing the costs)
+  packed     every lane always busy: sum of lane passes / 64 full passes (unreachable floor)
+m is bounded by the LAUNCH: one benchmark step = 93 750 chains, the GPU holds 3 072 waves = 196 608 lanes, so a lone
+job has m < 1 and the three steps the benchmark keeps in flight are three launches, each with m = 1 per wave.  A queue
+only has something to pull when a launch carries several times more chains than the GPU has lanes; the table says
+what that would buy (m = 2, 4, 8: launches of 2 / 4 / 8 M frames x 6 legs with half / a quarter / an eighth of the
+waves).
+
+    python tests/tools/queue_bound.py  > profiles/r04_queue_bound.json         (CPU, ~1 min)
+"""
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
+
+import numpy as np  # noqa: E402
+
+from oracle import c_oracle  # noqa: E402
+from seqikpy_amd import data, synthetic, utils  # noqa: E402
+
+BLOCKS = {  # block of the cycle breakdown -> the entry counter that says when a wave goes through it
+    "new_solve": "new_solve", "finished": "finished", "reflective": "reflective",
+    # everything else is executed by every lane that is in the body of a pass
+    "loop": "body", "fd_jacobian": "body", "scaling_gtol": "body", "tr_step": "body", "in_bounds": "body",
+    "trial_eval": "body", "post_trial": "body"}
+
+
+def cost_model(entries_json, stage):
+    st = entries_json["stages"][str(stage)]
+    cpp, share, epp, lanes = st["cycles_per_pass"], st["share"], st["entries_per_pass"], st["active_lanes_per_entry"]
+    body_lane_entries = epp["body"] * lanes["body"]
+    model = []
+    for blk, counter in BLOCKS.items():
+        if blk not in share:
+            continue
+        cycles_per_entry = share[blk] * cpp / epp[counter]
+        q = min(1.0, epp[counter] * lanes[counter] / body_lane_entries)   # per lane and pass
+        model.append((q, cycles_per_entry))
+    return model
+
+
+def pass_cost(model, n):
+    n = np.asarray(n, dtype=np.float64)
+    return sum((1.0 - (1.0 - q) ** n) * c for q, c in model)
+
+
+def wave_cost_now(model, passes):
+    """passes: (64,) lane pass counts of one wave and stage -> (wave passes, cost)"""
+    srt = np.sort(passes)
+    life = int(srt[-1])
+    # active lanes at pass p (0-based) = lanes whose count exceeds p
+    active = 64 - np.searchsorted(srt, np.arange(life), side="right")
+    return life, float(pass_cost(model, active).sum())
+
+
+def wave_cost_queue(model, chain_passes):
+    """greedy pull: 64 lanes, chains in pool order; returns (wave passes, cost)"""
+    import heapq
+    n_chains = len(chain_passes)
+    free_at = [(int(chain_passes[i]), i) for i in range(min(64, n_chains))]   # (time the lane gets free, lane)
+    heapq.heapify(free_at)
+    ends = []
+    nxt = len(free_at)
+    while free_at:
+        t, lane = heapq.heappop(free_at)
+        if nxt < n_chains:
+            heapq.heappush(free_at, (t + int(chain_passes[nxt]), lane))
+            nxt += 1
+        else:
+            ends.append(t)
+    ends = np.sort(np.array(ends))
+    life = int(ends[-1])
+    # all 64 lanes busy until the first lane runs dry, then as in `now`
+    active = len(ends) - np.searchsorted(ends, np.arange(life), side="right")
+    return life, float(pass_cost(model, active).sum())
+
+
+def lane_passes(variant, n_seq, n_frames=64, seed=synthetic.SEED_BASE):
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    pose = synthetic.synthetic_pose(n_seq, n_frames, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION,
+                                    variant=variant, seed=seed)
+    out = np.zeros((len(legs), n_seq, 4), dtype=np.int64)
+
+    def one(args):
+        li, s = args
+        seg, b, seeds = c_oracle.leg_params(legs[li], data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+        r = c_oracle.seq_leg(pose[s, li], seg, b, seeds, want_fk=False)
+        out[li, s] = (r["nfev"] - 1 + (r["status"] == 1)).sum(0)
+
+    c_oracle.lib()
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(one, [(li, s) for li in range(len(legs)) for s in range(n_seq)]))
+    return out
+
+
+def main():
+    n_seq = 2048   # 32 waves per leg
+    res = {"what": __doc__.split("\n\n")[0].replace("\n", " "),
+           "sample": f"{n_seq} sequences x 6 legs x 64 frames per variant (the benchmark's generator and seeds), "
+                     "per-solve evaluation counts from the C oracle; pass-cost model from profiles/r03_block_entries_*.json"}
+    for variant in ("iid", "smooth"):
+        ej = json.load(open(os.path.join(ROOT, "profiles", f"r03_block_entries_{variant}.json")))
+        p = lane_passes(variant, n_seq)                     # (L, S, 4)
+        models = {s: cost_model(ej, s) for s in (1, 2, 3, 4)}
+        rows = {}
+        for name, m in (("now", 1), ("queue_m2", 2), ("queue_m4", 4), ("queue_m8", 8)):
+            wave_passes = cost = 0.0
+            for li in range(p.shape[0]):
+                for w0 in range(0, n_seq, 64 * m):
+                    for s in (1, 2, 3, 4):
+                        chunk = p[li, w0:w0 + 64 * m, s - 1]
+                        life, c = wave_cost_now(models[s], chunk) if m == 1 else wave_cost_queue(models[s], chunk)
+                        wave_passes += life
+                        cost += c
+            rows[name] = {"wave_passes": wave_passes, "cycles": cost}
+        packed_passes = sum(p[:, :, s - 1].sum() / 64.0 for s in (1, 2, 3, 4))
+        packed_cost = sum(p[:, :, s - 1].sum() / 64.0 * float(pass_cost(models[s], 64)) for s in (1, 2, 3, 4))
+        rows["packed"] = {"wave_passes": float(packed_passes), "cycles": float(packed_cost)}
+        now = rows["now"]
+        for r in rows.values():
+            r["passes_vs_now"] = r["wave_passes"] / now["wave_passes"]
+            r["cycles_vs_now"] = r["cycles"] / now["cycles"]
+        # sanity of the model against the measurement it was built from: predicted cycles per wave pass now vs measured
+        # (the diagnostic build's `cycles_per_pass` is per pass of LANE 0; a wave makes entries_per_pass["body"] passes per
+        # pass of its lane 0 -- 1.22 .. 1.56 -- so the cycles of one real wave pass are the quotient)
+        meas = {s: ej["stages"][str(s)]["cycles_per_pass"] / ej["stages"][str(s)]["entries_per_pass"]["body"] for s in (1, 2, 3, 4)}
+        pred = {}
+        for s in (1, 2, 3, 4):
+            tot_c = tot_p = 0.0
+            for li in range(p.shape[0]):
+                for w0 in range(0, n_seq, 64):
+                    life, c = wave_cost_now(models[s], p[li, w0:w0 + 64, s - 1])
+                    tot_c += c
+                    tot_p += life
+            pred[s] = tot_c / tot_p
+        rows["model_check_cycles_per_wave_pass"] = {"predicted": pred, "measured_r03": meas}
+        rows["full_pass_cost_over_3_lane_pass_cost"] = {s: float(pass_cost(models[s], 64) / pass_cost(models[s], 3)) for s in (1, 2, 3, 4)}
+        res[variant] = rows
+    res["reading"] = ("`now` -> `packed` is everything lane balancing could ever give; `queue_m` is what a chain queue gives when a "
+                      "LAUNCH carries 64 m chains per wave.  One benchmark step is 93 750 chains on 196 608 lane slots (m < 1), "
+                      "and the steps in flight are separate launches, so for config 3 as BASELINE.json states it (1M frames x 6 "
+                      "legs per GPU and step) the queue has nothing to pull: gain 0.  cycles_vs_now of queue_m2 is what doubling "
+                      "the step to 2M frames with half the waves would buy in steady state, at twice the step latency and a "
+                      "slower lone job.")
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
