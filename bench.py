@@ -129,7 +129,7 @@ BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
 BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 + 24, 4: 48 + 96 + 8 + 144}
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
-TRAFFIC_ROUNDS = ("r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
+TRAFFIC_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
 LF_WINDOW = (284, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
@@ -409,9 +409,10 @@ def measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step):
     ones (~2.7).  None when the files are absent."""
     try:
         costs = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue_costs.json")))["classes"]
-        isa = json.load(open(os.path.join(ROOT, "profiles", "r03_fused_isa.json")))["kernels"]["fused_kernel<fk=1>"]
+        isa_path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_fused_isa.json") for r in ("r04", "r03")) if os.path.exists(p))
+        isa = json.load(open(isa_path))["kernels"]["fused_kernel<fk=1>"]
         share4 = isa["valu_not_f64_arith_issue_split"]["share_about_4.2_cycles"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
     c = lambda name: costs[name]["waves_per_simd_3"]["cycles_per_inst"]  # noqa: E731
     c_f64 = (c("v_fma_f64") + c("v_mul_f64") + c("v_add_f64")) / 3.0
@@ -657,10 +658,16 @@ def reference_configs(time_box_s=240.0):
                        "(profiles/r04_perturbation_generic.json: real scipy vs real scipy + 1 ulp), so the claw, the limits and "
                        "the smoothness of the joint series are what can be pinned; HIP == C restatement bit for bit (tests)"}
     # ---- latency floors of the two latency-bound kernels (item: "latency-bound" as a number) -------------------------
-    for key, entry, kernel_key, ms_key in (("4", out["4"], "config4_serial_walk", None), ("generic", out["generic"], "generic_rf_6000", None)):
+    for entry, kernel_key, live_ms in ((out["4"], "config4_serial_walk", out["4"]["default"]["ms"]),
+                                       (out["generic"], "generic_rf_6000", out["generic"]["ms"])):
         fl = latency_floor(kernel_key)
         if fl:
-            entry["latency_floor"] = fl
+            keep = ("kernel", "issue_floor_ms", "latency_floor_frac", "critical_stage", "kernel_ms", "kernel_ms_lane_pairs_on",
+                    "kernel_ms_lane_pairs_off", "valu_insts_per_frame")
+            entry["latency_floor"] = {k: fl[k] for k in keep if k in fl}
+            entry["latency_floor"]["source"] = "profiles/r04_latency_floor.json (rocprofv3 PMC instruction counts of one wavefront x lone-wavefront issue costs)"
+            # live: the committed floor against THIS run's whole call (upload + kernel + download, host clock)
+            entry["latency_floor_frac"] = fl["issue_floor_ms"] / live_ms
     # ---- config 5: streamed from pinned host slabs, alignment fused, PCIe-inclusive ----------------------------------
     spec = importlib.util.spec_from_file_location("stream_config5", os.path.join(ROOT, "scripts", "stream_config5.py"))
     sc5 = importlib.util.module_from_spec(spec)
@@ -783,12 +790,8 @@ def main():
     # CU slots as solver waves retire) does not hold back the launch that wants to reuse its buffer
     n_buf = max(2, len(streams) + (2 if use_dist else 0))
     d_ang = [batch.angle_buffer() for _ in range(n_buf)]
-    # final joint-angle gather: peer writes over xGMI when every rank can map rank 0's buffers and the copies are
-    # not pathologically slow (a block needs 336 MB / 14 ms = 24 GB/s per link to keep up; a link that cannot do
-    # that is no faster under RCCL, and the peer writes at least leave the root's compute units alone), grouped
-    # RCCL point-to-point otherwise; the measured link rate is reported in config.gather
-    gather, gather_how = (peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=8.0)
-                          if use_dist else (None, None))
+    # final joint-angle gather: chosen below (choose_gather), once timed_region exists
+    gather, gather_how, gather_calibration = None, None, None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -828,6 +831,42 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tmax = float(t.item())
         return tmax, mine
+
+    def choose_gather():
+        """The final joint-angle gather of the headline.  BASELINE.json's north star names it: "RCCL over xGMI only for the
+        final joint-angle gather" -- so on a real multi-GPU job (process group on RCCL) grouped RCCL point-to-point is the
+        DEFAULT, and the copy-engine peer writes (seqikpy_amd/peer_gather.py: no compute unit busy on either GPU) replace
+        it only when a short calibration IN THIS RUN -- the same batch, the same process group, 6 steps each -- measures
+        them at least 5 % faster on the slowest rank (they never saw two GPUs before the driver's scaling run, so the
+        choice is made from a measurement, not from the one-GPU rehearsal).  Both figures go into config.gather.
+        SEQIK_GATHER=rccl|peer forces one.  Ranks that share a GPU (rehearsal, process group on gloo): peer writes, as
+        gloo would stage every block through the host.  -> (pipeline, description, calibration or None)"""
+        if not use_dist:
+            return None, None, None
+        rehearse = os.environ.get("SEQIK_BENCH_CALIBRATE_GATHER") == "1"   # run the calibration on a gloo rehearsal too (tests)
+        if os.environ.get("SEQIK_GATHER") or world == 1 or (backend != "nccl" and not rehearse):
+            g, how = peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, min_gbps=8.0)
+            return g, how, None
+        k_cal, cal, cands = 6, {}, {}
+        for how in ("rccl", "peer"):
+            g2, desc = peer_gather.make_gather(dist, world, rank, d_ang[0], n_buffers=n_buf, prefer=how, min_gbps=8.0)
+            if how == "peer" and not isinstance(g2, peer_gather.PeerWriteGather):
+                cal["peer"] = {"unavailable": desc}     # it fell back to the RCCL pipeline on every rank alike
+                if hasattr(g2, "close"):
+                    g2.close()
+                continue
+            tm, _ = timed_region(batch, d_ang, g2, k_cal, 2)        # max over ranks: every rank sees the same figure
+            cal[how] = {"ms_per_step": tm / k_cal * 1e3, "ran_as": desc}
+            cands[how] = (g2, desc, tm)
+        pick = "peer" if ("peer" in cands and cands["peer"][2] < 0.95 * cands["rccl"][2]) else "rccl"
+        for how, (g2, _, _) in cands.items():
+            if how != pick and hasattr(g2, "close"):
+                g2.close()
+        cal["rule"] = "RCCL point-to-point (the north star's gather) unless peer writes are >= 5 % faster in this calibration"
+        cal["chosen"] = pick
+        return cands[pick][0], cands[pick][1], cal
+
+    gather, gather_how, gather_calibration = choose_gather()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     for row in ev:          # torch creates the underlying hipEvent_t lazily, on the first record()
@@ -939,7 +978,8 @@ def main():
                 pose2, _, _, _, units_all2 = workload_for(other_scaling)
                 b2 = Batch(pose2, params, args, n_streams)
                 bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
-                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0)
+                kind = "peer" if isinstance(gather, peer_gather.PeerWriteGather) else "rccl"   # as the headline's
+                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=kind)
                 k2 = max(4, min(40, args.steps))
                 tm, _ = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
                 res = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
@@ -983,7 +1023,8 @@ def main():
                                        if args.variant == "iid" else
                                        "temporally continuous poses (the realistic variant); `parity` holds the shipped recordings"),
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
-                       **({"gather": gather_how} if gather_how else {})},
+                       **({"gather": gather_how} if gather_how else {}),
+                       **({"gather_calibration": gather_calibration} if gather_calibration else {})},
             "roofline": roofline,
             "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
                         "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",

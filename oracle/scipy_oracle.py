@@ -88,6 +88,40 @@ def seq_leg(pose, leg, bounds_dof, body_size, initial_angles, stages=(1, 2, 3, 4
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)
 
 
+def generic_leg(pose, leg, bounds_dof, body_size, initial_angles):
+    """LegInvKinGeneric.calculate_ik_stage (seqikpy/leg_inverse_kinematics.py:474-499) over real scipy: ONE 9-link chain
+    (KinematicChainGeneric, kinematic_chain.py:464-530) follows the claw, frame t warm-started from frame t - 1, frame 0
+    from initial_angles[leg]["stage_4"].  Returns dict(angles (N, 7) in DOFS order, fk (N, 9, 3), status (N,), nfev (N,))."""
+    from ikpy.chain import Chain
+    from seqikpy_amd.kinematic_chain import KinematicChainGeneric
+    pose = np.asarray(pose, dtype=np.float64)
+    n = pose.shape[0]
+    chain = _to_ikpy(KinematicChainGeneric(bounds_dof, [leg], body_size).create_leg_chain(leg))
+    names = [l.name for l in chain.links]
+    cols = [names.index(f"{leg}_{d}") for d in DOFS]
+    origin = pose[:, 0]
+    target = pose[:, 4] - origin
+    sol = np.empty((n, 9))
+    fk = np.zeros((n, 9, 3))
+    status = np.full(n, -1, dtype=np.int32)
+    nfev = np.zeros(n, dtype=np.int32)
+    x0 = np.asarray(initial_angles[leg]["stage_4"], dtype=np.float64)
+    for t in range(n):
+        Chain.solve_log = []
+        sol[t] = chain.inverse_kinematics(target_position=target[t], initial_position=x0 if t == 0 else sol[t - 1])
+        status[t], nfev[t] = Chain.solve_log[-1]
+        fk[t] = np.array([m[:3, 3] for m in chain.forward_kinematics(sol[t], full_kinematics=True)]) + origin[t]
+    Chain.solve_log = None
+    return dict(angles=sol[:, cols], fk=fk, status=status, nfev=nfev)
+
+
+def generic_leg_arrays(pose, seg, bounds, seeds, leg="RF"):
+    """Same, with the array-shaped parameters of the C oracle / the fixtures (seg[4], bounds[7,2], seeds[27])."""
+    body = {f"{leg}_{s}": float(seg[i]) for i, s in enumerate(SEGMENTS)}
+    bd = {f"{leg}_{d}": (float(bounds[i][0]), float(bounds[i][1])) for i, d in enumerate(DOFS)}
+    return generic_leg(pose, leg, bd, body, {leg: {"stage_4": np.asarray(seeds[18:27], dtype=np.float64)}})
+
+
 def seq_leg_arrays(pose, seg, bounds, seeds, leg="RF"):
     """Same, with the array-shaped parameters of the C oracle / the fixtures (seg[4], bounds[7,2], seeds[27])."""
     body = {f"{leg}_{s}": float(seg[i]) for i, s in enumerate(SEGMENTS)}

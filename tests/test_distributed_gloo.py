@@ -102,7 +102,7 @@ def _pipeline_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])   # 8: the size the driver's scaling run ends with
 def test_gather_pipeline_double_buffering(tmp_path, world):
     """Rank 0 posts one receive per peer and step (grouped point-to-point), the peers one send each; buffers
     alternate; what rank 0 sees for step s is every rank's block of step s."""
@@ -185,7 +185,7 @@ def _frame_shard_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_one_recording_sharded_by_frame_over_ranks(tmp_path, oracle, world):
     """610 frames x 3 legs cut into slabs of whole 50-frame chunks over 2 / 3 ranks (the model of the library's chunked
     call stands in for the GPU): every slab speculates from a run-in, end states are all-gathered, each rank > 0 settles
@@ -381,7 +381,7 @@ def _strong_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_strong_scaling_shares_tile_the_fixed_problem(tmp_path, world):
     from seqikpy_amd.sharding import rank_share
     assert [rank_share(10, 4, r, "weak") for r in range(4)] == [(0, 10, 40), (10, 20, 40), (20, 30, 40), (30, 40, 40)]
@@ -440,14 +440,18 @@ def test_bench_launches_its_own_ranks(tmp_path):
     carries the N > 1 extras: ranks seen, per-rank step times, both gathers, the strong leg."""
     import json
     import subprocess
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"   # the calibration a real RCCL job runs before its headline (choose_gather)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--frames", "8192"], env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["roofline"]["frac"] > 0
+    cal = b["config"]["gather_calibration"]
+    assert cal["chosen"] in ("rccl", "peer") and cal["rccl"]["ms_per_step"] > 0 and ("ms_per_step" in cal["peer"] or "unavailable" in cal["peer"])
+    assert ("peer writes" in b["config"]["gather"]) == (cal["chosen"] == "peer")
     m = b["multi_gpu"]
     assert sorted(r_["rank"] for r_ in m["ranks_seen"]) == [0, 1]
     assert m["rank_ms_per_step"]["min"] <= m["rank_ms_per_step"]["max"]
@@ -456,6 +460,30 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert m["strong"]["sequences_per_gpu"] == 64 and m["strong"]["leg_frames_per_step_all_ranks"] == 8192 * 6
     assert sum(m["one_recording"]["frames_per_rank"]) == 8192 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
     assert abs(b["value"] - 2 * 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
+    """Round-3 review, item 4a: the N > 1 path at the largest rank count the GPU box allows beside the test process (the
+    pool's process guard admits 6 processes on a card; an 8-rank rehearsal is not possible there -- the 8-rank host logic
+    runs in the CPU tier on gloo).  Four ranks share the GPU: launcher, process group, calibrated gather choice, library,
+    IPC, streams, both scalings, the one-recording leg -- rc 0, every rank seen."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "1",
+                        "--frames", "32000"], env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    m = b["multi_gpu"]
+    assert b["n_gpus"] == 4 and sorted(r_["rank"] for r_ in m["ranks_seen"]) == [0, 1, 2, 3]
+    assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"]) and "strong" in m and "error" not in m["strong"]
+    assert sum(m["one_recording"]["frames_per_rank"]) == 32000
+    assert b["config"]["gather_calibration"]["chosen"] in ("rccl", "peer")
 
 
 def _frame_shard_gpu_worker(rank, world, port, out_dir):
