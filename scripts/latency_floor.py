@@ -114,9 +114,11 @@ def main():
         "latency_floor_frac": fl / b_ms, "latency_floor_frac_vs_product_launch": fl / a_ms,
         "pipe_kernel_valu_insts_per_wave_pairs_on": p_sq[reps - 1]["SQ_INSTS_VALU"] / p_sq[reps - 1]["SQ_WAVES"],
         "pipe_kernel_valu_insts_per_wave_pairs_off": p_sq[2 * reps - 1]["SQ_INSTS_VALU"] / p_sq[2 * reps - 1]["SQ_WAVES"],
-        "note": "floor = the critical stage's instruction stream (unpaired) at the lone-wavefront issue rate; the product launch "
-                "(lane pairs on) issues fewer instructions per pass than that stream, which is why its fraction can exceed the "
-                "unpaired one"}
+        "note": "floor = the critical stage's instruction stream as the per-stage kernel issues it (no lane pairs, Jacobian re-derived "
+                "in every pass) at the lone-wavefront issue rate.  Both pipeline launches skip the re-derivation after a rejected "
+                "trial (run_stage REUSE: stage 1 rejects 32 % / 10 % of its trials on RF / LF), and the product launch (lane pairs "
+                "on) also splits the two joints of a pass over two lanes: they issue fewer instructions than that stream, so their "
+                "fractions are upper estimates of how close they are to THEIR floors"}
     dst = os.path.join(ROOT, "profiles", f"{rnd}_latency_floor.json")
     json.dump(out, open(dst, "w"), indent=1)
     trace[trace.Kernel_Name.str.contains("seqik_")][["Kernel_Name", "ms"]].to_csv(os.path.join(ROOT, "profiles", f"{rnd}_latency_kernel_trace.csv"), index=False)

@@ -1328,10 +1328,14 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //               io.t_store on (ChainIO); false = the whole chain from frame 0, everything stored.
 //   PIPED     : the hand-off goes through the LDS ring of io.pipe (stage pipeline, see PipeLane) instead of io.frames.
 //   SPLIT     : the lane and its neighbour lane ^ 1 carry the same chain and share the work of a pass ("Lane pairs").
+//   REUSE     : Jacobian, gradient and scaling are kept across passes and not re-derived after a rejected trial when no lane
+//               of the wavefront has moved (see jac_valid below).  Set by the 256-register build of the stage pipeline
+//               (small grids: serial walks, short recordings); the 168-register build would spill the 14 doubles.
 template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false,
-          bool SPLIT = false>
+          bool SPLIT = false, bool REUSE = false>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
+    static_assert(!REUSE || (PIPED && !WANT_DIAG), "REUSE is a stage-pipeline option");
     constexpr bool PAIRED = SPLIT && StageTraits<STAGE>::NA == 2;
     const bool odd = PAIRED && pair_is_odd();
     static_assert(!(PIPED && FROM_ANGLES), "the stage pipeline starts at stage 1");
@@ -1372,6 +1376,16 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     int pipe_spins = 0;  // PIPED: consecutive passes this lane sat out (watchdog only)
     double pe[3] = {0.0, 0.0, 0.0};  // stage 1: end-effector position at x (see the new-solve block)
     bool have_pe = false;
+    // Jacobian, gradient, Coleman-Li scaling and its square root at the current x.  scipy leaves its inner loop
+    // (`while actual_reduction <= 0`) only on an accepted step, so after a REJECTED trial these are what they were; the
+    // pass loop re-derives them anyway (bit-identical values) because in a full wavefront some lane has always just
+    // accepted.  On the stage pipeline a wavefront carries one or a few chains: when NO lane of it has moved since they
+    // were formed (jac_valid on every lane) the finite differences, the gradient, the scaling and the two square roots are
+    // skipped for the whole wavefront.  Stage 1 -- the critical stage of a serial walk -- rejects 32 % (RF) / 10 % (LF) of its
+    // trials on the shipped recording (serial walk of config 4: 122.8 -> 118.2 ms).  REUSE instantiations only; same values
+    // either way.
+    double J[3][2], g[2], v[2], dv[2], d[2];
+    bool jac_valid = false;
 
     // (Tried and dropped: loading the NEXT frame's inputs (key point, origin, prefix frame: 18 doubles) into staging
     // registers at the top of every pass and moving them into place when a lane finishes its frame, so that no lane
@@ -1534,6 +1548,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             status = STATUS_NONE;
             first_pass = true;
             new_solve = false;
+            jac_valid = false;
         }
 
         bool finished = false;
@@ -1545,7 +1560,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             if (__popcll(__ballot(1)) < 32) SEQIK_BLK_COUNT(CNT_BODY_LT32);
 #endif
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
-            double J[3][2], g[2], v[2], dv[2];
+            bool derive = true;
+            if constexpr (REUSE) derive = wave_any(!jac_valid);   // wave-uniform: nobody moved since the last pass
+            if (derive) {
             if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
             else fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
             SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
@@ -1562,9 +1579,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 #endif
             else { v[1] = 1.0; dv[1] = 0.0; }
             // d = sqrt_(v): needed by the trust-region scaling below and by Delta_0 (computed once, here)
-            double d[2];
             d[0] = sqrt_pos_(v[0]);
             d[1] = (NA == 2) ? sqrt_pos_(v[1]) : 1.0;
+            jac_valid = true;
+            }
             if (first_pass) {
                 SEQIK_BLK_COUNT(CNT_FIRST_PASS);
                 // Delta_0 = || x0 / sqrt_(v) || over ALL links (inert entries: v = 1)
@@ -1667,6 +1685,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 }
                 if (actual_reduction > 0) {
                     SEQIK_BLK_COUNT(CNT_ACCEPT);
+                    jac_valid = false;
                     x[0] = x_new[0]; x[1] = x_new[1];
                     f[0] = f_new[0]; f[1] = f_new[1]; f[2] = f_new[2];
                     cost = cost_new;

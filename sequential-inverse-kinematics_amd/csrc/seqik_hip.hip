@@ -381,7 +381,8 @@ struct PipeShared {
 
 // pairs (wave-uniform): the wave carries every chain on an even number of adjacent lanes, lanes 2k / 2k + 1 split the
 // passes of the stages with two active joints between them
-template <bool WANT_FK, bool CHUNK_SPEC_MODE>
+// REUSE: run_stage's option of the same name (the 256-register builds set it)
+template <bool WANT_FK, bool CHUNK_SPEC_MODE, bool REUSE>
 __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane,
                                          bool pairs, int32_t *fault, int base = 0)
 {
@@ -396,13 +397,13 @@ __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::Chain
     pl.produced_out = stage_wave < 3 ? &sh.produced[stage_wave][lane] : nullptr;
     pl.consumed_out = stage_wave < 3 ? &sh.consumed[stage_wave][lane] : nullptr;
     switch (stage_wave + (pairs && stage_wave < 3 ? 4 : 0)) {  // wave-uniform
-    case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
-    case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
-    case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true>(lc, io); break;
-    case 4: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
-    case 5: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
-    case 6: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true>(lc, io); break;
-    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true>(lc, io); break;  // one joint
+    case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
+    case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
+    case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
+    case 4: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
+    case 5: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
+    case 6: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
+    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;  // one joint
     }
 }
 
@@ -442,7 +443,7 @@ seqik_pipe_kernel(KernelArgs a)
     io.init = a.init ? a.init + c * 7 : nullptr;
     io.frames = nullptr;
     io.n_frames = a.n_frames;
-    pipe_run<WANT_FK, false>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
+    pipe_run<WANT_FK, false, WPE == 2>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -768,7 +769,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
         seqik::ChainIO io;
         chunk_io(a, ca, vc, leg, true, io);
         // the four waves of a chunk each record their own joints of the run-in's last frame (disjoint entries)
-        pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
+        pipe_run<WANT_FK, true, WPE == 2>(s_legs[leg], io, sh, stage_wave, lane, use_pairs(a), a.fault);
     } else {
         // the work list of round ca.round (SERIAL: the serial list), spread over the workgroups as thinly as possible; the
         // four stage waves of a workgroup walk the same entries in the same order (the ring counters of a lane keep
@@ -792,7 +793,7 @@ seqik_chunk_pipe_kernel(KernelArgs a, ChunkArgs ca)
                 leg = (int)(vc % a.n_legs);
                 chunk_io(a, ca, vc, leg, false, io, CHUNK_FLAG_REPAIRED);
             }
-            pipe_run<WANT_FK, true>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), a.fault, base);
+            pipe_run<WANT_FK, true, WPE == 2>(s_legs[leg], io, sh, stage_wave, lane, a.lane_pairs != 0 && lane_pairs((int)W), a.fault, base);
             base += (int)(io.n_frames - io.t_begin);
         }
     }
