@@ -31,6 +31,43 @@ BLOCKS = ["loop", "new_solve", "fd_jacobian", "scaling_gtol", "tr_step", "in_bou
           "finished", "pipe_wait"]
 
 
+def recording(a):
+    lib = _lib.load()
+    if not hasattr(lib, "seqik_debug_block_cycles"):
+        raise SystemExit("this library was not built with -DSEQIK_BLOCK_CYCLES=1 (set SEQIK_LIB)")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
+    legs = ["RF", "LF"]
+    params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    pose = np.stack([z[f"{l}_pose"] for l in legs])[None]
+    n = pose.shape[2]
+    d_pose = torch.from_numpy(pose).cuda()
+    d_ang = torch.zeros((1, 2, n, 7), dtype=torch.float64, device="cuda")
+    d_fk = torch.zeros((1, 2, n, 9, 3), dtype=torch.float64, device="cuda")
+    buf = (ctypes.c_ulonglong * (4 * (len(BLOCKS) + 1)))()
+    ebuf = (ctypes.c_ulonglong * (4 * 2 * len(COUNTED)))()
+
+    def run():
+        _lib.solve_seq_device(d_pose.data_ptr(), 1, 2, n, params, d_ang.data_ptr(), d_fk.data_ptr(), pipeline=a.pipeline)
+        torch.cuda.synchronize()
+    run()
+    lib.seqik_debug_block_cycles(None, 1)
+    lib.seqik_debug_block_entries(None, 1)
+    run()
+    lib.seqik_debug_block_cycles(buf, 1)
+    lib.seqik_debug_block_entries(ebuf, 1)
+    c = np.array(list(buf), dtype=np.float64).reshape(4, len(BLOCKS) + 1)
+    e = np.array(list(ebuf), dtype=np.float64).reshape(4, 2, len(COUNTED))
+    out = {"case": "anipose RF + LF x 6000 frames, serial walk", "kernel": "stage pipeline" if a.pipeline >= 2 else "lane per chain",
+           "frames": n, "stages": {}}
+    for st in range(4):
+        cyc, passes = c[st, :-1], max(c[st, -1], 1)
+        out["stages"][str(st + 1)] = {"lane0_passes_both_legs": passes, "wave_cycles_both_legs": float(cyc.sum()),
+                                      "cycles_per_frame_and_leg": float(cyc.sum() / (2 * n)),
+                                      "cycles_per_frame_by_block": {b: round(float(v / (2 * n)), 1) for b, v in zip(BLOCKS, cyc) if v},
+                                      "entries_per_frame": {nm: round(float(e[st, 0, i] / (2 * n)), 3) for i, nm in enumerate(COUNTED) if e[st, 0, i]}}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", default="iid")
@@ -42,7 +79,12 @@ def main():
     ap.add_argument("--no-fk", action="store_true", help="do not ask for the forward kinematics (no FK stores)")
     ap.add_argument("--staged", action="store_true", help="one launch per stage instead of the single launch")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = lane-per-chain fused kernel (the benchmark's), 2 = stage pipeline")
+    ap.add_argument("--recording", action="store_true",
+                    help="the shipped anipose recording (RF + LF x 6000 frames) walked serially instead of the synthetic batch: "
+                         "with --pipeline 2 this is config 4's default path, one workgroup of four stage wavefronts per leg")
     a = ap.parse_args()
+    if a.recording:
+        return recording(a)
     lib = _lib.load()
     if not hasattr(lib, "seqik_debug_block_cycles"):
         raise SystemExit("this library was not built with -DSEQIK_BLOCK_CYCLES=1 (set SEQIK_LIB)")

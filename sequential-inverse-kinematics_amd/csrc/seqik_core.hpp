@@ -1026,6 +1026,146 @@ SEQIK_HD double select_step_reflective(
 }
 
 // ---------------------------------------------------------------------------
+// The same three functions written for LATENCY instead of instruction count (run_stage<..., LAT>: the 256-register build
+// of the stage pipeline, where a wavefront carries one or a few chains and its time is the length of its dependent
+// chains, not its instruction count).  A basic block is the scheduler's horizon: a division inside `if (s[i] != 0)` or
+// `if (a != 0)` cannot overlap with the next one.  Here every quotient is formed unconditionally and selected, and
+// everything that does not depend on the strides comes first, in one block.  Same operations on the same operands wherever
+// the original uses a value; the discarded quotients (zero direction, a == 0) are +-inf / NaN and never selected.
+// Measured with the s_memtime stamps on config 4's serial walk: the reflective branch was 2 864 cycles per entry, 25 % of the
+// critical stage-1 wavefront (scripts/block_cycles.py --recording --pipeline 2; EXPERIMENTS.md 4.11).  The lane-per-chain
+// kernels keep the compact forms above: they are bound by issue, and these issue more.
+// ---------------------------------------------------------------------------
+template <int NA>
+SEQIK_HD double step_size_to_bound_ilp(const double *x, const double *s, const double *lb, const double *ub, bool *hit)
+{
+    const double INF = __builtin_huge_val();
+    const double inv0 = div_(1.0, s[0]);
+    const double st0 = fmax((lb[0] - x[0]) * inv0, (ub[0] - x[0]) * inv0);
+    double steps[2] = {(s[0] != 0.0) ? st0 : INF, INF};
+    if constexpr (NA == 2) {
+        const double inv1 = div_(1.0, s[1]);
+        const double st1 = fmax((lb[1] - x[1]) * inv1, (ub[1] - x[1]) * inv1);
+        steps[1] = (s[1] != 0.0) ? st1 : INF;
+    }
+    const double min_step = fmin(steps[0], steps[1]);
+    if (hit) {
+        hit[0] = (steps[0] == min_step) && (s[0] != 0.0);
+        hit[1] = (NA == 2) && (steps[1] == min_step) && (s[1] != 0.0);
+    }
+    return min_step;
+}
+
+// minimize_quadratic_1d with the extremum -b / (2a) formed by the caller (unconditionally, early)
+SEQIK_HD double minimize_quadratic_1d_ext(double a, double b, double lb, double ub, double c, double extremum, double &y_out)
+{
+    double tbest = lb;
+    double ybest = fma_(lb, fma_(a, lb, b), c);
+    {
+        double y = fma_(ub, fma_(a, ub, b), c);
+        if (y < ybest) { ybest = y; tbest = ub; }
+    }
+    if (a != 0 && lb < extremum && extremum < ub) {
+        double y = fma_(extremum, fma_(a, extremum, b), c);
+        if (y < ybest) { ybest = y; tbest = extremum; }
+    }
+    y_out = ybest;
+    return tbest;
+}
+
+template <int NA>
+SEQIK_HD double select_step_reflective_ilp(
+    const double *x, const double Jh[3][2], const double *diag_h, const double *g_h, double *p, double *p_h,
+    const double *d, double Delta, const double *lb, const double *ub, double theta, double *step, double *step_h)
+{
+    const double INF = __builtin_huge_val();
+    // ---- stride-independent part of the three candidates ----------------------------------------------------------------
+    bool hit[2];
+    const double p_stride = step_size_to_bound_ilp<NA>(x, p, lb, ub, hit);
+    double r_h[2], r[2], x_on_bound[2], pt_h[2], ag_h[2], ag[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        r_h[i] = hit[i] ? p_h[i] * -1.0 : p_h[i];
+        r[i] = d[i] * r_h[i];
+        p[i] = p[i] * p_stride;
+        p_h[i] = p_h[i] * p_stride;
+        x_on_bound[i] = x[i] + p[i];
+        pt_h[i] = p_h[i] * theta;
+        ag_h[i] = -g_h[i];
+        ag[i] = d[i] * ag_h[i];
+    }
+    const double a_tr = dot2v<NA>(r_h, r_h);
+    const double b_tr = dot2v<NA>(p_h, r_h);
+    const double c_tr = fma_(-Delta, Delta, dot2v<NA>(p_h, p_h));
+    const double to_bound_r = step_size_to_bound_ilp<NA>(x_on_bound, r, lb, ub, nullptr);
+    double v[3], u[3], w[3];
+    matvec32<NA>(Jh, r_h, v);
+    matvec32<NA>(Jh, p_h, u);
+    double a_q = dot3(v, v);
+    a_q = a_q + diag_form<NA>(r_h, diag_h, r_h);
+    a_q = a_q * 0.5;
+    double b_q = dot2v<NA>(g_h, r_h);
+    b_q = b_q + dot3(u, v);
+    double c_q = fma_(0.5, dot3(u, u), dot2v<NA>(g_h, p_h));
+    b_q = b_q + diag_form<NA>(p_h, diag_h, r_h);
+    c_q = fma_(0.5, diag_form<NA>(p_h, diag_h, p_h), c_q);
+    const double ext_q = div_(-0.5 * b_q, a_q);
+    const double p_value = evaluate_quadratic<NA>(Jh, g_h, pt_h, diag_h);
+    const double to_tr_ag = div_(Delta, norm2v<NA>(ag_h));
+    const double to_bound_ag = step_size_to_bound_ilp<NA>(x, ag, lb, ub, nullptr);
+    matvec32<NA>(Jh, ag_h, w);
+    double a_ag = dot3(w, w);
+    a_ag = a_ag + diag_form<NA>(ag_h, diag_h, ag_h);
+    a_ag = a_ag * 0.5;
+    const double b_ag = dot2v<NA>(g_h, ag_h);
+    const double ext_ag = div_(-0.5 * b_ag, a_ag);
+    // ---- strides ---------------------------------------------------------------------------------------------------------
+    double to_tr;
+    {
+        double dd = sqrt_(fma_(b_tr, b_tr, -(a_tr * c_tr)));
+        double q = -(b_tr + copysign(dd, b_tr));
+        double t1 = div_(q, a_tr);
+        double t2 = div_(c_tr, q);
+        to_tr = (t1 < t2) ? t2 : t1;
+    }
+    double r_stride = fmin(to_bound_r, to_tr);
+    const double stride_l = div_((1 - theta) * p_stride, r_stride);
+    double r_stride_l, r_stride_u;
+    if (r_stride > 0) {
+        r_stride_l = stride_l;
+        r_stride_u = (r_stride == to_bound_r) ? theta * to_bound_r : to_tr;
+    } else {
+        r_stride_l = 0;
+        r_stride_u = -1;
+    }
+    double r_value;
+    if (r_stride_l <= r_stride_u) {
+        r_stride = minimize_quadratic_1d_ext(a_q, b_q, r_stride_l, r_stride_u, c_q, ext_q, r_value);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            r_h[i] = r_h[i] * r_stride;
+            r_h[i] = r_h[i] + p_h[i];
+            r[i] = r_h[i] * d[i];
+        }
+    } else {
+        r_value = INF;
+    }
+    double ag_stride = (to_bound_ag < to_tr_ag) ? theta * to_bound_ag : to_tr_ag;
+    double ag_value;
+    ag_stride = minimize_quadratic_1d_ext(a_ag, b_ag, 0.0, ag_stride, 0.0, ext_ag, ag_value);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ag_h[i] = ag_h[i] * ag_stride; ag[i] = ag[i] * ag_stride; }
+    const bool take_p = p_value < r_value && p_value < ag_value;
+    const bool take_r = !take_p && r_value < p_value && r_value < ag_value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        step[i] = take_p ? p[i] * theta : (take_r ? r[i] : ag[i]);
+        step_h[i] = take_p ? pt_h[i] : (take_r ? r_h[i] : ag_h[i]);
+    }
+    return -(take_p ? p_value : (take_r ? r_value : ag_value));
+}
+
+// ---------------------------------------------------------------------------
 // Forward kinematics of the active part of a stage chain
 // ---------------------------------------------------------------------------
 template <int STAGE>
@@ -1328,14 +1468,16 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //               io.t_store on (ChainIO); false = the whole chain from frame 0, everything stored.
 //   PIPED     : the hand-off goes through the LDS ring of io.pipe (stage pipeline, see PipeLane) instead of io.frames.
 //   SPLIT     : the lane and its neighbour lane ^ 1 carry the same chain and share the work of a pass ("Lane pairs").
-//   REUSE     : Jacobian, gradient and scaling are kept across passes and not re-derived after a rejected trial when no lane
-//               of the wavefront has moved (see jac_valid below).  Set by the 256-register build of the stage pipeline
-//               (small grids: serial walks, short recordings); the 168-register build would spill the 14 doubles.
+//   LAT       : the LATENCY build, set by the 256-register instantiations of the stage pipeline (small grids: serial walks,
+//               short recordings, where a wavefront carries one or a few chains): (i) Jacobian, gradient and scaling are
+//               kept across passes and not re-derived after a rejected trial when no lane of the wavefront has moved (see
+//               jac_valid below; the 168-register build would spill the 14 doubles); (ii) the reflective select_step and
+//               the post-trial block in their branch-free forms (select_step_reflective_ilp).  Same values.
 template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false,
-          bool SPLIT = false, bool REUSE = false>
+          bool SPLIT = false, bool LAT = false>
 SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 {
-    static_assert(!REUSE || (PIPED && !WANT_DIAG), "REUSE is a stage-pipeline option");
+    static_assert(!LAT || (PIPED && !WANT_DIAG), "LAT is a stage-pipeline option");
     constexpr bool PAIRED = SPLIT && StageTraits<STAGE>::NA == 2;
     const bool odd = PAIRED && pair_is_odd();
     static_assert(!(PIPED && FROM_ANGLES), "the stage pipeline starts at stage 1");
@@ -1382,7 +1524,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     // accepted.  On the stage pipeline a wavefront carries one or a few chains: when NO lane of it has moved since they
     // were formed (jac_valid on every lane) the finite differences, the gradient, the scaling and the two square roots are
     // skipped for the whole wavefront.  Stage 1 -- the critical stage of a serial walk -- rejects 32 % (RF) / 10 % (LF) of its
-    // trials on the shipped recording (serial walk of config 4: 122.8 -> 118.2 ms).  REUSE instantiations only; same values
+    // trials on the shipped recording (serial walk of config 4: 122.8 -> 118.2 ms).  LAT instantiations only; same values
     // either way.
     double J[3][2], g[2], v[2], dv[2], d[2];
     bool jac_valid = false;
@@ -1561,7 +1703,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
 #endif
             // ---- top of scipy's outer loop: J, g, scaling, gtol test --------------------
             bool derive = true;
-            if constexpr (REUSE) derive = wave_any(!jac_valid);   // wave-uniform: nobody moved since the last pass
+            if constexpr (LAT) derive = wave_any(!jac_valid);   // wave-uniform: nobody moved since the last pass
             if (derive) {
             if constexpr (PAIRED) fd_jacobian_pair<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, odd, J);
             else fd_jacobian<STAGE>(P, x, f, lb, ub, sa, ca, sb, cb, J);
@@ -1638,8 +1780,12 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 } else {
                     SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
                     SEQIK_BLK_COUNT(CNT_REFLECTIVE);
-                    predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
-                                                                     theta, step, step_h);
+                    if constexpr (LAT)
+                        predicted_reduction = select_step_reflective_ilp<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
+                                                                             theta, step, step_h);
+                    else
+                        predicted_reduction = select_step_reflective<NA>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub,
+                                                                         theta, step, step_h);
                     SEQIK_BLK_END_OF(BLK_REFLECTIVE);
                 }
                 SEQIK_BLK_END_OF(BLK_IN_BOUNDS);
@@ -1661,9 +1807,14 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 double cost_new = 0.5 * dot3(f_new, f_new);
                 double actual_reduction = cost - cost_new;
                 double ratio;
-                if (predicted_reduction > 0) ratio = div_(actual_reduction, predicted_reduction);
-                else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
-                else ratio = 0;
+                if constexpr (LAT) {  // the quotient formed unconditionally (overlaps with the norms), then selected
+                    const double q = div_(actual_reduction, predicted_reduction);
+                    ratio = (predicted_reduction > 0) ? q : ((predicted_reduction == 0 && actual_reduction == 0) ? 1.0 : 0.0);
+                } else {
+                    if (predicted_reduction > 0) ratio = div_(actual_reduction, predicted_reduction);
+                    else if (predicted_reduction == 0 && actual_reduction == 0) ratio = 1;
+                    else ratio = 0;
+                }
                 double Delta_new = Delta;
                 if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
                 else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
@@ -1679,7 +1830,10 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
                 if (ftol_ok && xtol_ok) status = 4;
                 else if (ftol_ok) status = 2;
                 else if (xtol_ok) status = 3;
-                if (status == STATUS_NONE) {
+                if constexpr (LAT) {
+                    const double alpha_scaled = alpha * div_(Delta, Delta_new);
+                    if (status == STATUS_NONE) { alpha = alpha_scaled; Delta = Delta_new; }
+                } else if (status == STATUS_NONE) {
                     alpha = alpha * div_(Delta, Delta_new);
                     Delta = Delta_new;
                 }

@@ -381,8 +381,8 @@ struct PipeShared {
 
 // pairs (wave-uniform): the wave carries every chain on an even number of adjacent lanes, lanes 2k / 2k + 1 split the
 // passes of the stages with two active joints between them
-// REUSE: run_stage's option of the same name (the 256-register builds set it)
-template <bool WANT_FK, bool CHUNK_SPEC_MODE, bool REUSE>
+// LAT: run_stage's option of the same name (the latency build; the 256-register instantiations set it)
+template <bool WANT_FK, bool CHUNK_SPEC_MODE, bool LAT>
 __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::ChainIO &io, PipeShared &sh, int stage_wave, int lane,
                                          bool pairs, int32_t *fault, int base = 0)
 {
@@ -397,13 +397,13 @@ __device__ __forceinline__ void pipe_run(const seqik::LegConst &lc, seqik::Chain
     pl.produced_out = stage_wave < 3 ? &sh.produced[stage_wave][lane] : nullptr;
     pl.consumed_out = stage_wave < 3 ? &sh.consumed[stage_wave][lane] : nullptr;
     switch (stage_wave + (pairs && stage_wave < 3 ? 4 : 0)) {  // wave-uniform
-    case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
-    case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
-    case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;
-    case 4: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
-    case 5: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
-    case 6: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, REUSE>(lc, io); break;
-    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true, false, REUSE>(lc, io); break;  // one joint
+    case 0: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, false, LAT>(lc, io); break;
+    case 1: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, LAT>(lc, io); break;
+    case 2: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, false, LAT>(lc, io); break;
+    case 4: seqik::run_stage<1, false, false, false, true, CHUNK_SPEC_MODE, true, true, LAT>(lc, io); break;
+    case 5: seqik::run_stage<2, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, LAT>(lc, io); break;
+    case 6: seqik::run_stage<3, WANT_FK, false, false, true, CHUNK_SPEC_MODE, true, true, LAT>(lc, io); break;
+    default: seqik::run_stage<4, WANT_FK, false, false, false, CHUNK_SPEC_MODE, true, false, LAT>(lc, io); break;  // one joint
     }
 }
 

@@ -197,3 +197,20 @@ extern "C" int harness_run_generic(const double *pose, int64_t n_frames, const S
     else seqik::run_generic<false>(gc, aff, io);
     return SEQIK_OK;
 }
+
+// The reflective select_step in its two forms (seqik_core.hpp): compact (lane-per-chain kernels) and written for latency
+// (run_stage<..., LAT>): out = {step[2], step_h[2], predicted_reduction}.  tests/test_core_bitexact_host.py feeds both the same
+// made-up inputs and compares the bits.
+extern "C" void harness_select_step(int32_t na, int32_t ilp, const double *x, const double *Jh6 /* [3][2] */, const double *diag_h,
+                                    const double *g_h, const double *p_in, const double *p_h_in, const double *d, double Delta,
+                                    const double *lb, const double *ub, double theta, double *out5)
+{
+    double Jh[3][2], p[2] = {p_in[0], p_in[1]}, p_h[2] = {p_h_in[0], p_h_in[1]}, step[2] = {0, 0}, step_h[2] = {0, 0};
+    for (int k = 0; k < 3; ++k) { Jh[k][0] = Jh6[2 * k]; Jh[k][1] = Jh6[2 * k + 1]; }
+    double pr;
+    if (na == 2) pr = ilp ? seqik::select_step_reflective_ilp<2>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h)
+                          : seqik::select_step_reflective<2>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+    else pr = ilp ? seqik::select_step_reflective_ilp<1>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h)
+                  : seqik::select_step_reflective<1>(x, Jh, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+    out5[0] = step[0]; out5[1] = step[1]; out5[2] = step_h[0]; out5[3] = step_h[1]; out5[4] = pr;
+}

@@ -145,3 +145,54 @@ def test_core_equals_oracle_with_open_and_one_sided_limits(oracle, host_harness)
         assert np.isfinite(o["angles"]).all() and np.isfinite(o["fk"]).all()
         _cmp(host_harness.run(pose, seg, b, seeds), o)
     assert opened > 100
+
+
+def test_latency_form_of_the_reflective_step_gives_the_same_bits(host_harness):
+    """run_stage<..., LAT> (the 256-register build of the stage pipeline) uses select_step_reflective_ilp: every quotient
+    formed unconditionally and selected, stride-independent parts first.  Same operations on the same operands wherever a
+    value is used -> the same bits as the compact form, on made-up inputs that hit every branch: steps that leave through
+    one bound / both, zero directions, points on a bound, tiny and huge radii, one and two unknowns."""
+    import ctypes
+    dp = ctypes.POINTER(ctypes.c_double)
+    fn = host_harness.lib.harness_select_step
+    fn.restype = None
+    fn.argtypes = [ctypes.c_int32, ctypes.c_int32, dp, dp, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp, ctypes.c_double, dp]
+    rng = np.random.default_rng(17)
+    for case in range(20000):
+        na = 2 if rng.random() < 0.8 else 1
+        lb = rng.uniform(-3.0, 0.0, 2)
+        ub = lb + rng.choice([0.05, 0.5, 3.0], 2) * rng.uniform(0.5, 1.0, 2)
+        if rng.random() < 0.2:
+            ub[rng.integers(0, 2)] = 0.0
+            lb = np.minimum(lb, ub - 0.1)
+        u = rng.random(2)
+        u[rng.random(2) < 0.15] = rng.choice([1e-17, 1.0 - 1e-16])          # next to a bound
+        x = lb + u * (ub - lb)
+        d = np.sqrt(np.maximum(np.minimum(x - lb, ub - x), 1e-300))
+        Jh = rng.standard_normal((3, 2)) * d
+        g_h = rng.standard_normal(2) * d
+        diag_h = np.abs(rng.standard_normal(2)) * rng.choice([0.0, 1.0], 2)
+        Delta = float(rng.choice([1e-6, 1e-2, 1.0, 50.0]) * rng.uniform(0.5, 2.0))
+        p_h = rng.standard_normal(2)
+        p_h *= Delta / np.linalg.norm(p_h[:na])
+        if rng.random() < 0.1:
+            p_h[rng.integers(0, 2)] = 0.0                                       # a zero direction
+        if na == 1:
+            p_h[1] = 0.0
+            Jh[:, 1] = 0.0
+            g_h[1] = 0.0
+            diag_h[1] = 0.0
+        p = d * p_h
+        # make sure the step leaves the bounds (the caller only calls select_step_reflective then)
+        if np.all((x + p >= lb) & (x + p <= ub)):
+            p_h *= 10.0 * (ub - lb).max() / max(np.abs(p).max(), 1e-300)
+            p = d * p_h
+        theta = max(0.995, 1.0 - float(rng.random()) * 1e-2)
+        outs = []
+        for ilp in (0, 1):
+            out = np.zeros(5)
+            args = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, Jh, diag_h, g_h, p, p_h, d)]
+            fn(na, ilp, *[a.ctypes.data_as(dp) for a in args], Delta, lb.ctypes.data_as(dp), ub.ctypes.data_as(dp), theta,
+               out.ctypes.data_as(dp))
+            outs.append(out)
+        assert np.array_equal(outs[0], outs[1], equal_nan=True), (case, outs)
