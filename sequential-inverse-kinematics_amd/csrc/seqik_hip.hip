@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -86,8 +87,8 @@ int fail(int code, const char *fmt, const char *detail = "")
 // are entered, and seqik_check_faults() is there for callers that synchronise themselves.
 // ---------------------------------------------------------------------------------------------------------------
 std::once_flag g_fault_once;
-int32_t *g_fault_host = nullptr;    // host address
-int32_t *g_fault_device = nullptr;  // the same word as the GPUs address it
+std::atomic<int32_t *> g_fault_host{nullptr};  // host address (read by threads that never launched: check_faults)
+int32_t *g_fault_device = nullptr;             // the same word as the GPUs address it (written once, under g_fault_once)
 
 int32_t *fault_word()
 {
@@ -97,8 +98,8 @@ int32_t *fault_word()
         memset(h, 0, 64);
         void *d = nullptr;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
-        g_fault_host = static_cast<int32_t *>(h);
         g_fault_device = static_cast<int32_t *>(d);
+        g_fault_host.store(static_cast<int32_t *>(h), std::memory_order_release);
     });
     return g_fault_device;  // null: no mapped host memory on this system -- the watchdog then only leaves its NaN
 }
@@ -106,8 +107,9 @@ int32_t *fault_word()
 // reads and clears the fault word; SEQIK_OK or SEQIK_ERR_HIP with the message set
 int check_faults(const char *where)
 {
-    if (!g_fault_host) return SEQIK_OK;
-    const int32_t v = __atomic_exchange_n(g_fault_host, 0, __ATOMIC_ACQ_REL);
+    int32_t *word = g_fault_host.load(std::memory_order_acquire);
+    if (!word) return SEQIK_OK;   // nothing has been launched yet
+    const int32_t v = __atomic_exchange_n(word, 0, __ATOMIC_ACQ_REL);
     if (v == 0) return SEQIK_OK;
     snprintf(g_err, sizeof(g_err),
              "%s: stage pipeline watchdog: a lane of stage %d waited more than %d passes for its neighbour wave; the "
