@@ -616,8 +616,8 @@ def test_config5_one_recording_streamed_over_ranks_equals_single_process_stream(
     params, affs, slabs, T, L, n_slabs = _config5_case()
     c, h, _ = hiplib.frame_chunk_plan(T)
     ref = [(np.zeros((1, L, 7, T)), np.zeros((1, L, T, 9, 3))) for _ in range(n_slabs)]
-    with SeqikStream(params, 1, T, affine=affs, layout=hiplib.planar_layout(T), want_fk=True, carry=True, frame_chunk=c,
-                     frame_halo=h) as st:
+    # the single-process stream as scripts/stream_config5.py opens it: automatic geometry, per-chain guard on the carried slabs
+    with SeqikStream(params, 1, T, affine=affs, layout=hiplib.planar_layout(T), want_fk=True, carry=True, frame_chunk=-1) as st:
         for k in range(n_slabs):
             st.submit(slabs[k], ref[k][0], ref[k][1])
         st.wait()
@@ -632,6 +632,27 @@ def test_config5_one_recording_streamed_over_ranks_equals_single_process_stream(
             assert np.array_equal(got["fk"][i], ref[k][1]), (r, k)
             seen += 1
     assert seen == n_slabs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_stream_config5_script_four_ranks_on_one_gpu_rehearsal():
+    """Round-3 review, item 4a, second half: `scripts/stream_config5.py --gpus N --one-recording` launches its own ranks (as
+    bench.py does), every rank streams its slabs of ONE recording from its own pinned buffers, rank 0 prints one JSON line.  Four
+    ranks share the box's GPU (the pool admits six GPU processes; process group on gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stream_config5.py"), "--gpus", "4", "--one-recording",
+                        "--frames", "96000", "--slab-frames", "8000", "--gpu-stats"], env=env, capture_output=True, text=True, timeout=800)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 4 and b["slabs"] == 12 and b["frames_total"] == 96000
+    assert [tuple(x["slabs"]) for x in sorted(b["ranks"], key=lambda x: x["rank"])] == [(0, 3), (3, 6), (6, 9), (9, 12)]
+    assert all(x["boundary_rounds"] == 0 and x["restreams"] == 0 for x in b["ranks"]) and b["value"] > 0
+    assert b["alignment_statistics_pass"]["frames_per_leg"] == 96000
 
 
 @pytest.mark.gpu
