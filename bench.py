@@ -683,8 +683,10 @@ def reference_configs(time_box_s=240.0):
         # the synthetic iid sequences of the headline (64 frames each): data generation costs ~6 s per distinct 1M-frame
         # slab on the host, so ONE distinct slab is generated and cycled (the kernels cannot tell); sized to the time left
         if left > 60:
+            # gpu_stats: also pass 1 of config 5 -- AlignPose's whole-recording order statistics (the constants of the fused
+            # affine) extracted and sorted on the GPU from the RAW slabs
             a5s = SimpleNamespace(frames=10_000_000, slab_frames=500_000, frames_per_seq=64, unique=1, slots=3, no_fk=False,
-                                  pageable=False, check=True, gpu_stats=False)
+                                  pageable=False, check=True, gpu_stats=True)
             c5["synthetic_sequences"] = sc5.synthetic_sequences(a5s)
         else:
             c5["synthetic_sequences"] = {"skipped": f"time box: {left:.0f} s left"}

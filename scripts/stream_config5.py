@@ -271,25 +271,6 @@ def synthetic_sequences(args):
     outs = [(alloc((S, L, 7, T)), alloc((S, L, T, 9, 3)) if want_fk else None) for _ in range(args.slots)]
     t_gen = time.perf_counter() - t_gen
 
-    # ---- pass 1: the alignment constants from the RAW slabs (AlignPose's quantile reductions) on the GPU --------
-    stats = None
-    if args.gpu_stats:
-        n_tot = n_slabs * S * T
-        qs = (0.45, 0.55)
-        ranks = [r for q in qs for r in (int(np.floor((n_tot - 1) * q)), min(int(np.floor((n_tot - 1) * q)) + 1, n_tot - 1))]
-        with _lib.AlignStats(L, n_tot) as ast:
-            ast.add(slabs[0].array, n_seq=S, n_frames=T, layout=layout)     # warm-up (allocations, first launch)
-            ast.reset()
-            t0 = time.perf_counter()
-            for k in range(n_slabs):
-                ast.add(slabs[k % args.unique].array, n_seq=S, n_frames=T, layout=layout)
-            order = ast.finish(ranks)
-            dt_stats = time.perf_counter() - t0
-        stats = {"seconds": dt_stats, "frames_per_leg": n_tot, "leg_frames_per_s": n_tot * L / dt_stats,
-                 "what": "7 series per leg extracted from the RAW slabs, radix-sorted, 4 order statistics each "
-                         "(np.quantile 0.45 / 0.55 neighbours) -> fixed_coxa, mean segment lengths, scale",
-                 "median_coxa_x_RF": float(order[0, 0, 0])}
-
     with SeqikStream(params, S, T, affine=affs, layout=layout, want_fk=want_fk, n_slots=args.slots) as st:
         for k in range(min(3, n_slabs)):  # warm-up: allocator pools, first-launch costs
             a, f = outs[k % args.slots]
@@ -318,6 +299,26 @@ def synthetic_sequences(args):
                      "median_abs_diff_vs_solve_on_prealigned": float(np.median(err)),
                      "leg_frames_gt_1e-4_vs_prealigned": int((err > 1e-4).sum()),
                      "leg_frames_checked": int(err.size)}
+
+    # ---- pass 1: the alignment constants from the RAW slabs (AlignPose's quantile reductions) on the GPU -- timed AFTER the
+    # stream here (its multi-GB device buffers, allocated and freed in front of the stream, cost the stream 15 % on this box)
+    stats = None
+    if args.gpu_stats:
+        n_tot = n_slabs * S * T
+        qs = (0.45, 0.55)
+        ranks = [r for q in qs for r in (int(np.floor((n_tot - 1) * q)), min(int(np.floor((n_tot - 1) * q)) + 1, n_tot - 1))]
+        with _lib.AlignStats(L, n_tot) as ast:
+            ast.add(slabs[0].array, n_seq=S, n_frames=T, layout=layout)     # warm-up (allocations, first launch)
+            ast.reset()
+            t0 = time.perf_counter()
+            for k in range(n_slabs):
+                ast.add(slabs[k % args.unique].array, n_seq=S, n_frames=T, layout=layout)
+            order = ast.finish(ranks)
+            dt_stats = time.perf_counter() - t0
+        stats = {"seconds": dt_stats, "frames_per_leg": n_tot, "leg_frames_per_s": n_tot * L / dt_stats,
+                 "what": "7 series per leg extracted from the RAW slabs, radix-sorted, 4 order statistics each "
+                         "(np.quantile 0.45 / 0.55 neighbours) -> fixed_coxa, mean segment lengths, scale",
+                 "median_coxa_x_RF": float(order[0, 0, 0])}
 
     units = n_slabs * S * L * T
     bytes_per = 120 + 56 + (216 if want_fk else 0)
