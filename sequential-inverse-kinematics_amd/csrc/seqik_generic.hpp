@@ -589,19 +589,47 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
         SEQIK_BLK_END_OF(BLK_NEW_SOLVE);
         if (WANT_DIAG || status == STATUS_NONE) {
             // ---- 2-point finite-difference Jacobian: column j perturbs joint j only ---------------
-            double J[3][GN], g[GN], v[GN], dv[GN];
-            if constexpr (GROUPED) {  // one column per lane of the group
+            double d[GN], diag_h[GN], g_h[GN], Jh[3][GN], ga[GN];
+            if constexpr (GROUPED) {
+                // One joint per lane of the group, and everything that is per-joint stays on that lane: the column of J, its
+                // gradient entry, the Coleman-Li scaling, d, diag_h, g_h and the column of J_h.  Only what the 3 x 3 algebra and
+                // the norms need from ALL joints is exchanged afterwards (J_h, d, diag_h, g_h, |g v|: 7 gathers instead of
+                // forming 172 instructions' worth of per-joint values seven times over on every lane).  Same operations on
+                // the same operands as the one-lane code below.
                 const double xj = pick7(x, jm);
                 double h = fd_step(xj, gc.lb[jm], gc.ub[jm]);
                 double x1 = xj + h;
                 double dx = x1 - xj;
-                double s1, c1, v1[3];
+                double s1, c1, v1[3], col[3];
                 sincos_cw(x1, s1, c1);
                 generic_claw_perturbed(gc, sn, cs, jm, s1, c1, v1);
                 double inv_dx = div_(1.0, dx);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) group8_gather(((v1[k] - target[k]) - f[k]) * inv_dx, J[k]);
+                for (int k = 0; k < 3; ++k) col[k] = ((v1[k] - target[k]) - f[k]) * inv_dx;
+                SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
+                const double gj = fma_(col[2], f[2], fma_(col[1], f[1], fma_(col[0], f[0], 0.0)));
+                double vj, dvj;
+                cl_scaling_gated(xj, gj, gc.lb[jm], gc.ub[jm], gc.gate_lb[jm], gc.gate_ub[jm], vj, dvj);
+                const double rj = sqrt_pos_(vj);
+                if (first_pass) {   // (wave-uniform: the group's lanes carry the same solve)
+                    double tq[GN];
+                    group8_gather(div_(xj, rj), tq);
+                    double acc = gc.x_pre_sq;
+                    for (int j = 0; j < GN; ++j) acc = fma_(tq[j], tq[j], acc);
+                    acc = fma_(gc.x_suf, gc.x_suf, acc);
+                    Delta = sqrt_(acc);
+                    if (Delta == 0) Delta = 1.0;
+                    first_pass = false;
+                }
+                const double dj = rj * 1.0;
+                group8_gather(fabs(gj * vj), ga);
+                group8_gather(dj, d);
+                group8_gather(gj * dvj * 1.0, diag_h);
+                group8_gather(dj * gj, g_h);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) group8_gather(col[k] * dj, Jh[k]);
             } else {
+                double J[3][GN], g[GN], v[GN], dv[GN];
                 // the columns share the part of the chain behind the perturbed link (suf, at the base angles)
                 double suf[GN][3], vb[3];
                 generic_claw(gc, sn, cs, vb, suf);
@@ -609,39 +637,36 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
                 fd_column<2>(gc, x, sn, cs, suf, target, f, J); fd_column<3>(gc, x, sn, cs, suf, target, f, J);
                 fd_column<4>(gc, x, sn, cs, suf, target, f, J); fd_column<5>(gc, x, sn, cs, suf, target, f, J);
                 fd_column<6>(gc, x, sn, cs, suf, target, f, J);
-            }
-            SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
-            for (int j = 0; j < GN; ++j) {
-                g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
-                cl_scaling_gated(x[j], g[j], gc.lb[j], gc.ub[j], gc.gate_lb[j], gc.gate_ub[j], v[j], dv[j]);
-            }
-            if (first_pass) {
-                double acc = gc.x_pre_sq;
-                for (int j = 0; j < GN; ++j) { double tj = div_(x[j], sqrt_pos_(v[j])); acc = fma_(tj, tj, acc); }
-                acc = fma_(gc.x_suf, gc.x_suf, acc);
-                Delta = sqrt_(acc);
-                if (Delta == 0) Delta = 1.0;
-                first_pass = false;
+                SEQIK_BLK_END_OF(BLK_FD_JACOBIAN);
+                for (int j = 0; j < GN; ++j) {
+                    g[j] = fma_(J[2][j], f[2], fma_(J[1][j], f[1], fma_(J[0][j], f[0], 0.0)));
+                    cl_scaling_gated(x[j], g[j], gc.lb[j], gc.ub[j], gc.gate_lb[j], gc.gate_ub[j], v[j], dv[j]);
+                }
+                if (first_pass) {
+                    double acc = gc.x_pre_sq;
+                    for (int j = 0; j < GN; ++j) { double tj = div_(x[j], sqrt_pos_(v[j])); acc = fma_(tj, tj, acc); }
+                    acc = fma_(gc.x_suf, gc.x_suf, acc);
+                    Delta = sqrt_(acc);
+                    if (Delta == 0) Delta = 1.0;
+                    first_pass = false;
+                }
+                for (int j = 0; j < GN; ++j) {
+                    ga[j] = fabs(g[j] * v[j]);
+                    d[j] = sqrt_pos_(v[j]) * 1.0;
+                    diag_h[j] = g[j] * dv[j] * 1.0;
+                    g_h[j] = d[j] * g[j];
+                }
+                for (int k = 0; k < 3; ++k)
+                    for (int j = 0; j < GN; ++j) Jh[k][j] = J[k][j] * d[j];
             }
             // ||g * v||_inf: the maximum is exact in any order (the products are >= +0 after fabs), so a tree of fmax gives
             // the oracle's running `if (a > g_norm) g_norm = a` value with a third of the dependent steps
-            double ga[GN];
-            for (int j = 0; j < GN; ++j) ga[j] = fabs(g[j] * v[j]);
             double g_norm = fmax(fmax(fmax(ga[0], ga[1]), fmax(ga[2], ga[3])), fmax(fmax(ga[4], ga[5]), fmax(ga[6], 0.0)));
             if (g_norm < gtol) status = 1;
 
             if (status != STATUS_NONE || nfev == gc.max_nfev) {
                 finished = true;
             } else {
-                double d[GN], diag_h[GN], g_h[GN], Jh[3][GN];
-                if constexpr (GROUPED) group8_gather(sqrt_pos_(pick7(v, jm)) * 1.0, d);
-                for (int j = 0; j < GN; ++j) {
-                    if constexpr (!GROUPED) d[j] = sqrt_pos_(v[j]) * 1.0;
-                    diag_h[j] = g[j] * dv[j] * 1.0;
-                    g_h[j] = d[j] * g[j];
-                }
-                for (int k = 0; k < 3; ++k)
-                    for (int j = 0; j < GN; ++j) Jh[k][j] = J[k][j] * d[j];
                 double theta = fmax(0.995, 1 - g_norm);
 
                 double p_h[GN], p[GN], step[GN], step_h[GN];
