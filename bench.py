@@ -606,6 +606,23 @@ def reference_configs(time_box_s=240.0):
                                data.TEMPLATE_NMF_LOCOMOTION,
                                "config 2: all 6 legs, df3d locomotion recording, 1000 frames (fixture = the reference's source run "
                                "over real scipy, oracle/gen_golden.py)", False)
+    # ---- the reference's semantics at the target rate: MANY recordings per call (a lab's flies / trials), every chain still
+    # walked frame by frame (the default), each recording's result the bits it gets alone (tests/test_frame_chunks.py)
+    from seqikpy_amd.batch import run_ik_and_fk_many
+    recs = [{f"{l}_leg": np.ascontiguousarray(zd[f"{l}_pose"]) for l in legs6} for _ in range(64)]
+    chain6 = KinematicChainSeq(bounds_dof=data.BOUNDS_LOCOMOTION, legs_list=legs6,
+                               body_size=utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs6))
+    holder = {}
+
+    def many():
+        holder["res"] = run_ik_and_fk_many(recs, chain6, data.INITIAL_ANGLES_LOCOMOTION)
+    ms_many = best_ms(many, reps=3)
+    a_many = np.stack([np.stack([holder["res"][-1][0][f"Angle_{l}_{d}"] for d in DOFS], 1) for l in legs6])
+    ref6 = np.stack([zd[f"{l}_angles"] for l in legs6])
+    out["2"]["default_64_recordings_one_call"] = {
+        "what": "run_ik_and_fk_many: 64 recordings x 6 legs x 1000 frames in one call, DEFAULT semantics (serial walk per chain, "
+                "bit-identical to the one-recording call)", "ms": ms_many, "leg_frames_per_s": 64 * 6 * 1000 / ms_many * 1e3,
+        "max_abs_dtheta_vs_fixture_last_recording": float(np.abs(a_many - ref6).max())}
     # ---- config 4: legs + head / antenna angles of the shipped 6000-frame recording in ONE submission ----------------
     e4, aligned4, chain4 = leg_entry(za, ["RF", "LF"], 6000, data.BOUNDS, data.INITIAL_ANGLES, data.NMF_TEMPLATE,
                                      "config 4: anipose_220525_aJO_Fly001_001 (6000 frames; stands in for the absent "
@@ -1109,6 +1126,15 @@ def main():
                 del batch, d_ang
                 torch.cuda.empty_cache()
                 out["configs"] = reference_configs()
+                # config 3 is the headline of this line: the same figures under its key, so that all five configs read alike
+                out["configs"]["3"].update({
+                    "leg_frames": units_per_step, "ms_per_step_three_batches_in_flight": ms_per_step, "leg_frames_per_s": out["value"],
+                    "ms_one_job_at_a_time": out["single_job"]["ms_per_step"], "leg_frames_per_s_one_job_at_a_time": out["value_single_job"],
+                    "smooth_variant_leg_frames_per_s": out["variants"].get("smooth", {}).get("value"),
+                    "one_recording_1M_frames_leg_frames_per_s": out["single_recording"]["value"],
+                    "parity": "every buffer of the timed region == one launch made alone, bit for bit (`verified`); that launch == the C "
+                              "restatement bit for bit on sampled chains (tests/test_gpu_parity.py::test_full_size_synthetic_properties); "
+                              "against the reference itself see `parity_note` in `config`"})
             _lib.check_faults()   # the device entry points do not synchronise: a kernel fault of any launch above raises here
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
