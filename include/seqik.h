@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 4
+#define SEQIK_ABI_VERSION 5
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -296,6 +296,28 @@ int seqik_head_angles(const double *r_head, const double *l_head, int64_t n_fram
 int seqik_head_angles_device(const double *d_r_head, const double *d_l_head, int64_t n_frames, const double *d_neck,
                              int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch,
                              int32_t compute_ant, double *d_angles, void *hip_stream);
+
+/* ABI 5.  The same with the two things the reference's per-quantity methods allow beyond compute_head_angles:
+ *   n_points   key points per head record: r_head / l_head are [n_frames][n_points][3] and only point 0 (and, for the
+ *              antennae, point 1) is read.  1 = one head key point per side, e.g. a bristle, with compute_ant = 0
+ *              (seqikpy/head_inverse_kinematics.py:26); compute_ant != 0 with n_points < 2 is SEQIK_ERR_BAD_ARG.
+ *   head_roll  nullable [n_frames]: the antenna vectors are derotated by THIS head roll instead of the frame's own --
+ *              compute_antenna_pitch(side, head_roll) / compute_antenna_yaw(side, head_roll), :242-307, take it as an
+ *              argument.  Rows 0-2 are the frame's own head angles either way.
+ * seqik_head_angles(...) == seqik_head_angles_ex(..., n_points = 2, head_roll = NULL). */
+int seqik_head_angles_ex(const double *r_head, const double *l_head, int64_t n_frames, int32_t n_points, const double *neck,
+                         int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch, int32_t compute_ant,
+                         const double *head_roll, double *angles, const SeqikOptions *opt);
+int seqik_head_angles_ex_device(const double *d_r_head, const double *d_l_head, int64_t n_frames, int32_t n_points,
+                                const double *d_neck, int64_t neck_stride, double rest_head_pitch,
+                                double rest_antenna_pitch, int32_t compute_ant, const double *d_head_roll,
+                                double *d_angles, void *hip_stream);
+
+/* ABI 5.  HeadInverseKinematics.angle_between_segments (seqikpy/head_inverse_kinematics.py:163-182) for general vectors:
+ * out[i] = acos(v1_i . v2_i / (|v1_i| |v2_i|)), negated unless det([axis, v1_i, v2_i]) > 0.  v1 / v2 are [n][3] (stride 3)
+ * or one vector [3] used for every row (stride 0); axis [3]; host buffers. */
+int seqik_signed_angles(const double *v1, int64_t v1_stride, const double *v2, int64_t v2_stride, const double *axis,
+                        int64_t n, double *out, const SeqikOptions *opt);
 
 /*
  * Peer gather ("RCCL over xGMI only for the final joint-angle gather").  One process per GPU; the rank

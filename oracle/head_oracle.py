@@ -27,8 +27,9 @@ def derotate(roll, v):
     return np.stack([v[:, 0], c * v[:, 1] + s * v[:, 2], -s * v[:, 1] + c * v[:, 2]], axis=1)
 
 
-def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch):
-    """(N, 2, 3), (N, 2, 3), neck (1 or N, 3) -> (7, N) in the reference's dict order."""
+def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, head_roll=None, compute_ant=True):
+    """(N, K, 3), (N, K, 3), neck (1 or N, 3) -> (7, N) in the reference's dict order (3 rows without the antennae).
+    head_roll: the roll compute_antenna_pitch / _yaw are handed (:242, :278); None = the frames' own."""
     rb, lb = r_head[:, 0], l_head[:, 0]
     hor = lb - rb
     mid = (rb + lb) * 0.5 - neck
@@ -39,6 +40,10 @@ def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch):
     v = hor.copy(); v[:, 2] = 0
     yaw = signed_angle(Y, v, Z)
     out = [roll, pitch, yaw]
+    if not compute_ant:
+        return np.stack(out)
+    if head_roll is not None:
+        roll = np.broadcast_to(np.asarray(head_roll, dtype=np.float64).reshape(-1), roll.shape)
     hor_d = derotate(roll, hor)
     for side, head in (("L", l_head), ("R", r_head)):
         ant = derotate(roll, head[:, 1] - head[:, 0])

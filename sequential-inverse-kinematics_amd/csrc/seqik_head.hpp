@@ -120,9 +120,28 @@ SEQIK_HD void derotate_x(double m11, double two_xw, const double *v, double *out
     out[2] = hfma(two_xw, v[1], m11 * v[2]);
 }
 
+// angle_between_segments (:163-178) for two general 3-vectors and a general axis: acos of the normalised dot product,
+// negative unless det([axis, v1, v2]) = axis . (v1 x v2) > 0.
+SEQIK_HD double signed_angle3(const double *v1, const double *v2, const double *axis)
+{
+    const double n1 = hfma(v1[0], v1[0], hfma(v1[1], v1[1], v1[2] * v1[2]));
+    const double n2 = hfma(v2[0], v2[0], hfma(v2[1], v2[1], v2[2] * v2[2]));
+    double d = hfma(v1[0], v2[0], hfma(v1[1], v2[1], v1[2] * v2[2])) * inv_sqrt(n1 * n2);
+    d = fmin(1.0, fmax(-1.0, d));
+    const double cx = hfma(v1[1], v2[2], -(v1[2] * v2[1])), cy = hfma(v1[2], v2[0], -(v1[0] * v2[2])),
+                 cz = hfma(v1[0], v2[1], -(v1[1] * v2[0]));
+    const double det = hfma(axis[0], cx, hfma(axis[1], cy, axis[2] * cz));
+    const double ang = acos_unit(d);
+    return (det > 0) ? ang : -ang;
+}
+
 struct HeadArgs {
-    const double *r_head;   // [n][2][3]: antenna base, antenna tip (right)
-    const double *l_head;   // [n][2][3] (left)
+    const double *r_head;   // [n][n_points][3]: antenna base, antenna tip (right); a frame's record is `rec` doubles
+    const double *l_head;   // [n][n_points][3] (left)
+    int64_t rec;            // 3 * n_points: 6 for (base, tip) records; 3 when only one head key point per side was
+                            // tracked (no antenna angles then, head_inverse_kinematics.py:26)
+    const double *roll_in;  // nullable [n]: the antenna vectors are derotated by THIS head roll instead of the frame's own
+                            // (compute_antenna_pitch / compute_antenna_yaw take `head_roll` as an argument, :242, :278)
     const double *neck;     // [3], or [n][3] when neck_stride == 3
     int64_t neck_stride;    // 0 or 3
     double rest_head_pitch, rest_antenna_pitch;
@@ -133,8 +152,10 @@ struct HeadArgs {
 
 // The seven angles of one frame from its key points: rb / lb = antenna base + tip (right / left, 6 doubles each),
 // neck (3).  out: head roll, pitch, yaw, antenna yaw L, pitch L, yaw R, pitch R (the last four only with compute_ant).
+// roll_given: nullable, the caller's head roll for the derotation (reference: Rotation.from_euler("x", -head_roll)).
 SEQIK_HD void head_angles_compute(const double *rb, const double *lb, const double *neck, double rest_head_pitch,
-                                  double rest_antenna_pitch, bool compute_ant, double *out)
+                                  double rest_antenna_pitch, bool compute_ant, double *out,
+                                  const double *roll_given = nullptr)
 {
     const double PI = 3.141592653589793;
     double hor[3] = {lb[0] - rb[0], lb[1] - rb[1], lb[2] - rb[2]};            // R base -> L base
@@ -149,6 +170,7 @@ SEQIK_HD void head_angles_compute(const double *rb, const double *lb, const doub
     // head yaw (:212-226): Y axis -> horizontal vector projected on the frontal (x, y) plane, about Z: det([Z, Y, v]) = -v_x
     out[2] = axis_angle(hor[1], -hor[0]);
     if (!compute_ant) return;
+    if (roll_given) { sin_roll = sin(*roll_given); cos_roll = cos(*roll_given); }
     const double m11 = cos_roll, two_xw = -sin_roll;
     double hor_d[3];
     derotate_x(m11, two_xw, hor, hor_d);
@@ -174,8 +196,8 @@ SEQIK_HD void head_angles_compute(const double *rb, const double *lb, const doub
 SEQIK_HD void head_angles_frame(const HeadArgs &a, int64_t t)
 {
     double out[7];
-    head_angles_compute(a.r_head + t * 6, a.l_head + t * 6, a.neck + t * a.neck_stride, a.rest_head_pitch,
-                        a.rest_antenna_pitch, a.compute_ant != 0, out);
+    head_angles_compute(a.r_head + t * a.rec, a.l_head + t * a.rec, a.neck + t * a.neck_stride, a.rest_head_pitch,
+                        a.rest_antenna_pitch, a.compute_ant != 0, out, a.roll_in ? a.roll_in + t : nullptr);
     const int n_out = a.compute_ant ? 7 : 3;
     for (int j = 0; j < n_out; ++j) a.angles[j * a.n_frames + t] = out[j];
 }

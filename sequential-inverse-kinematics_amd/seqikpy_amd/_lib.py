@@ -46,7 +46,7 @@ class SeqikOptions(ctypes.Structure):
                 ("chunk_resume", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 N_CHUNK_STATS = 16
 CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
                       "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check",
@@ -285,6 +285,16 @@ def load():
         L.seqik_head_angles_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                ctypes.c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.c_void_p]
+        L.seqik_head_angles_ex.restype = ctypes.c_int
+        L.seqik_head_angles_ex.argtypes = [_dp, _dp, ctypes.c_int64, ctypes.c_int32, _dp, ctypes.c_int64, ctypes.c_double,
+                                           ctypes.c_double, ctypes.c_int32, _dp, _dp, ctypes.POINTER(SeqikOptions)]
+        L.seqik_head_angles_ex_device.restype = ctypes.c_int
+        L.seqik_head_angles_ex_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.seqik_signed_angles.restype = ctypes.c_int
+        L.seqik_signed_angles.argtypes = [_dp, ctypes.c_int64, _dp, ctypes.c_int64, _dp, ctypes.c_int64, _dp,
+                                          ctypes.POINTER(SeqikOptions)]
         L.seqik_host_alloc.restype = ctypes.c_void_p
         L.seqik_host_alloc.argtypes = [ctypes.c_size_t]
         L.seqik_host_free.restype = None
@@ -327,6 +337,7 @@ EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error
                     "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
                     "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",
+                    "seqik_head_angles_ex", "seqik_head_angles_ex_device", "seqik_signed_angles",
                     "seqik_validate_legs_generic", "seqik_solve_generic", "seqik_solve_generic_device",
                     "seqik_host_alloc", "seqik_host_free", "seqik_host_register", "seqik_host_unregister",
                     "seqik_stream_open", "seqik_stream_submit", "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry",
@@ -504,24 +515,56 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_si
     return dict(angles=angles, fk=fk, status=status, nfev=nfev)
 
 
-def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=-1):
-    """``seqik_head_angles`` on host arrays: (N, 2, 3), (N, 2, 3), neck (3,) or (N, 3) -> (7 or 3, N)."""
+def head_angles(r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, device=-1, head_roll=None):
+    """``seqik_head_angles_ex`` on host arrays: (N, K, 3), (N, K, 3), neck (3,) or (N, 3) -> (7 or 3, N).
+
+    K = key points per side: point 0 gives the head angles, point 1 (the antenna tip) the antenna angles; K = 1 is
+    allowed without them.  ``head_roll`` (N,): derotate the antenna vectors by this roll instead of the frame's own."""
     r_head = np.ascontiguousarray(r_head, dtype=np.float64)
     l_head = np.ascontiguousarray(l_head, dtype=np.float64)
     n = r_head.shape[0]
-    if r_head.shape != (n, 2, 3) or l_head.shape != (n, 2, 3):
-        raise ValueError("R_head / L_head must have shape (N, 2, 3)")
+    if r_head.ndim != 3 or r_head.shape[2] != 3 or r_head.shape[1] < 1 or l_head.shape != r_head.shape:
+        raise ValueError("R_head / L_head must have the same shape (N, key points, 3)")
+    k = r_head.shape[1]
+    if compute_ant and k < 2:
+        # what the reference's get_ant_vector runs into (head_inverse_kinematics.py:159-161)
+        raise IndexError(f"index 1 is out of bounds for axis 1 with size {k}: the antenna angles need the antenna base "
+                         "and tip; call compute_head_angles(compute_ant_angles=False)")
     neck = np.ascontiguousarray(neck, dtype=np.float64).reshape(-1, 3)
     if neck.shape[0] not in (1, n):
         raise ValueError("Neck must hold one point or one point per frame")
     stride = 3 if (neck.shape[0] == n and n > 1) else 0
+    roll_p = None
+    if head_roll is not None and compute_ant:
+        head_roll = np.ascontiguousarray(np.broadcast_to(np.asarray(head_roll, dtype=np.float64).reshape(-1), (n,)))
+        roll_p = head_roll.ctypes.data_as(_dp)
     out = np.zeros((7 if compute_ant else 3, n))
     opt = SeqikOptions()
     opt.device = device
-    rc = load().seqik_head_angles(r_head.ctypes.data_as(_dp), l_head.ctypes.data_as(_dp), n,
-                                  neck.ctypes.data_as(_dp), stride, float(rest_head_pitch),
-                                  float(rest_antenna_pitch), 1 if compute_ant else 0, out.ctypes.data_as(_dp),
-                                  ctypes.byref(opt))
+    rc = load().seqik_head_angles_ex(r_head.ctypes.data_as(_dp), l_head.ctypes.data_as(_dp), n, k,
+                                     neck.ctypes.data_as(_dp), stride, float(rest_head_pitch),
+                                     float(rest_antenna_pitch), 1 if compute_ant else 0, roll_p,
+                                     out.ctypes.data_as(_dp), ctypes.byref(opt))
+    if rc != SEQIK_OK:
+        _raise(rc)
+    return out
+
+
+def signed_angles(v1, v2, rot_axis, device=-1):
+    """``seqik_signed_angles``: the reference's ``angle_between_segments`` for (N, 3) arrays (either side may be one
+    vector, used for every row) -> (N,)."""
+    v1 = np.ascontiguousarray(np.asarray(v1, dtype=np.float64).reshape(-1, 3))
+    v2 = np.ascontiguousarray(np.asarray(v2, dtype=np.float64).reshape(-1, 3))
+    axis = np.ascontiguousarray(np.asarray(rot_axis, dtype=np.float64).reshape(3))
+    n = max(v1.shape[0], v2.shape[0])
+    if v1.shape[0] not in (1, n) or v2.shape[0] not in (1, n):
+        raise ValueError(f"operands could not be broadcast together with shapes {v1.shape} {v2.shape}")
+    out = np.zeros(n)
+    opt = SeqikOptions()
+    opt.device = device
+    rc = load().seqik_signed_angles(v1.ctypes.data_as(_dp), 3 if v1.shape[0] == n and n > 1 else 0, v2.ctypes.data_as(_dp),
+                                    3 if v2.shape[0] == n and n > 1 else 0, axis.ctypes.data_as(_dp), n,
+                                    out.ctypes.data_as(_dp), ctypes.byref(opt))
     if rc != SEQIK_OK:
         _raise(rc)
     return out

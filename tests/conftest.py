@@ -79,7 +79,8 @@ class HostHarness:
         self.lib.harness_run_generic.restype = ctypes.c_int
         self.lib.harness_run_generic.argtypes = [dp, ctypes.c_int64, ctypes.POINTER(LegParamsC), dp, dp, ip, ip, dp]
         self.lib.harness_head_angles.argtypes = [dp, dp, ctypes.c_int64, dp, ctypes.c_int64, ctypes.c_double,
-                                                 ctypes.c_double, ctypes.c_int32, dp]
+                                                 ctypes.c_double, ctypes.c_int32, dp, ctypes.c_int32, dp]
+        self.lib.harness_signed_angles.argtypes = [dp, ctypes.c_int64, dp, ctypes.c_int64, dp, ctypes.c_int64, dp]
 
     def run(self, pose, seg, bounds, seeds, first=1, last=4, prior=None, diag=True, want_fk=True, affine=None, init=None):
         dp = ctypes.POINTER(ctypes.c_double)
@@ -166,16 +167,31 @@ class HostHarness:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
 
-    def head_angles(self, r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True):
+    def head_angles(self, r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, head_roll=None):
         dp = ctypes.POINTER(ctypes.c_double)
         r_head = np.ascontiguousarray(r_head, dtype=np.float64)
         l_head = np.ascontiguousarray(l_head, dtype=np.float64)
         neck = np.ascontiguousarray(neck, dtype=np.float64).reshape(-1, 3)
         n = r_head.shape[0]
+        assert r_head.shape[1] >= (2 if compute_ant else 1)
+        if head_roll is not None:
+            head_roll = np.ascontiguousarray(np.broadcast_to(np.asarray(head_roll, dtype=np.float64).reshape(-1), (n,)))
         out = np.zeros((7, n))
         self.lib.harness_head_angles(r_head.ctypes.data_as(dp), l_head.ctypes.data_as(dp), n, neck.ctypes.data_as(dp),
                                      3 if neck.shape[0] == n and n > 1 else 0, rest_head_pitch, rest_antenna_pitch,
-                                     1 if compute_ant else 0, out.ctypes.data_as(dp))
+                                     1 if compute_ant else 0, out.ctypes.data_as(dp), r_head.shape[1],
+                                     head_roll.ctypes.data_as(dp) if head_roll is not None else None)
+        return out
+
+    def signed_angles(self, v1, v2, axis):
+        dp = ctypes.POINTER(ctypes.c_double)
+        v1 = np.ascontiguousarray(np.asarray(v1, dtype=np.float64).reshape(-1, 3))
+        v2 = np.ascontiguousarray(np.asarray(v2, dtype=np.float64).reshape(-1, 3))
+        axis = np.ascontiguousarray(np.asarray(axis, dtype=np.float64).reshape(3))
+        n = max(len(v1), len(v2))
+        out = np.zeros(n)
+        self.lib.harness_signed_angles(v1.ctypes.data_as(dp), 3 if len(v1) == n and n > 1 else 0, v2.ctypes.data_as(dp),
+                                       3 if len(v2) == n and n > 1 else 0, axis.ctypes.data_as(dp), n, out.ctypes.data_as(dp))
         return out
 
     def sincos(self, x):

@@ -170,13 +170,20 @@ extern "C" void harness_sincos(double x, double *s, double *c) { seqik::sincos_c
 // head / antenna angles: the kernel's per-frame device function, run on the host
 extern "C" void harness_head_angles(const double *r_head, const double *l_head, int64_t n, const double *neck,
                                     int64_t neck_stride, double rest_head_pitch, double rest_antenna_pitch,
-                                    int32_t compute_ant, double *angles)
+                                    int32_t compute_ant, double *angles, int32_t n_points, const double *head_roll)
 {
     seqik::HeadArgs a;
     a.r_head = r_head; a.l_head = l_head; a.neck = neck; a.neck_stride = neck_stride;
+    a.rec = 3 * (int64_t)n_points; a.roll_in = compute_ant ? head_roll : nullptr;
     a.rest_head_pitch = rest_head_pitch; a.rest_antenna_pitch = rest_antenna_pitch;
     a.angles = angles; a.n_frames = n; a.compute_ant = compute_ant;
     for (int64_t t = 0; t < n; ++t) seqik::head_angles_frame(a, t);
+}
+
+extern "C" void harness_signed_angles(const double *v1, int64_t s1, const double *v2, int64_t s2, const double *axis,
+                                      int64_t n, double *out)
+{
+    for (int64_t t = 0; t < n; ++t) out[t] = seqik::signed_angle3(v1 + t * s1, v2 + t * s2, axis);
 }
 
 // generic (single-chain) IK: the kernel's per-chain device function, run on the host

@@ -24,6 +24,7 @@ def test_header_declares_expected_entry_points():
                                            "seqik_validate_legs", "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export",
                                            "seqik_peer_open", "seqik_peer_close", "seqik_peer_copy", "seqik_solve_seq", "seqik_solve_seq_device",
                                            "seqik_head_angles", "seqik_head_angles_device",
+                                           "seqik_head_angles_ex", "seqik_head_angles_ex_device", "seqik_signed_angles",
                                            "seqik_validate_legs_generic", "seqik_solve_generic",
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
@@ -39,7 +40,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 4 == hiplib.ABI_VERSION
+    assert lib.seqik_abi_version() == 5 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):

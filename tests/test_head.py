@@ -33,6 +33,42 @@ def test_head_device_code_on_host_vs_golden(z, host_harness):
     assert np.abs(out.T - z["shipped"]).max() < TOL
 
 
+def test_head_device_code_on_host_given_roll_and_single_point_records(z, host_harness):
+    """What the reference's per-quantity methods allow beyond compute_head_angles (head_inverse_kinematics.py:26, :242, :278):
+    a head roll handed in by the caller, and head records with one key point per side (no antenna angles)."""
+    args = (z["R_head"], z["L_head"], z["Neck"][:, 0], float(z["rest_head_pitch"][0]), float(z["rest_antenna_pitch"][0]))
+    own = host_harness.head_angles(*args)
+    # the frames' own roll handed back in: sin / cos of the angle instead of the normalised components, same to ~1e-12 after the acos
+    again = host_harness.head_angles(*args, head_roll=own[0])
+    assert np.array_equal(again[:3], own[:3]) and np.abs(again - own).max() < 1e-10
+    rng = np.random.default_rng(3)
+    for roll in (0.3, -1.1, rng.uniform(-np.pi, np.pi, 6000)):
+        got = host_harness.head_angles(*args, head_roll=roll)
+        want = head_oracle.head_angles(*args, head_roll=roll)
+        assert np.array_equal(got[:3], own[:3])
+        assert np.abs(got - want).max() < TOL
+        assert np.abs(got[3:] - own[3:]).max() > 1e-3   # ... and it is a different derotation
+    one = host_harness.head_angles(z["R_head"][:, :1], z["L_head"][:, :1], *args[2:], compute_ant=False)
+    assert np.array_equal(one[:3], own[:3]) and not one[3:].any()
+    three = host_harness.head_angles(np.concatenate([z["R_head"], z["R_head"][:, :1] + 7.0], 1),
+                                     np.concatenate([z["L_head"], z["L_head"][:, :1] - 7.0], 1), *args[2:])
+    assert np.array_equal(three, own)
+
+
+def test_signed_angle_device_code_on_host(host_harness):
+    """angle_between_segments (:163-182) for general vectors and axis."""
+    rng = np.random.default_rng(4)
+    v1, v2 = rng.normal(size=(5000, 3)), rng.normal(size=(5000, 3))
+    for axis in (np.eye(3)[0], np.eye(3)[1], np.eye(3)[2], rng.normal(size=3)):
+        want = head_oracle.signed_angle(v1, v2, axis)
+        assert np.abs(host_harness.signed_angles(v1, v2, axis) - want).max() < 1e-7
+    # one vector against many (the reference tiles it with get_plane), and the sign convention at det == 0
+    want = head_oracle.signed_angle(np.eye(3)[1], v2, np.eye(3)[0])
+    assert np.abs(host_harness.signed_angles(np.eye(3)[1], v2, np.eye(3)[0]) - want).max() < 1e-7
+    assert host_harness.signed_angles([1.0, 0, 0], [0.0, 1, 0], [0.0, 0, 1])[0] == pytest.approx(np.pi / 2, abs=1e-15)
+    assert host_harness.signed_angles([1.0, 0, 0], [0.0, 1, 0], [1.0, 0, 0])[0] == pytest.approx(-np.pi / 2, abs=1e-15)
+
+
 def test_rest_angles_from_template(z):
     from seqikpy_amd.data import NMF_TEMPLATE
     from seqikpy_amd.head_inverse_kinematics import HeadInverseKinematics
@@ -65,6 +101,68 @@ def test_head_angles_on_gpu(z, hiplib, tmp_path):
                                 log_level="ERROR")
     assert np.array_equal(hk2.compute_head_angles()["Angle_head_pitch"], ang["Angle_head_pitch"])
     assert hiplib.head_angles(z["R_head"][:0], z["L_head"][:0], z["Neck"][:, 0], 0.1, 0.2).shape == (7, 0)
+
+
+@pytest.mark.gpu
+def test_head_per_quantity_methods_on_gpu(z, hiplib):
+    """Every public method of the reference's HeadInverseKinematics (:144-339): the three head angles one by one, the
+    antenna angles with the head roll as an ARGUMENT, angle_between_segments, the array helpers; records with a single
+    key point per side."""
+    from scipy.spatial.transform import Rotation
+    from seqikpy_amd.data import NMF_TEMPLATE
+    from seqikpy_amd.head_inverse_kinematics import ANGLE_NAMES, Axes, HeadInverseKinematics
+    pos = {"R_head": z["R_head"], "L_head": z["L_head"], "Neck": z["Neck"]}
+    hk = HeadInverseKinematics(pos, NMF_TEMPLATE, log_level="ERROR")
+    both = hk.compute_head_angles()
+    col = {n: z["shipped"][:, i] for i, n in enumerate(ANGLE_NAMES)}
+    roll = hk.compute_head_roll()
+    for name, got in (("Angle_head_roll", roll), ("Angle_head_pitch", hk.compute_head_pitch()),
+                      ("Angle_head_yaw", hk.compute_head_yaw())):
+        assert np.array_equal(got, both[name]) and np.abs(got - col[name]).max() < TOL
+    for side in ("L", "R", "l"):
+        for kind, fn in (("yaw", hk.compute_antenna_yaw), ("pitch", hk.compute_antenna_pitch)):
+            name = f"Angle_antenna_{kind}_{side.upper()}"
+            got = fn(side=side, head_roll=roll)
+            assert np.abs(got - both[name]).max() < 1e-10 and np.abs(got - col[name]).max() < TOL
+    with pytest.raises(ValueError, match="Side should be either R or L"):
+        hk.compute_antenna_yaw("X", roll)
+    # a roll that is NOT the frames' own (the reference derotates by whatever it is handed)
+    args = (z["R_head"], z["L_head"], z["Neck"][:, 0], hk.rest_head_pitch, hk.rest_antenna_pitch)
+    for other in (roll + 0.3, np.full(6000, -0.7)):
+        want = head_oracle.head_angles(*args, head_roll=other)
+        assert np.abs(hk.compute_antenna_yaw("L", other) - want[3]).max() < TOL
+        assert np.abs(hk.compute_antenna_pitch("L", other) - want[4]).max() < TOL
+        assert np.abs(hk.compute_antenna_yaw("R", other) - want[5]).max() < TOL
+        assert np.abs(hk.compute_antenna_pitch("R", other) - want[6]).max() < TOL
+    dev = hiplib.head_angles(*args, head_roll=roll + 0.3)
+    assert np.array_equal(dev[:3], np.stack([both[n] for n in ANGLE_NAMES[:3]]))
+    # array helpers and attributes
+    assert np.array_equal(hk.head_vector_mid, (z["R_head"][:, 0] + z["L_head"][:, 0]) * 0.5 - z["Neck"][:, 0])
+    assert np.array_equal(hk.head_vector_horizontal, z["L_head"][:, 0] - z["R_head"][:, 0])
+    assert np.array_equal(hk.get_head_vector("R"), z["Neck"][:, 0] - z["R_head"][:, 0])
+    assert np.array_equal(hk.get_ant_vector("L"), z["L_head"][:, 1] - z["L_head"][:, 0])
+    assert hk.get_plane(Axes.X_AXIS, 5).shape == (5, 3)
+    v = hk.get_ant_vector("R")[:50]
+    assert np.abs(hk.derotate_vector(0.4, v) - Rotation.from_euler("x", -0.4).apply(v)).max() < 1e-15
+    # angle_between_segments as the reference uses it for the head roll, and for general operands
+    hv = hk.head_vector_horizontal.copy()
+    hv[:, 0] = 0
+    got = HeadInverseKinematics.angle_between_segments(v1=hk.get_plane(Axes.Y_AXIS, 6000), v2=hv, rot_axis=Axes.X_AXIS)
+    assert np.abs(got - roll).max() < 1e-10
+    rng = np.random.default_rng(8)
+    v1, v2, axis = rng.normal(size=(4097, 3)), rng.normal(size=(4097, 3)), rng.normal(size=3)
+    assert np.abs(HeadInverseKinematics.angle_between_segments(v1, v2, axis) - head_oracle.signed_angle(v1, v2, axis)).max() < 1e-7
+    assert HeadInverseKinematics.angle_between_segments(v1[:0], v2[:0], axis).shape == (0,)
+    # one key point per side (e.g. a bristle): head angles only (reference docstring :26)
+    one = HeadInverseKinematics({"R_head": z["R_head"][:, :1], "L_head": z["L_head"][:, :1], "Neck": z["Neck"]},
+                                NMF_TEMPLATE, log_level="ERROR")
+    only = one.compute_head_angles(compute_ant_angles=False)
+    assert list(only) == ANGLE_NAMES[:3] and all(np.array_equal(only[n], both[n]) for n in only)
+    assert np.array_equal(one.compute_head_yaw(), both["Angle_head_yaw"])
+    with pytest.raises(IndexError):
+        one.compute_head_angles()
+    lib = hiplib.load()
+    assert lib.seqik_head_angles_ex(None, None, 0, 0, None, 0, 0.0, 0.0, 0, None, None, None) == hiplib.SEQIK_ERR_BAD_ARG
 
 
 @pytest.mark.gpu
