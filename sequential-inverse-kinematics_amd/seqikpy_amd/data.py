@@ -86,6 +86,25 @@ PTS2ALIGN = {
     "LF_leg": ["thorax_coxa_L", "coxa_femur_L", "femur_tibia_L", "tibia_tarsus_L", "claw_L"],
 }
 
+
+
+def get_pts2align(path: str):
+    """``PTS2ALIGN`` without the leg(s) the recording's path says were not tracked (reference ``seqikpy/data.py:101-113``:
+    ``_RF`` / ``_LF`` / ``_RLF`` | ``_LRF`` in the path)."""
+    pts = PTS2ALIGN.copy()
+    if "_RF" in path:
+        del pts["RF_leg"]
+    elif "_LF" in path:
+        del pts["LF_leg"]
+    elif "_RLF" in path or "_LRF" in path:
+        del pts["LF_leg"]
+        del pts["RF_leg"]
+    return pts
+
+
+# every key point the alignment uses, in PTS2ALIGN's order (reference ``seqikpy/data.py:116-134``)
+SKELETON = [name for names in PTS2ALIGN.values() for name in names]
+
 # ---------------------------------------------------------------------------
 # Six-leg locomotion setup (df3d recording)
 # ---------------------------------------------------------------------------
@@ -142,3 +161,17 @@ BOUNDS_LOCOMOTION.update(_loco_bounds("RH", _D50, _D50, (-_PI, 0), (np.deg2rad(-
 BOUNDS_LOCOMOTION.update(_loco_bounds("LF", _FULL, _D90, _FULL, _FULL))
 BOUNDS_LOCOMOTION.update(_loco_bounds("LM", _D50, _FULL, (0, _PI), _FULL))
 BOUNDS_LOCOMOTION.update(_loco_bounds("LH", _D50, _D50, (0, _PI), (np.deg2rad(-180), np.deg2rad(0))))
+
+# Sizes of the template's body segments (reference ``seqikpy/data.py:44-77``; the parallel example imports it,
+# ``examples/example_leg_inv_kinematics_parallel.py:18``): the front legs' rounded lengths, the middle and hind legs' from
+# the locomotion template above, the antenna's from NMF_TEMPLATE -- the same numbers the reference lists.
+NMF_SIZE = {}
+for _seg, _front in (("Coxa", 0.40), ("Femur", 0.69), ("Tibia", 0.54), ("Tarsus", 0.63)):
+    _nxt = {"Coxa": "Femur", "Femur": "Tibia", "Tibia": "Tarsus", "Tarsus": "Claw"}[_seg]
+    for _leg in ("RF", "RM", "RH", "LF", "LM", "LH"):
+        NMF_SIZE[f"{_leg}_{_seg}"] = _front if _leg[1] == "F" else float(np.linalg.norm(
+            TEMPLATE_NMF_LOCOMOTION[f"{_leg}_{_seg}"] - TEMPLATE_NMF_LOCOMOTION[f"{_leg}_{_nxt}"]))
+for _leg, _total in (("RF", 2.26), ("RM", 2.328), ("RH", 2.515), ("LF", 2.26), ("LM", 2.328), ("LH", 2.515)):
+    NMF_SIZE[_leg] = _total
+NMF_SIZE["Antenna"] = float(np.linalg.norm(NMF_TEMPLATE["R_Antenna_base"] - NMF_TEMPLATE["R_Antenna_edge"]))
+NMF_SIZE["Antenna_mid_thorax"] = float(np.linalg.norm(NMF_TEMPLATE["R_Antenna_base"] - NMF_TEMPLATE["Thorax_mid"]))

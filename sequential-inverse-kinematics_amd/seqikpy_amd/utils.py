@@ -1,4 +1,10 @@
-"""Host helpers the leg-IK path needs (subset of the reference's ``seqikpy/utils.py``)."""
+"""Host helpers on either side of the leg-IK path: body sizes, the pickle formats, and the converters between the
+pose / angle containers the reference's callers hold (DeepFly3D dictionaries) and the ``(N, key points, 3)`` /
+``(N, dofs)`` arrays the solvers take and give, and the resampling of the resulting joint-angle series -- the
+data-format part of the reference's ``seqikpy/utils.py`` (:89-123, :235-245, :293-362).  Not here: the stimulus /
+video / DeepLabCut helpers of that file (not part of the path), its duplicates of AlignPose's private reductions, and
+``from_anipose_to_array`` / ``df_to_nparray`` (:248-290), which assign a ``(3, N)`` block into an ``(N, 3)`` slot and so
+only run for N == 3 -- nothing in the reference calls them."""
 import pickle
 from typing import Dict, List
 
@@ -57,3 +63,32 @@ def dict_to_nparray_pose(pose_dict, claw_is_end_effector: bool):
     for i, kp in enumerate(key_points):
         out[:, i, :] = np.array(pose_dict[kp]["raw_pos_aligned"])
     return out
+
+
+def dict_to_nparray_angle(angle_dict, leg, claw_is_end_effector):
+    """DeepFly3DPostProcessing angle dictionary (``{"RF_leg": {"ThC_roll": (N,), ...}}``) -> ``(N, 7 or 6)`` in THAT
+    format's column order -- roll, yaw, pitch, then CTr pitch / roll, FTi, (TiTa) (``seqikpy/utils.py:313-329``)."""
+    dofs = ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch"] + \
+        (["TiTa_pitch"] if claw_is_end_effector else [])
+    return np.stack([np.asarray(angle_dict[f"{leg}_leg"][d], dtype=np.float64) for d in dofs], axis=1)
+
+
+def interpolate_signal(signal, original_ts, new_ts):
+    """Resamples one series from time step ``original_ts`` to ``new_ts`` with a shape-preserving cubic (PCHIP) over
+    ``[0, N * original_ts)`` (``seqikpy/utils.py:332-349``).  As there: if the interpolation fails, infinities and the
+    last sample are zeroed IN the caller's array and it is tried once more."""
+    from scipy.interpolate import pchip_interpolate
+    total = signal.shape[0] * original_ts
+    x_old, x_new = np.arange(0, total, original_ts), np.arange(0, total, new_ts)
+    try:
+        return np.array(pchip_interpolate(x_old, signal, x_new))
+    except BaseException:  # noqa: B036 -- the reference's own breadth
+        signal[np.isinf(signal)] = 0
+        signal[-1] = 0
+        return np.array(pchip_interpolate(x_old, signal, x_new))
+
+
+def interpolate_joint_angles(joint_angles_dict, **kwargs):
+    """``interpolate_signal`` over every series of a joint-angle dictionary (``run_ik_and_fk``'s first result);
+    ``original_ts`` / ``new_ts`` as keyword arguments (``seqikpy/utils.py:352-360``)."""
+    return {dof: interpolate_signal(signal=series, **kwargs) for dof, series in joint_angles_dict.items()}

@@ -199,3 +199,34 @@ def test_frame_parallel_default_and_chunk_report(monkeypatch):
     assert rep[0]["LF"]["failed_first_check"] == [] and rep[1]["LF"]["walked_serially"] and not rep[1]["RF"]["walked_serially"]
     assert rep[1]["LF"]["failed_first_check"] == [0, 8, 16, 24, 32]
     assert chunk_report(dict(angles=np.zeros((3, 1, 4, 7)), chunk_flags=None, chunk_stats=dict(chunks=0)), ["RF"], 4) == [{}, {}, {}]
+
+
+def test_output_side_converters_and_resampling():
+    """utils.dict_to_nparray_angle / interpolate_signal / interpolate_joint_angles (reference seqikpy/utils.py:313-362) and
+    the constant tables the reference's callers import (data.NMF_SIZE, SKELETON, get_pts2align)."""
+    from scipy.interpolate import PchipInterpolator
+    from seqikpy_amd import data, utils
+    rng = np.random.default_rng(0)
+    dofs = ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
+    ang = {"RF_leg": {d: rng.normal(size=50) for d in dofs}}
+    full = utils.dict_to_nparray_angle(ang, "RF", True)
+    assert full.shape == (50, 7) and all(np.array_equal(full[:, i], ang["RF_leg"][d]) for i, d in enumerate(dofs))
+    assert np.array_equal(utils.dict_to_nparray_angle(ang, "RF", False), full[:, :6])
+    series = {"Angle_RF_ThC_yaw": np.sin(np.linspace(0, 3, 100)), "Angle_RF_ThC_pitch": rng.normal(size=100)}
+    out = utils.interpolate_joint_angles(series, original_ts=1e-2, new_ts=1e-3)
+    assert list(out) == list(series)
+    x_old, x_new = np.arange(0, 1.0, 1e-2), np.arange(0, 1.0, 1e-3)
+    for k in series:
+        assert out[k].shape == x_new.shape
+        assert np.array_equal(out[k], PchipInterpolator(x_old, series[k])(x_new))
+        assert np.array_equal(out[k][::10][:99], series[k][:99])      # passes through the samples
+    bad = np.ones(10)
+    bad[3] = np.inf
+    fixed = utils.interpolate_signal(bad, 1.0, 0.5)      # the reference's repair: inf and the last sample zeroed in place
+    assert np.isfinite(fixed).all() and bad[3] == 0 and bad[-1] == 0
+    assert len(data.NMF_SIZE) == 32 and data.NMF_SIZE["RF"] == 2.26 and data.NMF_SIZE["RM_Coxa"] == 0.182
+    for leg in data.LEGS:
+        assert sum(data.NMF_SIZE[f"{leg}_{s}"] for s in data.SEGMENTS) == pytest.approx(data.NMF_SIZE[leg], abs=1e-12)
+    assert data.SKELETON[:2] == ["base_anten_R", "tip_anten_R"] and len(data.SKELETON) == 17
+    assert "RF_leg" not in data.get_pts2align("rec_RF_x") and "LF_leg" in data.get_pts2align("rec_RF_x")
+    assert set(data.get_pts2align("rec_RLF")) == {"R_head", "Thorax", "L_head"} and "RF_leg" in data.PTS2ALIGN

@@ -28,6 +28,50 @@ def test_constants_equal_the_reference():
             assert np.array_equal(data.INITIAL_ANGLES[leg][st], rd.INITIAL_ANGLES[leg][st])
     a, b = utils.calculate_body_size(data.NMF_TEMPLATE, ["RF", "LF"]), ref_body(rd.NMF_TEMPLATE, ["RF", "LF"])
     assert set(a) == set(b) and all(a[k] == b[k] for k in a)
+    assert list(data.NMF_SIZE) == list(rd.NMF_SIZE) and all(data.NMF_SIZE[k] == rd.NMF_SIZE[k] for k in rd.NMF_SIZE)
+    assert data.PTS2ALIGN == rd.PTS2ALIGN and data.SKELETON == rd.SKELETON
+    for path in ("x/pose_RF/y", "x_LF", "a_RLF_b", "a_LRF", "plain"):
+        assert data.get_pts2align(path) == rd.get_pts2align(path)
+
+
+def test_head_methods_with_a_given_roll_against_the_reference(host_harness):
+    """The reference's per-quantity head methods (head_inverse_kinematics.py:185-307), run here, against the head kernel's
+    device code compiled for the host: antenna angles derotated by a head roll that is NOT the frames' own; the general
+    angle_between_segments."""
+    import_reference()
+    from seqikpy.data import NMF_TEMPLATE
+    from seqikpy.head_inverse_kinematics import HeadInverseKinematics as RefHead
+    z = load_golden("anipose_head")
+    n = 300
+    pos = {"R_head": z["R_head"][:n], "L_head": z["L_head"][:n], "Neck": z["Neck"]}
+    ref = RefHead(pos, NMF_TEMPLATE, log_level="ERROR")
+    rest_hp, rest_ap = float(np.ravel(ref.rest_head_pitch)[0]), float(np.ravel(ref.rest_antenna_pitch)[0])
+    rng = np.random.default_rng(2)
+    for roll in (ref.compute_head_roll(), ref.compute_head_roll() + 0.4, rng.uniform(-3, 3, n)):
+        got = host_harness.head_angles(pos["R_head"], pos["L_head"], pos["Neck"][:, 0], rest_hp, rest_ap, head_roll=roll)
+        assert np.abs(got[0] - ref.compute_head_roll()).max() < 1e-9
+        assert np.abs(got[1] - ref.compute_head_pitch()).max() < 1e-9
+        assert np.abs(got[2] - ref.compute_head_yaw()).max() < 1e-9
+        for row, (kind, side) in zip((3, 4, 5, 6), (("yaw", "L"), ("pitch", "L"), ("yaw", "R"), ("pitch", "R"))):
+            want = getattr(ref, f"compute_antenna_{kind}")(side=side, head_roll=roll)
+            assert np.abs(got[row] - want).max() < 1e-7, (kind, side)
+    v1, v2, axis = rng.normal(size=(200, 3)), rng.normal(size=(200, 3)), rng.normal(size=3)
+    assert np.abs(host_harness.signed_angles(v1, v2, axis) - RefHead.angle_between_segments(v1, v2, axis)).max() < 1e-7
+
+
+def test_output_side_utils_equal_the_reference():
+    import_reference()
+    import seqikpy.utils as ru
+    from seqikpy_amd import utils
+    rng = np.random.default_rng(1)
+    dofs = ["ThC_roll", "ThC_yaw", "ThC_pitch", "CTr_pitch", "CTr_roll", "FTi_pitch", "TiTa_pitch"]
+    ang = {"LM_leg": {d: rng.normal(size=40) for d in dofs}}
+    for claw in (True, False):
+        assert np.array_equal(utils.dict_to_nparray_angle(ang, "LM", claw), ru.dict_to_nparray_angle(ang, "LM", claw))
+    series = {f"Angle_RF_{d}": rng.normal(size=200).cumsum() for d in dofs}
+    a = utils.interpolate_joint_angles(series, original_ts=1e-2, new_ts=1e-4)
+    b = ru.interpolate_joint_angles(series, original_ts=1e-2, new_ts=1e-4)
+    assert list(a) == list(b) and all(np.array_equal(a[k], b[k]) for k in a)
 
 
 def test_locomotion_constants_equal_the_reference_example():
