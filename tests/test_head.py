@@ -162,7 +162,7 @@ def test_head_per_quantity_methods_on_gpu(z, hiplib):
     with pytest.raises(IndexError):
         one.compute_head_angles()
     lib = hiplib.load()
-    assert lib.seqik_head_angles_ex(None, None, 0, 0, None, 0, 0.0, 0.0, 0, None, None, None) == hiplib.SEQIK_ERR_BAD_ARG
+    assert lib.seqik_head_angles_ex(None, None, 0, 0, None, 0, 0.0, 0.0, 0, None, None, None) == hiplib.ERR_ARG
 
 
 @pytest.mark.gpu
