@@ -644,6 +644,46 @@ def reference_configs(time_box_s=240.0):
             "ms": ms, "leg_frames_per_s": 2 * 6000 / ms * 1e3, "angles_per_frame": 21,
             "max_abs_dtheta_legs_vs_fixture": float(np.abs(legs_a - ref)[ok].max()),
             "max_abs_head_vs_shipped_head_joint_angles": float(np.abs(head - zh["shipped"]).max())}
+    # the head / antenna kernel on its own at a size where it is bound by HBM (config 4's 6000 frames are a launch latency):
+    # 16 M frames resident in HBM, HIP events on the stream the kernel is launched on
+    try:
+        reps = 16_000_000 // 6000
+        d_r = torch.from_numpy(zh["R_head"]).cuda().repeat(reps, 1, 1)
+        d_l = torch.from_numpy(zh["L_head"]).cuda().repeat(reps, 1, 1)
+        d_neck = torch.from_numpy(zh["Neck"][0, 0].copy()).cuda()
+        n_h = d_r.shape[0]
+        d_out = torch.zeros((7, n_h), dtype=torch.float64, device="cuda")
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+
+        def head_launch():
+            rc = lib.seqik_head_angles_device(d_r.data_ptr(), d_l.data_ptr(), n_h, d_neck.data_ptr(), 0,
+                                              float(zh["rest_head_pitch"][0]), float(zh["rest_antenna_pitch"][0]), 1,
+                                              d_out.data_ptr(), stream)
+            if rc != 0:
+                raise RuntimeError("seqik_head_angles_device failed")
+        for _ in range(15):
+            head_launch()
+        k_h = 30
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(k_h + 1)]
+        evs[0].record()
+        for i in range(k_h):
+            head_launch()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        each = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(k_h)])
+        gbps = (96 + 56) * n_h / float(each.mean()) / 1e6
+        small = _lib.head_angles(zh["R_head"], zh["L_head"], zh["Neck"][:, 0], float(zh["rest_head_pitch"][0]),
+                                 float(zh["rest_antenna_pitch"][0]))
+        same = bool(np.array_equal(d_out[:, -6000:].cpu().numpy(), small))
+        e4["head_kernel"] = {"kernel": "seqik_head_kernel<true>", "frames": n_h, "launches": k_h, "ms": float(each.mean()),
+                             "ms_best": float(each.min()), "frames_per_s": n_h / float(each.mean()) * 1e3,
+                             "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                                          "frac": round(gbps / 8000.0, 3), "algorithmic_bytes_per_frame": 152},
+                             "equals_the_6000_frame_call_tiled": same}
+        del d_r, d_l, d_out
+    except Exception as exc:  # noqa: BLE001
+        e4["head_kernel"] = {"error": f"{type(exc).__name__}: {exc}"}
     out["4"] = e4
     out["3"] = {"workload": "config 3: synthetic 1M frames x 6 legs", "see": "top level: value (3 batches in flight), "
                 "value_single_job, variants.smooth, single_recording (ONE recording), strong_projection"}
