@@ -676,10 +676,19 @@ def reference_configs(time_box_s=240.0):
         small = _lib.head_angles(zh["R_head"], zh["L_head"], zh["Neck"][:, 0], float(zh["rest_head_pitch"][0]),
                                  float(zh["rest_antenna_pitch"][0]))
         same = bool(np.array_equal(d_out[:, -6000:].cpu().numpy(), small))
+        traffic = None
+        try:   # committed PMC summary of the same kernel and size (scripts/gpu_head_profile.sh): HBM bytes per frame
+            with open(os.path.join(ROOT, "profiles", "r04_head_profile.json")) as fh:
+                traffic = json.load(fh)["traffic_bytes_per_frame"] * n_h
+        except (OSError, KeyError, ValueError):
+            pass
         e4["head_kernel"] = {"kernel": "seqik_head_kernel<true>", "frames": n_h, "launches": k_h, "ms": float(each.mean()),
                              "ms_best": float(each.min()), "frames_per_s": n_h / float(each.mean()) * 1e3,
                              "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
-                                          "frac": round(gbps / 8000.0, 3), "algorithmic_bytes_per_frame": 152},
+                                          "frac": round(gbps / 8000.0, 3), "algorithmic_bytes_per_frame": 152,
+                                          "traffic": traffic,
+                                          "traffic_source": "profiles/r04_head_profile.json (FETCH_SIZE doubled for 16-byte-per-"
+                                                            "lane streaming loads as the guide prescribes, + WRITE_SIZE)"},
                              "equals_the_6000_frame_call_tiled": same}
         del d_r, d_l, d_out
     except Exception as exc:  # noqa: BLE001
