@@ -23,6 +23,9 @@ Fixtures (all float64 unless noted; DOF order = c_oracle.DOFS):
   generic_rf_100.npz    LegInvKinGeneric on anipose RF frames 0:100, run here
   anipose_raw_cut.npz   converted_dict.pkl[:1500] (un-aligned legs, antennae, thorax) + reference AlignPose output
   anipose_head.npz      aligned head key points, shipped head_joint_angles.pkl, HeadInverseKinematics run here
+  df3d_align_pins.npz   reference-HELD pins of the alignment row on all six legs: the un-aligned df3d key points of
+                        frames 300:400 (seqikpy_locomotion.ipynb cell 2), the six find_scale_leg values the
+                        notebook's stored cell-6 output prints, and the shipped pose3d_aligned.pkl of that cut
 """
 import argparse
 import importlib.util
@@ -217,6 +220,35 @@ def gen_anipose_raw_cut():
     return out
 
 
+def gen_df3d_align_pins():
+    """Pins held by the reference itself (no run of anything here): examples/seqikpy_locomotion.ipynb cell 2 cuts frames
+    300:400 of the df3d recording, cell 6 aligns them and its STORED OUTPUT prints the six `find_scale_leg` results
+    (seqikpy/alignment.py:417-423); data/df3d_pose_result__210902_PR_Fly1/pose3d_aligned.pkl is what that cell
+    exported.  Stored: the cut's un-aligned key points, the six printed floats, the shipped aligned arrays."""
+    import json
+    import re
+    import_reference()
+    from seqikpy.alignment import convert_from_df3dpp_to_dict
+    legs = ["RF", "RM", "RH", "LF", "LM", "LH"]
+    raw = load_pickle(os.path.join(DF3D, "pose_result__210902_PR_Fly1_aligned.pkl"))
+    converted = convert_from_df3dpp_to_dict(raw)
+    shipped = load_pickle(os.path.join(DF3D, "pose3d_aligned.pkl"))
+    with open(os.path.join(REFERENCE_ROOT, "examples", "seqikpy_locomotion.ipynb")) as fh:
+        nb = json.load(fh)
+    printed = {}
+    for cell in nb["cells"]:
+        for o in cell.get("outputs", []):
+            for m in re.finditer(r"Scale factor for (\w\w) leg: ([0-9.eE+-]+)", "".join(o.get("text", []))):
+                printed[m.group(1)] = float(m.group(2))
+    assert sorted(printed) == sorted(legs), printed
+    out = {"legs": np.array(legs), "frames": np.array([300, 400]),
+           "printed_scale_factors": np.array([printed[l] for l in legs], dtype=np.float64)}
+    for leg in legs:
+        out[f"{leg}_raw"] = np.ascontiguousarray(converted[f"{leg}_leg"][300:400], dtype=np.float64)
+        out[f"{leg}_shipped_aligned"] = np.ascontiguousarray(shipped[f"{leg}_leg"], dtype=np.float64)
+    return out
+
+
 GENERATORS = {
     "anipose_shipped": gen_anipose_shipped,
     "anipose_scipy_cut": gen_anipose_scipy_cut,
@@ -225,6 +257,7 @@ GENERATORS = {
     "generic_rf_100": gen_generic_rf_100,
     "anipose_head": gen_anipose_head,
     "anipose_raw_cut": gen_anipose_raw_cut,
+    "df3d_align_pins": gen_df3d_align_pins,
 }
 
 

@@ -209,3 +209,28 @@ def test_linear_quantile_index_equals_numpy_for_every_n():
             if n <= 100_000:
                 want = np.quantile(np.arange(n, dtype=np.float64), q)
                 assert lerp(float(lo), float(hi), g) == want, (n, q)
+
+
+def test_reference_held_pins_six_legs_notebook_scale_factors_and_shipped_alignment():
+    """Pins the reference itself holds for the alignment row on ALL SIX legs with the locomotion template (nothing here
+    was produced by the build container): the six `find_scale_leg` values printed in the stored output of
+    examples/seqikpy_locomotion.ipynb cell 6 (seqikpy/alignment.py:417-423) and the aligned poses that cell exported,
+    shipped as data/df3d_pose_result__210902_PR_Fly1/pose3d_aligned.pkl (alignment.py:392-434, 436-487).  Fixture:
+    df3d_align_pins.npz (oracle/gen_golden.py::gen_df3d_align_pins)."""
+    z = load_golden("df3d_align_pins")
+    legs = [str(l) for l in z["legs"]]
+    raw = {f"{l}_leg": z[f"{l}_raw"] for l in legs}
+    al = AlignPose(raw, legs_list=legs, include_claw=False, body_template=data.TEMPLATE_NMF_LOCOMOTION,
+                   body_size=None, log_level="ERROR")
+    for leg, printed in zip(legs, z["printed_scale_factors"]):
+        scale = al.find_scale_leg(leg, al.get_mean_length(raw[f"{leg}_leg"], segment_is_leg=True))
+        assert float(scale) == float(printed), (leg, scale, printed)      # repr round trip: every printed digit
+        assert al.leg_affine(raw[f"{leg}_leg"], leg)[1] == float(printed)
+    aligned = al.align_pose()
+    assert list(aligned.keys()) == [f"{l}_leg" for l in legs]
+    for leg in legs:
+        assert np.array_equal(aligned[f"{leg}_leg"], z[f"{leg}_shipped_aligned"]), leg   # max |delta| = 0
+    # and the shipped file is the input of the df3d_100 leg fixture: the chain of custody of config 2's short cut
+    z100 = load_golden("df3d_100")
+    for leg in legs:
+        assert np.array_equal(z100[f"{leg}_pose"], z[f"{leg}_shipped_aligned"]), leg

@@ -119,3 +119,86 @@ def test_chain_link_names_equal_the_reference():
         assert mine.name == ref.name
         for a, b in zip(mine.links, ref.links):
             assert a.bounds == tuple(b.bounds)
+
+
+def test_public_signatures_equal_or_defaulted_supersets_of_the_reference():
+    """Drop-in guard: every public method / function of the reference's path classes exists here with the same
+    parameters in the same order, kinds and defaults; what this build adds must carry a default (so a reference caller's
+    positional and keyword calls keep their meaning).  Classes: LegInvKin*, KinematicChain*, AlignPose,
+    HeadInverseKinematics; plus the module-level functions a reference caller imports."""
+    import inspect
+    import_reference()
+    import importlib
+    import seqikpy.alignment  # noqa: F401
+    import seqikpy.head_inverse_kinematics  # noqa: F401
+    pairs = [("leg_inverse_kinematics", ["LegInvKinBase", "LegInvKinSeq", "LegInvKinGeneric"], []),
+             ("kinematic_chain", ["KinematicChainBase", "KinematicChainSeq", "KinematicChainGeneric"], []),
+             ("alignment", ["AlignPose"], ["convert_from_anipose_to_dict", "convert_from_df3d_to_dict",
+                                           "convert_from_df3dpp_to_dict", "_get_distance_btw_vecs", "_get_mean_quantile",
+                                           "_leg_length_model"]),
+             ("head_inverse_kinematics", ["HeadInverseKinematics"], []),
+             ("utils", [], ["calculate_body_size", "load_file", "save_file", "dict_to_nparray_pose"]),
+             ]
+    empty = inspect.Parameter.empty
+    problems = []
+    # the one deliberate difference: None stands for the reference's MUTABLE list default (same legs, same order)
+    equivalent_defaults = {("utils.calculate_body_size", "legs_list"): (None, ["RF", "LF", "RM", "LM", "RH", "LH"])}
+
+    def same_default(a, b):
+        if a is empty or b is empty:
+            return a is b
+        if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+            return np.array_equal(a, b)
+        return a == b or (callable(a) and callable(b) and getattr(a, "__name__", 1) == getattr(b, "__name__", 2))
+
+    def compare(where, ref_fn, my_fn):
+        try:
+            rs, ms = inspect.signature(ref_fn), inspect.signature(my_fn)
+        except (TypeError, ValueError):
+            return
+        rp, mp = list(rs.parameters.values()), list(ms.parameters.values())
+        for i, p in enumerate(rp):
+            if i >= len(mp) or mp[i].name != p.name:
+                problems.append(f"{where}: parameter {i} is {mp[i].name if i < len(mp) else None!r}, reference has {p.name!r}")
+                return
+            if mp[i].kind != p.kind:
+                problems.append(f"{where}({p.name}): kind {mp[i].kind} != {p.kind}")
+            if equivalent_defaults.get((where, p.name)) == (mp[i].default, p.default):
+                continue
+            if not same_default(p.default, mp[i].default) and not (p.default is empty and mp[i].default is not empty):
+                problems.append(f"{where}({p.name}): default {mp[i].default!r} != {p.default!r}")
+        for extra in mp[len(rp):]:
+            if extra.default is empty and extra.kind not in (extra.VAR_KEYWORD, extra.VAR_POSITIONAL):
+                problems.append(f"{where}: added parameter {extra.name!r} has no default")
+
+    for mod, classes, functions in pairs:
+        ref_mod = importlib.import_module(f"seqikpy.{mod}")
+        my_mod = importlib.import_module(f"seqikpy_amd.{mod}")
+        for fn in functions:
+            if not hasattr(ref_mod, fn):
+                continue
+            if not hasattr(my_mod, fn):
+                if not fn.startswith("_"):
+                    problems.append(f"{mod}.{fn}: missing")
+                continue
+            compare(f"{mod}.{fn}", getattr(ref_mod, fn), getattr(my_mod, fn))
+        for cls in classes:
+            rc, mc = getattr(ref_mod, cls), getattr(my_mod, cls, None)
+            if mc is None:
+                problems.append(f"{mod}.{cls}: missing")
+                continue
+            names = [n for n, v in vars(rc).items() if (not n.startswith("_") or n in ("__init__", "__call__"))
+                     and (inspect.isfunction(v) or isinstance(v, (staticmethod, classmethod, property)))]
+            for n in names:
+                if not hasattr(mc, n):
+                    problems.append(f"{cls}.{n}: missing")
+                    continue
+                rv, mv = inspect.getattr_static(rc, n), inspect.getattr_static(mc, n)
+                if isinstance(rv, property):
+                    if not isinstance(mv, property):
+                        problems.append(f"{cls}.{n}: property in the reference")
+                    continue
+                if type(rv) in (staticmethod, classmethod) and type(rv) is not type(mv):
+                    problems.append(f"{cls}.{n}: {type(rv).__name__} in the reference, {type(mv).__name__} here")
+                compare(f"{cls}.{n}", getattr(rc, n), getattr(mc, n))
+    assert not problems, "\n".join(problems)
