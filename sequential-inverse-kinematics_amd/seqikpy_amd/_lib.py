@@ -15,7 +15,9 @@ from .data import DOFS, SEGMENTS
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
-LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(CSRC, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
+# in the source tree: csrc/ next to the package; installed (pyproject.toml / setup.py): the built library inside it
+_LIB_DIR = CSRC if os.path.isdir(CSRC) else os.path.join(_PKG, "_native")
+LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(_LIB_DIR, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
 SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip", "seqik_core.hpp",
            "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp", "seqik_device_scope.hpp", "seqik_hostctx.hpp"]
 COMPILE_UNITS = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip"]
@@ -175,6 +177,8 @@ def csrc_sha256(files=None, read=None) -> str:
 
 
 def is_stale() -> bool:
+    if not os.path.isdir(CSRC):
+        return False          # installed package: the library was compiled when the distribution was built
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
