@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 5
+#define SEQIK_ABI_VERSION 6
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -92,7 +92,9 @@ typedef struct SeqikOptions {
                              1 = never, 2 = whenever applicable, 3 = as 2 but without lane pairs (a wavefront that
                              carries at most 32 chains runs each on two or more lanes, and neighbouring lanes split
                              the finite-difference columns and the trial point's sin / cos of a pass between them;
-                             3 is for measurements).  None of these changes a result bit. */
+                             3 is for measurements), 4 / 5 = as 2 / 3 but never the 256-register latency build of
+                             the pipeline kernels (tests: that build against the plain one).  None of these changes a
+                             result bit. */
     /* ---- frame chunks (ABI 2): ONE long recording on the whole GPU -------------------------------------------
      * The reference walks a recording serially because frame t is warm-started from frame t-1
      * (seqikpy/leg_inverse_kinematics.py:259-282).  With frame_chunk != 0 a run of all four stages (no status /
@@ -237,15 +239,20 @@ int seqik_selftest_div_sqrt(const double *a, const double *b, double *q, double 
  * limits against IEEE sqrt.  No reference counterpart. */
 int seqik_selftest_sqrt_pos(const double *a, double *r, int64_t n);
 
-/* ABI 4.  Device faults.  The reference reports every failure as a Python exception (IKPy raises on scipy status -1,
+/* ABI 4 / 6.  Device faults.  The reference reports every failure as a Python exception (IKPy raises on scipy status -1,
  * seqikpy/leg_inverse_kinematics.py:62-69 -> ikpy); it never returns silent garbage.  The one failure a kernel of this
  * library can detect by itself -- the stage pipeline's watchdog: a lane that waited 2^24 passes for its neighbour wave,
- * impossible by construction -- fills the rest of that chain with NaN and sets a process-wide fault word in mapped host
- * memory.  The blocking entry points (seqik_solve_seq, seqik_stream_wait) read and clear the word after they have
- * synchronised and return SEQIK_ERR_HIP with a message; seqik_solve_seq_device, which does not synchronise, reports a
- * fault left by EARLIER launches when it is entered.  Callers of the device entry point call seqik_check_faults() after
- * synchronising their stream: SEQIK_OK, or SEQIK_ERR_HIP (message in seqik_last_error(); the word is cleared). */
+ * impossible by construction -- fills the rest of that chain with NaN and sets a fault word in mapped host memory: since
+ * ABI 6 ONE WORD PER (device, stream), so that host threads that drive different GPUs or streams never consume each
+ * other's faults (more than 63 distinct (device, stream) pairs in a process share the last word).  The blocking entry
+ * points (seqik_solve_seq, seqik_stream_wait) read and clear the words of THEIR streams after they have synchronised and
+ * return SEQIK_ERR_HIP with a message; seqik_solve_seq_device, which does not synchronise, reports a fault left by EARLIER
+ * launches ON THE SAME STREAM when it is entered.  Callers of the device entry point call, after synchronising,
+ * seqik_check_faults_stream(stream) (that stream of the current device only; thread-safe next to other streams' users) or
+ * seqik_check_faults() (EVERY word: single-threaded callers, end-of-job checks): SEQIK_OK, or SEQIK_ERR_HIP (message
+ * in seqik_last_error(); the words read are cleared). */
 int seqik_check_faults(void);
+int seqik_check_faults_stream(void *hip_stream);
 
 /* The frame chunks a call over recordings of n_frames frames would use with these options (frame_chunk / frame_halo /
  * frame_lead): frames per chunk, run-in frames, chunks per chain K -- all 0 when the call would be walked serially.

@@ -80,36 +80,76 @@ int fail(int code, const char *fmt, const char *detail = "")
 // (seqikpy/leg_inverse_kinematics.py:232-236: IKPy raises when scipy's status is -1).  The one condition a kernel of
 // this library can detect by itself is the stage pipeline's watchdog (run_stage, PIPED: a lane that waited 2^24 passes
 // for its neighbour wave -- impossible by construction, so if it happens something is broken).  The lane then fills the
-// rest of its chain with NaN, frees its neighbours AND writes the stage number into one 32-bit word in pinned,
-// device-mapped HOST memory (one word per process, visible to every GPU).  No launch pays for it: the store sits in the
-// branch that never runs.  Every host entry point that synchronises reads and clears the word afterwards and returns
-// SEQIK_ERR_HIP with a message; the asynchronous device entry points report a fault left by EARLIER launches when they
-// are entered, and seqik_check_faults() is there for callers that synchronise themselves.
+// rest of its chain with NaN, frees its neighbours AND writes the stage number into a 32-bit word in pinned,
+// device-mapped HOST memory.  No launch pays for it: the store sits in the branch that never runs.
+// ABI 6: ONE WORD PER (device, stream) -- kFaultSlots of them in one mapped block; a launch reports to the word of the
+// stream it was made on, so a host with one thread per GPU or per stream never consumes another thread's fault (with the
+// single process-wide word of ABI 4-5 thread B entering an asynchronous call would read and clear thread A's fault, refuse
+// its own valid launch, and A's blocking call would return SEQIK_OK with NaN data).  Every host entry point that
+// synchronises reads and clears the word OF ITS STREAM afterwards and returns SEQIK_ERR_HIP with a message; the
+// asynchronous device entry points report a fault EARLIER launches on the same stream left behind when they are entered;
+// seqik_check_faults_stream(stream) serves callers that synchronise a stream themselves, seqik_check_faults() reads and
+// clears EVERY word (single-threaded callers, end-of-job checks).  More than kFaultSlots - 1 distinct (device, stream)
+// pairs in one process share the last word: the behaviour of ABI 5, conservative (a fault is never lost).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kFaultSlots = 64;
 std::once_flag g_fault_once;
-std::atomic<int32_t *> g_fault_host{nullptr};  // host address (read by threads that never launched: check_faults)
-int32_t *g_fault_device = nullptr;             // the same word as the GPUs address it (written once, under g_fault_once)
+std::atomic<int32_t *> g_fault_host{nullptr};  // host address of the block (read by threads that never launched)
+int32_t *g_fault_device = nullptr;             // the same block as the GPUs address it (written once, under g_fault_once)
+std::mutex g_fault_mu;                         // guards the (device, stream) -> slot table below
+int g_fault_used = 0;
+int g_fault_dev[kFaultSlots];
+hipStream_t g_fault_stream[kFaultSlots];
 
-int32_t *fault_word()
+void fault_block()
 {
     std::call_once(g_fault_once, [] {
         void *h = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
-        memset(h, 0, 64);
+        const size_t bytes = sizeof(int32_t) * kFaultSlots;
+        if (hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
+        memset(h, 0, bytes);
         void *d = nullptr;
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
         g_fault_device = static_cast<int32_t *>(d);
         g_fault_host.store(static_cast<int32_t *>(h), std::memory_order_release);
     });
-    return g_fault_device;  // null: no mapped host memory on this system -- the watchdog then only leaves its NaN
 }
 
-// reads and clears the fault word; SEQIK_OK or SEQIK_ERR_HIP with the message set
-int check_faults(const char *where)
+// slot of (current device, stream): found or assigned; the table never shrinks (streams are pooled by every caller in
+// this tree); when it is full the last slot is shared
+int fault_slot(hipStream_t stream)
 {
-    int32_t *word = g_fault_host.load(std::memory_order_acquire);
-    if (!word) return SEQIK_OK;   // nothing has been launched yet
-    const int32_t v = __atomic_exchange_n(word, 0, __ATOMIC_ACQ_REL);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> lock(g_fault_mu);
+    for (int i = 0; i < g_fault_used; ++i)
+        if (g_fault_dev[i] == dev && g_fault_stream[i] == stream) return i;
+    if (g_fault_used < kFaultSlots - 1) {
+        g_fault_dev[g_fault_used] = dev;
+        g_fault_stream[g_fault_used] = stream;
+        return g_fault_used++;
+    }
+    return kFaultSlots - 1;
+}
+
+int32_t *fault_word(hipStream_t stream)
+{
+    fault_block();
+    if (!g_fault_device) return nullptr;  // no mapped host memory on this system -- the watchdog then only leaves its NaN
+    return g_fault_device + fault_slot(stream);
+}
+
+// reads and clears the fault word of `slot` (-1: every word); SEQIK_OK or SEQIK_ERR_HIP with the message set
+int check_faults(const char *where, int slot)
+{
+    int32_t *words = g_fault_host.load(std::memory_order_acquire);
+    if (!words) return SEQIK_OK;   // nothing has been launched yet
+    int32_t v = 0;
+    const int lo = slot < 0 ? 0 : slot, hi = slot < 0 ? kFaultSlots : slot + 1;
+    for (int i = lo; i < hi; ++i) {
+        const int32_t w = __atomic_exchange_n(words + i, 0, __ATOMIC_ACQ_REL);
+        if (w != 0 && v == 0) v = w;
+    }
     if (v == 0) return SEQIK_OK;
     snprintf(g_err, sizeof(g_err),
              "%s: stage pipeline watchdog: a lane of stage %d waited more than %d passes for its neighbour wave; the "
@@ -1129,7 +1169,7 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
 {
     KernelArgs a;
     a.init = d_init;
-    a.fault = fault_word();
+    a.fault = fault_word(stream);
     if (layout) {
         if (layout->pose_chain < 0 || layout->pose_row <= 0 || layout->pose_frame <= 0 || layout->ang_chain < 0 ||
             layout->ang_dof <= 0 || layout->ang_frame <= 0)
@@ -1164,13 +1204,15 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (n_vchains > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many frame chunks for one launch%s");
     // stage pipeline (four waves per group of chains, seqik_pipe_kernel): SeqikOptions.reserved[3] = 0 automatic (calls
     // with at most kPipeMaxChains chains / chunks: too few for the lane-per-chain kernels to fill the GPU, so the
-    // serial path per frame is what counts), 1 = never, 2 = whenever applicable
+    // serial path per frame is what counts), 1 = never, 2 = whenever applicable, 3 = as 2 without lane pairs, 4 / 5 = as
+    // 2 / 3 but never the 256-register LATENCY build (run_stage<..., LAT>): the A/B switch of the tests that pin LAT's
+    // register-carried Jacobian / gradient / scaling reuse against the plain instantiation, bit for bit
     const int pipe_opt = opt ? opt->reserved[3] : 0;
     const bool staged = opt && opt->reserved[1] == 1;  // "always one launch per stage" rules out the AUTOMATIC pipeline
     const bool piped = first_stage == 1 && last_stage == 4 && !diag &&
                        (pipe_opt >= 2 || (pipe_opt == 0 && !(staged && !chunked) &&
                                           n_vchains <= (chunked ? kPipeMaxChunks : kPipeMaxChains)));
-    a.lane_pairs = pipe_opt == 3 ? 0 : 1;  // 3 = as 2, thin waves without lane pairs (measurements)
+    a.lane_pairs = (pipe_opt == 3 || pipe_opt == 5) ? 0 : 1;  // 3 / 5 = thin waves without lane pairs (measurements)
     a.lanes_per_wave = pick_lanes_per_wave(n_vchains, opt, chunked || piped);
     int64_t n_waves = ((n_seq * n_chunks + a.lanes_per_wave - 1) / a.lanes_per_wave) * n_legs;  // leg-pure waves
     if (opt && opt->reserved[2] == 1) {  // leg-interleaved: |W| consecutive chains per wave
@@ -1181,7 +1223,8 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
     if (grid64 > 0x7fffffffLL || n_waves > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
     const dim3 pipe_grid((unsigned)n_waves), pipe_blk(256);  // one workgroup (4 stage waves) per group of W chains
-    const bool roomy = n_waves <= 2 * 256;  // at most two workgroups per CU: the 256-register build of the pipeline kernels
+    // at most two workgroups per CU: the 256-register (latency) build of the pipeline kernels, unless switched off (4 / 5)
+    const bool roomy = n_waves <= 2 * 256 && pipe_opt != 4 && pipe_opt != 5;
     // stage hand-off workspace: the frame after the active links of stage k is the prefix of stage k + 1
     a.frames = nullptr;
     static const bool pool_workspace = getenv("SEQIK_WORKSPACE_POOL") != nullptr;  // diagnosis only (see Workspace)
@@ -1406,7 +1449,13 @@ int seqik_device_attributes(int32_t device, int32_t *compute_units, int32_t *clo
 // used by the other translation units of the library (seqik_head.hip)
 void seqik_set_error(int code, const char *msg) { (void)fail(code, "%s", msg); }
 
-int seqik_check_faults(void) { return check_faults("seqik_check_faults"); }
+int seqik_check_faults(void) { return check_faults("seqik_check_faults", -1); }
+
+int seqik_check_faults_stream(void *hip_stream)
+{
+    if (!g_fault_host.load(std::memory_order_acquire)) return SEQIK_OK;  // nothing has been launched yet
+    return check_faults("seqik_check_faults_stream", fault_slot(static_cast<hipStream_t>(hip_stream)));
+}
 
 int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage)
 {
@@ -1434,8 +1483,10 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     int rc = check_args(n_seq, n_legs, n_frames, legs, first_stage, last_stage, d_pose, d_angles);
     if (rc != SEQIK_OK) return rc;
     // asynchronous: a fault of THIS launch cannot be known yet; one an earlier launch left behind is reported now
-    if ((rc = check_faults("seqik_solve_seq_device (fault of an earlier launch)")) != SEQIK_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    if (g_fault_host.load(std::memory_order_acquire) &&
+        (rc = check_faults("seqik_solve_seq_device (fault of an earlier launch on this stream)", fault_slot(stream))) != SEQIK_OK)
+        return rc;
     const seqik::LegConst *d_legs = nullptr;
     rc = device_leg_table(legs, affine, n_legs, &d_legs);
     if (rc != SEQIK_OK) return rc;
@@ -1631,7 +1682,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipStreamSynchronize(stream));
-    return check_faults("seqik_solve_seq");
+    return check_faults("seqik_solve_seq", fault_slot(stream));
 }
 
 // Self-test hook of the floating-point contract: q[i] = div_(a[i], b[i]), r[i] = sqrt_(a[i]) on the device.

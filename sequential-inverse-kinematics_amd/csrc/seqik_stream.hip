@@ -280,7 +280,13 @@ int seqik_stream_wait(SeqikStream *s)
     STRY(scope.enter(s->device));
     for (Slot &q : s->slots)
         if (q.in_flight) { STRY(hipEventSynchronize(q.done)); q.in_flight = false; }
-    return seqik_check_faults();  // every slab is back: a watchdog fault in one of them must not pass silently
+    // every slab is back: a watchdog fault in one of them must not pass silently (this pipeline's own streams only)
+    int rc = SEQIK_OK;
+    for (int i = 0; i < s->n_compute; ++i) {
+        const int r = seqik_check_faults_stream(s->compute[i]);
+        if (r != SEQIK_OK) rc = r;
+    }
+    return rc;
 }
 
 int seqik_stream_reset_carry(SeqikStream *s)

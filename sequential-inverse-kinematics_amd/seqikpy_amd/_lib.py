@@ -48,7 +48,7 @@ class SeqikOptions(ctypes.Structure):
                 ("chunk_resume", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 N_CHUNK_STATS = 16
 CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
                       "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check",
@@ -87,10 +87,13 @@ def selftest_sqrt_pos(a):
     return r
 
 
-def check_faults():
-    """``seqik_check_faults``: raises ``SeqikLibraryError`` when a kernel launched through the asynchronous device entry
-    points reported a fault (the stage pipeline's watchdog) since the last check.  Call it after synchronising."""
-    rc = load().seqik_check_faults()
+def check_faults(stream=None):
+    """``seqik_check_faults`` / ``seqik_check_faults_stream``: raises ``SeqikLibraryError`` when a kernel launched through
+    the asynchronous device entry points reported a fault (the stage pipeline's watchdog) since the last check.  Call it
+    after synchronising.  ``stream=None``: every stream of the process (single-threaded callers); ``stream=<hipStream_t as
+    int>`` (0 = the default stream): the launches made on that stream of the current device only -- what a host thread
+    that shares the process with other threads' GPUs / streams uses (ABI 6)."""
+    rc = load().seqik_check_faults() if stream is None else load().seqik_check_faults_stream(ctypes.c_void_p(int(stream)))
     if rc != SEQIK_OK:
         _raise(rc)
 
@@ -267,6 +270,8 @@ def load():
         L.seqik_selftest_sqrt_pos.argtypes = [_dp, _dp, ctypes.c_int64]
         L.seqik_check_faults.restype = ctypes.c_int
         L.seqik_check_faults.argtypes = []
+        L.seqik_check_faults_stream.restype = ctypes.c_int
+        L.seqik_check_faults_stream.argtypes = [ctypes.c_void_p]
         L.seqik_frame_chunk_plan.restype = ctypes.c_int
         L.seqik_frame_chunk_plan.argtypes = [ctypes.c_int64, ctypes.POINTER(SeqikOptions), _ip, _ip,
                                              ctypes.POINTER(ctypes.c_int64)]
@@ -337,7 +342,7 @@ def load():
 
 
 EXPORTED_SYMBOLS = ["seqik_abi_version", "seqik_device_count", "seqik_last_error", "seqik_device_attributes", "seqik_release_workspaces",
-                    "seqik_validate_legs", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_selftest_sqrt_pos", "seqik_check_faults",
+                    "seqik_validate_legs", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_selftest_sqrt_pos", "seqik_check_faults", "seqik_check_faults_stream",
                     "seqik_peer_alloc", "seqik_peer_free", "seqik_peer_export", "seqik_peer_open", "seqik_peer_close",
                     "seqik_peer_copy",
                     "seqik_solve_seq", "seqik_solve_seq_device", "seqik_head_angles", "seqik_head_angles_device",

@@ -111,8 +111,20 @@ class DeviceSlab:
             raise RuntimeError("a serially walked slab cannot be resumed")
         self._left = left_state.to(self.dev).contiguous()
         self._call(d_init=self._left.data_ptr(), resume=2 if exact else 1)
-        st = self.d_stats.cpu().numpy()
+        st = self.d_stats.cpu().numpy()      # blocking read: the speculative pass and this resume call have finished
+        self._check_stream_faults()
         self.repaired += int(st[3:7].sum())
+
+    def _check_stream_faults(self):
+        with self.torch.cuda.device(self.dev):
+            _lib.check_faults(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def check_faults(self):
+        """The launches of this slab go through the asynchronous device entry point, which cannot report a watchdog fault
+        of its own launch (include/seqik.h, "Device faults"): synchronise the slab's stream and raise if one of them did.
+        Called wherever a slab's results leave the GPU (``solve_frame_sharded``, ``stream_recording_sharded``)."""
+        self.torch.cuda.current_stream(self.dev).synchronize()
+        self._check_stream_faults()
 
     def end_state(self):
         return self.d_ang[:, :, :, self.n - 1].contiguous()
@@ -216,6 +228,12 @@ class FrameShardedRecording:
         return dict(angles=self._gather(lambda s: s.angles(), (7,)),
                     fk=self._gather(lambda s: s.fk(), (9, 3)) if (self.want_fk and gather_fk) else None)
 
+    def check_faults(self):
+        """Synchronises this rank's slab and raises ``SeqikLibraryError`` if one of its launches reported a kernel fault
+        (``solve()`` is asynchronous on the GPU; call this before trusting what it returned)."""
+        if self.slab is not None and hasattr(self.slab, "check_faults"):
+            self.slab.check_faults()
+
     def _gather(self, get, tail):
         """(S, L, n_r, ...) per rank -> (S, L, N, ...) on every rank: one padded all-gather along the frame axis."""
         torch, dist = self.torch, self.dist
@@ -243,6 +261,7 @@ def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: Optional[int] = Non
     ``torch.distributed`` process group when there is more than one rank ("nccl" = RCCL on the GPUs, "gloo" in tests)."""
     rec = FrameShardedRecording(pose, legs, chunk, halo, tol, want_fk, affine, device, group, slab_factory)
     out = rec.solve()
+    rec.check_faults()
     if stats is not None:
         stats.update(rec.stats)
         if rec.slab is not None and hasattr(rec.slab, "chunk_stats"):

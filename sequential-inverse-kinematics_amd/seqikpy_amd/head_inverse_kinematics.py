@@ -103,12 +103,22 @@ class HeadInverseKinematics:
         """``row`` repeated ``n_row`` times."""
         return np.tile(row, (n_row, 1))
 
-    def derotate_vector(self, head_roll_angle: float, vector_to_derotate: np.ndarray) -> np.ndarray:
+    def derotate_vector(self, head_roll_angle, vector_to_derotate: np.ndarray) -> np.ndarray:
         """``vector_to_derotate`` ((3,) or (M, 3)) rotated about the x axis by ``-head_roll_angle`` (:330-335; the
-        kernel does this in registers for the antenna angles -- this is the stand-alone helper)."""
-        c, s_ = np.cos(head_roll_angle), np.sin(head_roll_angle)
-        rot = np.array([[1.0, 0.0, 0.0], [0.0, c, s_], [0.0, -s_, c]])
-        return np.asarray(vector_to_derotate, dtype=np.float64) @ rot.T
+        kernel does this in registers for the antenna angles -- this is the stand-alone helper).  The angle may be a
+        scalar (one rotation for every row) or an (M,) array (one rotation per row), as ``Rotation.from_euler`` /
+        ``Rotation.apply`` broadcast in the reference, whose own callers pass ``(N,)`` angles with ``(N, 3)`` vectors
+        (:253, :290)."""
+        a = np.asarray(head_roll_angle, dtype=np.float64)
+        v = np.asarray(vector_to_derotate, dtype=np.float64)
+        if a.ndim > 1 or v.ndim > 2 or v.shape[-1] != 3:
+            raise ValueError(f"derotate_vector: angle {a.shape} / vector {v.shape}: expected () or (M,) and (3,) or (M, 3)")
+        if a.ndim == 1 and v.ndim == 2 and a.shape[0] not in (1, v.shape[0]):
+            raise ValueError(f"derotate_vector: {a.shape[0]} angles for {v.shape[0]} vectors")
+        c, s_ = np.cos(a), np.sin(a)
+        out = np.stack(np.broadcast_arrays(v[..., 0] + 0.0 * c, c * v[..., 1] + s_ * v[..., 2],
+                                           -s_ * v[..., 1] + c * v[..., 2]), axis=-1)
+        return out
 
     # ---- per-quantity methods (:163-307), each one launch of the head kernel --------------------------------------------
     @staticmethod

@@ -131,7 +131,8 @@ def stream_recording_sharded(get_slab: Callable[[int], np.ndarray], get_out: Cal
         rounds += 1
         if rounds > world:
             raise RuntimeError("sharded stream did not converge")
-    if first is not None:   # the settled first slab goes to the host
+    if first is not None:   # the settled first slab goes to the host -- not before its launches are known to be clean
+        first.check_faults()
         a, f = get_out(k0)
         torch.from_numpy(a).copy_(first.d_ang[:, :, :, first.lead:])
         if want_fk:

@@ -29,7 +29,7 @@ def test_header_declares_expected_entry_points():
                                            "seqik_solve_generic_device",
                                            "seqik_host_alloc", "seqik_host_free", "seqik_host_register",
                                            "seqik_host_unregister", "seqik_frame_chunk_plan", "seqik_selftest_div_sqrt", "seqik_selftest_sqrt_pos",
-                                           "seqik_check_faults", "seqik_stream_open", "seqik_stream_submit",
+                                           "seqik_check_faults", "seqik_check_faults_stream", "seqik_stream_open", "seqik_stream_submit",
                                            "seqik_stream_wait", "seqik_stream_reset_carry", "seqik_stream_set_carry", "seqik_stream_close",
                                            "seqik_align_stats_open", "seqik_align_stats_add", "seqik_align_stats_finish",
                                            "seqik_align_stats_reset", "seqik_align_stats_close"])
@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 5 == hiplib.ABI_VERSION
+    assert lib.seqik_abi_version() == 6 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):

@@ -154,3 +154,44 @@ def test_generic_on_gpu(hiplib, oracle):
     assert np.abs(ik.calculate_fk(chain, x)[8] - (z["RF_pose"][0, 4] - z["RF_pose"][0, 0])).max() < 1e-6
     fk1 = ik.calculate_ik_stage(z["RF_pose"][:, 4], z["RF_pose"][:, 0], INITIAL_ANGLES["RF"]["stage_4"], "RF")
     assert np.array_equal(fk1, fk["RF_leg"])
+
+
+def test_woodbury_form_1_is_as_well_conditioned_as_form_0(oracle):
+    """form 1 of the 3 x 3 push-through step (oracle woodbury_phi; kernel seqik_generic.hpp woodbury_phi) gets
+    phi' from a DIFFERENCE s1 - s2 that cancels when diag_h + alpha is small (W large).  Kernel and oracle moved together,
+    so kernel == oracle cannot see a conditioning regression; form 0 (two general solves, no such difference) is still in
+    the oracle (`set_variant(woodbury_form=0)`).  Over the full shipped 6000-frame recording and over a variant whose
+    limits are tightened until the solver rides them most of the time (tiny Coleman-Li distances = tiny diag_h + alpha),
+    form 1 must need no more evaluations, reach the claw as well, and stop for the same reasons as form 0.  (HIP == oracle
+    form 1 bit for bit: test_generic_on_gpu, tests/tools/soak_generic.py.)"""
+    z = load_golden("anipose_shipped")
+    pose, seg, b, seeds = z["RF_pose"], z["RF_seg"], z["RF_bounds"], z["RF_seeds"][18:27]
+
+    def run(form, bounds, seed):
+        oracle.set_variant(woodbury_form=form)
+        try:
+            return oracle.generic_leg(pose, seg, bounds, seed)
+        finally:
+            oracle.reset_variants()
+
+    def residual(r):
+        return np.linalg.norm(r["fk"][:, 8] - pose[:, 4], axis=1)
+
+    f1, f0 = run(1, b, seeds), run(0, b, seeds)
+    assert f1["nfev"].sum() < 1.05 * f0["nfev"].sum(), (f1["nfev"].sum(), f0["nfev"].sum())
+    assert f1["nfev"].max() < 2 * f0["nfev"].max()
+    assert residual(f1).max() < 1e-6 and residual(f0).max() < 1e-6
+    assert abs((f1["status"] == 1).mean() - (f0["status"] == 1).mean()) < 0.05
+    assert set(np.unique(f1["status"])) <= {1, 2, 3, 4}
+    # near the limits: every joint confined to the central 40 % of the range it actually used
+    lo, hi = np.quantile(f1["angles"], 0.3, axis=0), np.quantile(f1["angles"], 0.7, axis=0)
+    tight = np.stack([np.maximum(lo, b[:, 0]), np.minimum(hi, b[:, 1])], axis=1)
+    seed_t = seeds.copy()
+    order = [2, 0, 1, 3, 4, 5, 6]                      # generic link order: roll, yaw, pitch, CTr_pitch, CTr_roll, FTi, TiTa
+    seed_t[1:8] = 0.5 * (tight[order, 0] + tight[order, 1])
+    t1, t0 = run(1, tight, seed_t), run(0, tight, seed_t)
+    on_limit = ((t1["angles"] - tight[:, 0] < 1e-9) | (tight[:, 1] - t1["angles"] < 1e-9)).any(axis=1).mean()
+    assert on_limit > 0.5, on_limit                                     # the case really is "riding the limits"
+    assert t1["nfev"].sum() < 1.10 * t0["nfev"].sum(), (t1["nfev"].sum(), t0["nfev"].sum())
+    assert np.mean(residual(t1)) < 1.02 * np.mean(residual(t0)) + 1e-9   # the constrained optimum is found as well
+    assert abs((t1["status"] == 1).mean() - (t0["status"] == 1).mean()) < 0.1

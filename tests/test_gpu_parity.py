@@ -663,3 +663,81 @@ print("SERIAL OK" if np.isfinite(out["angles"]).all() else "SERIAL BAD")
     params = [lib.leg_params_from_arrays(*leg_arrays(z, l)[1:]) for l in legs]
     assert np.isfinite(lib.solve_seq(pose, params, pipeline=2)["angles"]).all()
     lib.check_faults()
+
+
+def test_latency_build_of_the_pipeline_equals_the_plain_build(lib):
+    """the 256-register LATENCY build of the stage pipeline (run_stage<..., LAT>: Jacobian, gradient, scaling
+    carried in registers across rejected trials behind a wave-uniform gate, branch-free reflective step) exists only in the
+    WPE == 2 pipeline kernels, which the host harness cannot instantiate.  SeqikOptions.reserved[3] = 4 / 5 runs the same
+    call on the plain instantiation: bit equality on the shipped 6000-frame recordings (RF + LF: 2 chains) and on the six
+    legs of the locomotion recording, lane pairs on (2 vs 4) and off (3 vs 5), against the lane-per-chain kernels, and on
+    the frame-chunk path, whose speculative and repair kernels have their own LAT instantiations."""
+    for name, legs in (("anipose_shipped", ["RF", "LF"]), ("df3d_1000", None)):
+        z = load_golden(name)
+        legs = legs or [str(l) for l in z["legs"]]
+        pose, params = _stack(z, legs), _params(lib, z, legs)
+        serial = lib.solve_seq(pose, params, want_fk=True, pipeline=1)
+        runs = {p: lib.solve_seq(pose, params, want_fk=True, pipeline=p) for p in (2, 3, 4, 5)}
+        for p, out in runs.items():
+            assert np.array_equal(out["angles"], serial["angles"]), (name, p)
+            assert np.array_equal(out["fk"], serial["fk"]), (name, p)
+        chunk_lat = lib.solve_seq(pose, params, want_fk=True, frame_chunk=-1, pipeline=2)
+        chunk_plain = lib.solve_seq(pose, params, want_fk=True, frame_chunk=-1, pipeline=4)
+        assert np.array_equal(chunk_lat["angles"], chunk_plain["angles"]) and np.array_equal(chunk_lat["fk"], chunk_plain["fk"])
+        assert chunk_lat["chunk_stats"] == chunk_plain["chunk_stats"]
+    # replicated thin waves with several chains per wave (lanes 2..16), both builds
+    z = load_golden("df3d_100")
+    legs = [str(l) for l in z["legs"]]
+    many = np.concatenate([_stack(z, legs)] * 40)                      # 240 chains of 100 frames
+    params = _params(lib, z, legs)
+    want = lib.solve_seq(many, params, want_fk=False, pipeline=1)["angles"]
+    for lanes in (2, 5, 16):
+        for p in (2, 4):
+            got = lib.solve_seq(many, params, want_fk=False, pipeline=p, lanes_per_wave=lanes)["angles"]
+            assert np.array_equal(got, want), (lanes, p)
+
+
+def test_fault_words_are_per_stream(lib):
+    """ADVICE r4 / ABI 6: a watchdog fault is reported to the word of the (device, stream) the launch was made on, so a host
+    thread that enters the library on ANOTHER stream neither sees nor clears it.  Diagnostic build (watchdog limit of one
+    pass), child process: a piped launch on stream A faults; a launch on stream B is accepted (ABI 5 refused it and cleared
+    A's fault); check_faults(B) is clean; check_faults(A) raises; afterwards everything is clean."""
+    from seqikpy_amd import _lib
+    if not os.path.exists(_lib.WATCHDOG_LIB_PATH):
+        _lib.build_watchdog_variant()
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from seqikpy_amd import _lib
+z = np.load(%r)
+legs = [str(l) for l in z["legs"]]
+pose = np.stack([z[f"{l}_pose"][:40] for l in legs])[None]
+params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+d_pose = torch.from_numpy(pose).cuda()
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+a_ang = torch.zeros((1, len(legs), 40, 7), dtype=torch.float64, device="cuda")
+b_ang = torch.zeros_like(a_ang)
+torch.cuda.synchronize()
+_lib.solve_seq_device(d_pose.data_ptr(), 1, len(legs), 40, params, a_ang.data_ptr(), pipeline=2, stream=sa.cuda_stream)
+sa.synchronize()
+print("A NAN" if bool(torch.isnan(a_ang).any()) else "A CLEAN")
+_lib.solve_seq_device(d_pose.data_ptr(), 1, len(legs), 40, params, b_ang.data_ptr(), pipeline=1, stream=sb.cuda_stream)
+sb.synchronize()
+print("B ACCEPTED", "B FINITE" if bool(torch.isfinite(b_ang).all()) else "B BAD")
+_lib.check_faults(sb.cuda_stream)
+print("B NO FAULT")
+try:
+    _lib.check_faults(sa.cuda_stream)
+    print("A: no error")
+except _lib.SeqikLibraryError as e:
+    print("A:", e)
+_lib.check_faults(sa.cuda_stream); _lib.check_faults()
+print("ALL CLEAR")
+''' % (PKG_PARENT, ROOT, os.path.join(GOLDEN, "df3d_100.npz"))
+    env = dict(os.environ, SEQIK_LIB=_lib.WATCHDOG_LIB_PATH)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "A NAN" in out and "B ACCEPTED B FINITE" in out and "B NO FAULT" in out, out
+    assert "A: seqik: HIP error: seqik_check_faults_stream: stage pipeline watchdog" in out, out
+    assert "ALL CLEAR" in out, out

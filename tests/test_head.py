@@ -208,3 +208,25 @@ def test_head_kernel_streaming_rate_and_linearity(z, hiplib):
     assert rc == 0
     torch.cuda.synchronize()
     assert torch.equal(out3[:3], out[:3, :m]) and bool((out3[3:] == 7.0).all())
+
+
+def test_derotate_vector_broadcasts_like_the_reference():
+    """the reference's own callers hand `derotate_vector` an (N,) roll with an (N, 3) vector through
+    np.vectorize(signature="(m),(m,n)->(m,n)") (head_inverse_kinematics.py:253, :290), and Rotation.from_euler builds one
+    rotation per row.  Scalar / (3,), scalar / (M, 3) and (M,) / (M, 3) all against scipy's Rotation (host helper: no GPU)."""
+    from scipy.spatial.transform import Rotation
+    from seqikpy_amd.head_inverse_kinematics import HeadInverseKinematics
+    hk = object.__new__(HeadInverseKinematics)      # the helper uses no state of the object
+    rng = np.random.default_rng(11)
+    v = rng.normal(size=(40, 3))
+    roll = rng.uniform(-3.0, 3.0, size=40)
+    assert np.abs(hk.derotate_vector(0.4, v[0]) - Rotation.from_euler("x", -0.4).apply(v[0])).max() < 1e-15
+    assert hk.derotate_vector(0.4, v[0]).shape == (3,)
+    assert np.abs(hk.derotate_vector(0.4, v) - Rotation.from_euler("x", -0.4).apply(v)).max() < 1e-15
+    got = hk.derotate_vector(roll, v)
+    assert got.shape == (40, 3) and np.abs(got - Rotation.from_euler("x", -roll).apply(v)).max() < 1e-15
+    vec = np.vectorize(hk.derotate_vector, signature="(m),(m,n)->(m,n)")     # exactly how the reference calls it
+    assert np.array_equal(vec(roll, v), got)
+    assert np.abs(hk.derotate_vector(roll, v[0]) - Rotation.from_euler("x", -roll).apply(v[0])).max() < 1e-15
+    with pytest.raises(ValueError):
+        hk.derotate_vector(roll[:7], v)
