@@ -10,11 +10,13 @@ rank 0's JSON line and exits with the child's code (launch_ranks_if_needed below
 Metric (BASELINE.json): leg-IK solves/s, one solve = one (frame, leg) = 4 stage sub-solves ->
 7 joint angles (+ the stage-4 forward kinematics); and max |d theta| vs the reference (`parity`).
 
-Workload: BASELINE config 3, "synthetic 1M frames x 6 legs, random in-workspace target key points".
-  --scaling weak   (default) 1,000,000 frames PER GPU, cut into 15,625 independent sequences of 64 frames (frame t
-                   of a sequence is warm-started from frame t-1, frame 0 from the seeds -- the reference's semantics
-                   applied to many recordings), 6 legs each = 93,750 chains per GPU
-  --scaling strong config 3 literally: 1,000,000 frames IN TOTAL, rank r solves sequences [r S/N, (r+1) S/N)
+Workload: BASELINE config 3, "synthetic 1M frames x 6 legs, random in-workspace target key points, 1 -> 8 MI355X
+frame-sharded": ONE fixed problem.
+  --scaling strong (default) config 3 literally: 1,000,000 frames IN TOTAL, cut into 15,625 independent sequences of 64
+                   frames (frame t of a sequence is warm-started from frame t-1, frame 0 from the seeds -- the reference's
+                   semantics applied to many recordings), 6 legs each = 93,750 chains; rank r solves sequences
+                   [r S/N, (r+1) S/N).  At N = 1 strong and weak are the same run.
+  --scaling weak   1,000,000 frames PER GPU (a named leg of the N > 1 line either way: `multi_gpu.weak`)
 A step is one pass of the hot path (one launch in which every wave takes its chains through stages 1-4;
 `--staged`: the 4 stage kernels) over the rank's batch with inputs resident in HBM; consecutive steps overlap on
 `--streams` HIP streams.  For N > 1 every step also sends the rank's joint angles to rank 0 (copy-engine peer writes
@@ -37,10 +39,14 @@ HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figure
                      fixture, chunk statistics, latency_floor_frac), 4 with the head / antenna angles in the same
                      submission, 3 = the headline, 5 streamed from pinned host slabs with the alignment fused
                      (PCIe-inclusive, checked), and the generic chain on the shipped 6000-frame recording
-and, at N > 1, `multi_gpu`:
+and, at N > 1, `multi_gpu` (every leg with its per-rank ms, the gather it used and `efficiency_vs_n1`):
   ranks_seen, rank_ms_per_step   who took part (rank, host, device from the process group) and how even the ranks were
+  n1_reference       the WHOLE fixed problem on rank 0's GPU alone, same run, same pipeline (the other ranks wait): what
+                     `efficiency_vs_n1` = value / (N x that) of the headline and of the weak leg is measured against
   gather_compare     the same batch with the angle gather as peer writes, as grouped RCCL point-to-point, and without
-  strong | weak      the other scaling mode, a short run beside the headline (strong = config 3 literally)
+  weak | strong      the other scaling mode, a short run beside the headline
+  one_recording      config 3 as ONE recording of 1M frames, truly frame-sharded (contiguous frame slabs, boundary repair),
+                     with its own one-GPU reference (`n1_reference_ms`)
 """
 import argparse
 import json
@@ -129,7 +135,8 @@ BYTES_PATH = 120 + 56 + 216   # key points in, 7 angles out, 9x3 FK out
 BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 + 24, 4: 48 + 96 + 8 + 144}
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
-TRAFFIC_ROUNDS = ("r04", "r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
+TRAFFIC_ROUNDS = ("r05", "r04", "r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
+LATENCY_ROUND = "r05"     # profiles/<round>_latency_floor.json (scripts/latency_floor.py)
 LF_WINDOW = (284, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
@@ -140,8 +147,9 @@ def parse():
     # edge still costs 5 % (20 steps 4.11e8, 400 steps 4.30e8, 1500 steps 4.31e8 solves/s)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: --frames per GPU; strong: --frames in total, split over the ranks (BASELINE config 3 literally)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): --frames in total, split over the ranks (BASELINE config 3 literally: ONE fixed problem); "
+                         "weak: --frames per GPU.  The same run at N = 1; the other mode is a named leg of the N > 1 line")
     ap.add_argument("--frames", type=int, default=1_000_000, help="frames (x 6 legs) per GPU (weak) or in total (strong)")
     ap.add_argument("--frames-per-seq", type=int, default=64)
     ap.add_argument("--variant", default="iid", choices=["iid", "smooth"])
@@ -410,7 +418,7 @@ def measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step):
     ones (~2.7).  None when the files are absent."""
     try:
         costs = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue_costs.json")))["classes"]
-        isa_path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_fused_isa.json") for r in ("r04", "r03")) if os.path.exists(p))
+        isa_path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_fused_isa.json") for r in ("r05", "r04", "r03")) if os.path.exists(p))
         isa = json.load(open(isa_path))["kernels"]["fused_kernel<fk=1>"]
         share4 = isa["valu_not_f64_arith_issue_split"]["share_about_4.2_cycles"]
     except (OSError, KeyError, ValueError, StopIteration):
@@ -544,16 +552,101 @@ def best_ms(fn, reps=5):
 
 
 def latency_floor(kernel_key):
-    """Committed PMC-derived issue floor of a latency-bound kernel (profiles/r04_latency_floor.json, written by
+    """Committed PMC-derived issue floor of a latency-bound kernel (profiles/r05_latency_floor.json, written by
     scripts/latency_floor.py from rocprofv3 --pmc / --kernel-trace runs): the VALU instructions ONE wavefront issues per
     frame on the critical path, priced at the lone-wavefront issue cost per class.  None when absent / another build."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r04_latency_floor.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", f"{LATENCY_ROUND}_latency_floor.json")))
     except (OSError, ValueError):
         return None
     if j.get("csrc_sha256") != _lib.csrc_sha256(_lib.LATENCY_SOURCES):
         return None
     return j.get(kernel_key)
+
+
+def share_floor(n):
+    """Committed issue floor of the lone 1/n share of the fixed problem (profiles/r05_latency_floor.json `strong_share_<n>`,
+    scripts/latency_floor.py: the instruction stream of the critical stage's wavefront at the lone-wavefront issue rate).
+    None when absent or measured on other kernel sources."""
+    fl = latency_floor(f"strong_share_{n}")
+    if not fl:
+        return None
+    return {"issue_floor_ms": fl["issue_floor_ms"], "source": "profiles/%s_latency_floor.json (%s)" % (LATENCY_ROUND, fl.get("kernel", ""))}
+
+
+def generic_batches(za, frames=32, sizes=(32768, 262144)):
+    """Batches of generic chains (`LegInvKinGeneric` over many recordings: seqikpy/leg_inverse_kinematics.py:545-613 once
+    per recording in the reference): windows of `frames` frames of the shipped 6000-frame recording, legs RF + LF, one lane
+    per chain, device-resident, 7 angles + FK.  For every size the static launch (a wavefront owns 64 chains and lives as
+    long as its slowest lane) against the chain queue (persistent wavefronts, one per SIMD; a lane that has finished its
+    chain takes the next one of its leg) -- same bits, checked -- with the pass counts that explain the difference (from a
+    diagnostics run: nfev per frame).  The library's automatic choice is the queue from two chains per GPU lane on."""
+    import ctypes
+    legs = ["RF", "LF"]
+    params = [_lib.leg_params_from_arrays(za[f"{l}_seg"], za[f"{l}_bounds"], za[f"{l}_seeds"]) for l in legs]
+    arr = (_lib.SeqikLegParams * 2)(*params)
+    d_rec = torch.from_numpy(np.stack([za[f"{l}_pose"] for l in legs])).cuda()                     # (2, 6000, 5, 3)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    n_cu = _lib.device_attributes(torch.cuda.current_device())[0]
+    res = {"workload": f"windows of {frames} frames of the shipped recording (offsets 11 s mod {6000 - frames}), legs RF + LF, "
+                       "generic chain, one lane per chain; leg_frames_per_s of the faster launch at the largest size is the figure",
+           "gpu_lanes_for_this_kernel": n_cu * 4 * 64, "sizes": {}}
+    for S in sizes:
+        offs = (torch.arange(S, device="cuda") * 11) % (6000 - frames)
+        idx = offs[:, None] + torch.arange(frames, device="cuda")[None, :]
+        d_pose = d_rec[:, idx].permute(1, 0, 2, 3, 4).contiguous()                                  # (S, 2, T, 5, 3)
+        d_ang = torch.zeros((S, 2, frames, 7), dtype=torch.float64, device="cuda")
+        d_fk = torch.zeros((S, 2, frames, 9, 3), dtype=torch.float64, device="cuda")
+        d_st = torch.zeros((S, 2, frames), dtype=torch.int32, device="cuda")
+        d_nf = torch.zeros((S, 2, frames), dtype=torch.int32, device="cuda")
+
+        def run(queue, diag=False):
+            opt = _lib.SeqikOptions()
+            opt.reserved[1] = queue
+            rc = lib.seqik_solve_generic_device(d_pose.data_ptr(), S, 2, frames, arr, d_ang.data_ptr(), d_fk.data_ptr(),
+                                                d_st.data_ptr() if diag else None, d_nf.data_ptr() if diag else None,
+                                                None, None, None, ctypes.byref(opt), stream)
+            if rc != 0:
+                raise RuntimeError("seqik_solve_generic_device failed")
+
+        row = {"sequences": S, "chains": 2 * S, "frames": frames, "leg_frames": 2 * S * frames,
+               "chains_per_gpu_lane": 2 * S / (n_cu * 4 * 64.0)}
+        keep, best = {}, {}
+        variants = (("static", 1), ("queue", 2), ("automatic", 0))
+        for name, q in variants:           # warm-up + the results of every variant
+            run(q)
+            torch.cuda.synchronize()
+            keep[name] = (d_ang.clone(), d_fk.clone())
+            best[name] = float("inf")
+        for _ in range(3):                 # variants interleaved: the first launches after a pause run slower
+            for name, q in variants:
+                t0 = time.perf_counter()
+                run(q)
+                torch.cuda.synchronize()
+                best[name] = min(best[name], time.perf_counter() - t0)
+        for name, _ in variants:
+            row[name] = {"ms": best[name] * 1e3, "leg_frames_per_s": 2 * S * frames / best[name]}
+        row["queue_equals_static_bit_for_bit"] = bool(torch.equal(keep["static"][0], keep["queue"][0]) and
+                                                      torch.equal(keep["static"][1], keep["queue"][1]) and
+                                                      torch.equal(keep["static"][0], keep["automatic"][0]))
+        row["queue_speedup_over_static"] = row["static"]["ms"] / row["queue"]["ms"]
+        run(1, diag=True)
+        torch.cuda.synchronize()
+        passes = (d_nf - 1 + (d_st == 1).int()).sum(2)                                               # (S, 2) passes per chain
+        pad = (-S) % 64
+        wave = torch.stack([torch.nn.functional.pad(passes[:, l], (0, pad)).reshape(-1, 64).max(1).values for l in range(2)])
+        row["passes"] = {"mean_lane": float(passes.float().mean().item()), "mean_wavefront_static": float(wave.float().mean().item()),
+                         "slowest_wavefront_static": int(wave.max().item()), "slowest_chain": int(passes.max().item())}
+        res["sizes"][str(2 * S)] = row
+        del d_pose, d_ang, d_fk, d_st, d_nf, keep
+        torch.cuda.empty_cache()
+    big = res["sizes"][str(2 * sizes[-1])]
+    res["leg_frames_per_s"] = max(big["queue"]["leg_frames_per_s"], big["static"]["leg_frames_per_s"])
+    res["queue_speedup_over_static_largest"] = big["queue_speedup_over_static"]
+    res["bound"] = "profiles/r05_generic_queue_bound.json (oracle pass counts, list scheduling): 1.00 / 1.21 / 1.38 / 1.57 at 1 / 2 / 4 / 8 chains per lane"
+    _lib.check_faults()
+    return res
 
 
 def reference_configs(time_box_s=240.0):
@@ -600,7 +693,7 @@ def reference_configs(time_box_s=240.0):
             err = np.abs(a - ref)
             e = {"ms": ms, "leg_frames_per_s": len(legs) * n / ms * 1e3,
                  "max_abs_dtheta_vs_fixture": float(err[ok].max()),
-                 "leg_frames_over_1e-4": int((err.max(-1) > 1e-4)[ok].sum())}
+                 "leg_frames_over_1e-4": int((err.max(-1) > 1e-4)[ok].sum()), **parity_tail(err, ok, legs)}
             if mask_lf and "LF" in legs:
                 e["max_abs_dtheta_incl_lf_window"] = float(err.max())
             if mode:
@@ -693,16 +786,17 @@ def reference_configs(time_box_s=240.0):
         same = bool(np.array_equal(d_out[:, -6000:].cpu().numpy(), small))
         traffic = None
         try:   # committed PMC summary of the same kernel and size (scripts/gpu_head_profile.sh): HBM bytes per frame
-            with open(os.path.join(ROOT, "profiles", "r04_head_profile.json")) as fh:
+            hp = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_head_profile.json") for r in ("r05", "r04")) if os.path.exists(p))
+            with open(hp) as fh:
                 traffic = json.load(fh)["traffic_bytes_per_frame"] * n_h
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
         e4["head_kernel"] = {"kernel": "seqik_head_kernel<true>", "frames": n_h, "launches": k_h, "ms": float(each.mean()),
                              "ms_best": float(each.min()), "frames_per_s": n_h / float(each.mean()) * 1e3,
                              "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
                                           "frac": round(gbps / 8000.0, 3), "algorithmic_bytes_per_frame": 152,
                                           "traffic": traffic,
-                                          "traffic_source": "profiles/r04_head_profile.json (FETCH_SIZE doubled for 16-byte-per-"
+                                          "traffic_source": "profiles/r0N_head_profile.json, newest (FETCH_SIZE doubled for 16-byte-per-"
                                                             "lane streaming loads as the guide prescribes, + WRITE_SIZE)"},
                              "equals_the_6000_frame_call_tiled": same}
         del d_r, d_l, d_out
@@ -738,6 +832,11 @@ def reference_configs(time_box_s=240.0):
         "parity_note": "7 unknowns, 3 equations: the reference's angles are not reproducible by the reference itself "
                        "(profiles/r04_perturbation_generic.json: real scipy vs real scipy + 1 ulp), so the claw, the limits and "
                        "the smoothness of the joint series are what can be pinned; HIP == C restatement bit for bit (tests)"}
+    # ---- BATCHES of generic chains: the chain queue (persistent wavefronts, lanes pull chains) against the static launch
+    try:
+        out["generic"]["batch"] = generic_batches(za)
+    except Exception as exc:  # noqa: BLE001
+        out["generic"]["batch"] = {"error": f"{type(exc).__name__}: {exc}"}
     # ---- latency floors of the two latency-bound kernels (item: "latency-bound" as a number) -------------------------
     for entry, kernel_key, live_ms in ((out["4"], "config4_serial_walk", out["4"]["default"]["ms"]),
                                        (out["generic"], "generic_rf_6000", out["generic"]["ms"])):
@@ -746,7 +845,7 @@ def reference_configs(time_box_s=240.0):
             keep = ("kernel", "issue_floor_ms", "latency_floor_frac", "critical_stage", "kernel_ms", "kernel_ms_lane_pairs_on",
                     "kernel_ms_lane_pairs_off", "valu_insts_per_frame")
             entry["latency_floor"] = {k: fl[k] for k in keep if k in fl}
-            entry["latency_floor"]["source"] = "profiles/r04_latency_floor.json (rocprofv3 PMC instruction counts of one wavefront x lone-wavefront issue costs)"
+            entry["latency_floor"]["source"] = f"profiles/{LATENCY_ROUND}_latency_floor.json (rocprofv3 PMC instruction counts of one wavefront x lone-wavefront issue costs)"
             # live: the committed floor against THIS run's whole call (upload + kernel + download, host clock)
             entry["latency_floor_frac"] = fl["issue_floor_ms"] / live_ms
     # ---- config 5: streamed from pinned host slabs, alignment fused, PCIe-inclusive ----------------------------------
@@ -850,6 +949,8 @@ def main():
     S_total = args.frames // T
     n_streams = args.streams
 
+    whole = {}   # rank 0 of an N > 1 job keeps the whole fixed problem: the one-GPU reference of the same run
+
     def workload_for(scaling):
         """(pose of this rank, legs, body, params, leg-frames per step over all ranks)"""
         lo, hi, S_job = sharding.rank_share(S_total, world, rank, scaling)
@@ -857,9 +958,13 @@ def main():
             # the fixed problem: S_total sequences, generated identically on every rank, rank r solves its slice
             legs_, body_, pose_all, params_ = make_workload(S_total, T, args.variant, synthetic.SEED_BASE)
             pose_ = pose_all[lo:hi]
+            if rank == 0 and world > 1:
+                whole["pose"] = pose_all
             del pose_all
         else:
             legs_, body_, pose_, params_ = make_workload(S_total, T, args.variant, synthetic.SEED_BASE + 1000 * rank)
+            if rank == 0 and world > 1 and "pose" not in whole:
+                whole["pose"] = pose_       # rank 0's weak batch IS the fixed problem (same seed)
         return pose_, legs_, body_, params_, S_job * len(legs_) * T
 
     pose, legs, body, params, units_all = workload_for(args.scaling)
@@ -1053,7 +1158,33 @@ def main():
                 else:
                     multi[name] = res
 
+            def rank_ms(mine_s, k):
+                """this leg's per-step time of every rank (ms), gathered over the process group"""
+                got = [None] * world
+                dist.all_gather_object(got, mine_s / k * 1e3)
+                return {"min": min(got), "max": max(got), "by_rank": got}
+
             k_cmp = max(4, min(20, args.steps))
+            headline_kind = "peer" if isinstance(gather, peer_gather.PeerWriteGather) else "rccl"
+
+            def leg_n1_reference():
+                # the WHOLE fixed problem (config 3: 1M frames x 6 legs) on rank 0's GPU alone, same pipeline, no gather (one
+                # GPU has nobody to gather from), while the other ranks wait in the leg's consensus all-reduce: what the
+                # scaling efficiencies of THIS run are measured against
+                res = None
+                if rank == 0:
+                    b1 = Batch(whole["pose"], params, args, n_streams)
+                    bufs1 = [b1.angle_buffer() for _ in range(len(b1.streams))]
+                    k1 = max(6, min(30, args.steps))
+                    dt1 = timed_steps(b1, bufs1, k1, len(b1.streams), warmup=3)
+                    res = {"value": b1.units * k1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
+                           "streams": len(b1.streams), "leg_frames_per_step": int(b1.units),
+                           "what": "the whole fixed problem on rank 0's GPU alone (the other ranks idle), same run"}
+                    del b1, bufs1
+                    torch.cuda.empty_cache()
+                got = [None] * world
+                dist.all_gather_object(got, res)
+                return got[0]
 
             def leg_gather_compare():
                 # the final joint-angle gather, both ways, same batch, same process group: copy-engine peer writes into
@@ -1078,25 +1209,43 @@ def main():
                 pose2, _, _, _, units_all2 = workload_for(other_scaling)
                 b2 = Batch(pose2, params, args, n_streams)
                 bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
-                kind = "peer" if isinstance(gather, peer_gather.PeerWriteGather) else "rccl"   # as the headline's
-                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=kind)
+                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=headline_kind)
                 k2 = max(4, min(40, args.steps))
-                tm, _ = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
+                tm, mine2 = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
                 res = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
                        "steps": k2, "scaling": other_scaling, "sequences_per_gpu": int(pose2.shape[0]),
-                       "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc}
+                       "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc, "rank_ms_per_step": rank_ms(mine2, k2)}
                 if hasattr(g2, "close"):
                     g2.close()
                 return res
 
             def leg_one_recording():
-                # config 3 read literally: ONE recording frame-sharded over the ranks (`--one-recording` runs it alone)
+                # config 3 read literally: ONE recording frame-sharded over the ranks (`--one-recording` runs it alone), and
+                # the same recording on rank 0's GPU alone (frame chunks, no exchange) as its one-GPU reference
                 torch.cuda.empty_cache()
-                return one_recording_leg(dist, world, rank, args.frames, max(3, min(10, args.steps)), 1, coll_dev)
+                res = one_recording_leg(dist, world, rank, args.frames, max(3, min(10, args.steps)), 1, coll_dev)
+                n1 = None
+                if rank == 0:
+                    torch.cuda.empty_cache()
+                    n1 = single_recording(args.frames, steps=4)["ms_per_step"]
+                got = [None] * world
+                dist.all_gather_object(got, n1)
+                res["n1_reference_ms"] = got[0]
+                res["efficiency_vs_n1"] = got[0] / res["ms_per_step"] / world
+                return res
 
+            guarded("n1_reference", leg_n1_reference)
             guarded("gather_compare", leg_gather_compare)
             guarded(other_scaling, leg_other_scaling)
             guarded("one_recording", leg_one_recording)
+            # scaling efficiencies against the one-GPU run of the SAME job in the SAME run: value / (N x value at N = 1)
+            n1 = multi.get("n1_reference")
+            if n1 and "value" in n1:
+                multi["efficiency_vs_n1"] = (units_all * args.steps / elapsed) / (world * n1["value"])
+                multi["speedup_vs_n1"] = (units_all * args.steps / elapsed) / n1["value"]
+                oth = multi.get(other_scaling)
+                if oth and "value" in oth:
+                    oth["efficiency_vs_n1"] = oth["value"] / (world * n1["value"])
 
     if rank == 0:
         out = {
@@ -1107,8 +1256,13 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs per GPU, in-workspace targets" if args.scaling == "weak"
-                                    else "config 3: synthetic 1M frames x 6 legs IN TOTAL, sequences split over the ranks"),
+            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs, in-workspace targets" if world == 1 else
+                                    "config 3 (weak-scaling variant): synthetic 1M frames x 6 legs PER GPU, in-workspace targets"
+                                    if args.scaling == "weak" else
+                                    f"config 3 literally: the FIXED problem of synthetic 1M frames x 6 legs IN TOTAL ({S_total} "
+                                    f"sequences of {T} frames), sequences split over the {world} ranks, joint angles gathered on rank 0"),
+                       "frames_total": S_total * T * (world if args.scaling == "weak" else 1),
+                       "leg_frames_per_step_all_ranks": int(units_all),
                        "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
                        "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
                        "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
@@ -1156,6 +1310,22 @@ def main():
                     if best is None or row["ms_per_step"] < best["ms_per_step"]:
                         best = row
                     del sub, bufs
+                # the floor of a share: ONE launch at a time, no second step to overlap with (what a rank can do at best when
+                # every step has to wait for the one before it)
+                sub = Batch(pose[: S // n], params, args, 1)
+                bufs = [sub.angle_buffer()]
+                k = max(8, min(40, args.steps // 2))
+                dt = timed_steps(sub, bufs, k, 1, warmup=2)
+                best["lone_job_ms"] = dt / k * 1e3
+                best["lone_job_speedup_vs_single_job"] = out["single_job"]["ms_per_step"] / best["lone_job_ms"]
+                best["ideal_ms"] = ms_per_step / n
+                best["efficiency"] = best["speedup_vs_1"] / n
+                fl = share_floor(n)
+                if fl:
+                    best["lone_job_issue_floor_ms"] = fl["issue_floor_ms"]
+                    best["lone_job_issue_floor_frac"] = fl["issue_floor_ms"] / best["lone_job_ms"]
+                    best["floor_source"] = fl["source"]
+                del sub, bufs
                 proj["by_n_gpus"][str(n)] = best
             out["strong_projection"] = proj
             # ---- the other synthetic variant -------------------------------------------------------------------
@@ -1200,9 +1370,43 @@ def main():
                               "restatement bit for bit on sampled chains (tests/test_gpu_parity.py::test_full_size_synthetic_properties); "
                               "against the reference itself see `parity_note` in `config`"})
             _lib.check_faults()   # the device entry points do not synchronise: a kernel fault of any launch above raises here
+            # ---- a handful of scalars at the TOP level of the line: the driver's record keeps top-level scalars only --------
+            def dig(obj, *path):
+                for k in path:
+                    if not isinstance(obj, dict) or k not in obj:
+                        return None
+                    obj = obj[k]
+                return obj
+            cf = out.get("configs", {})
+            par = out["parity"]
+            out.update({
+                "config1_default_ms": dig(cf, "1", "default", "ms"), "config1_auto_ms": dig(cf, "1", "frame_parallel_auto", "ms"),
+                "config2_default_ms": dig(cf, "2", "default", "ms"), "config2_auto_ms": dig(cf, "2", "frame_parallel_auto", "ms"),
+                "config2_64_recordings_leg_frames_per_s": dig(cf, "2", "default_64_recordings_one_call", "leg_frames_per_s"),
+                "config4_default_ms": dig(cf, "4", "default", "ms"), "config4_auto_ms": dig(cf, "4", "frame_parallel_auto", "ms"),
+                "config5_leg_frames_per_s": dig(cf, "5", "one_recording", "value"),
+                "config5_sequences_leg_frames_per_s": dig(cf, "5", "synthetic_sequences", "value"),
+                "generic_6000_frames_s": (dig(cf, "generic", "ms") or 0.0) / 1e3 or None,
+                "generic_batch_leg_frames_per_s": dig(cf, "generic", "batch", "leg_frames_per_s"),
+                "head_kernel_hbm_frac": dig(cf, "4", "head_kernel", "roofline", "frac"),
+                "parity_max_abs_dtheta": max(par[n]["serial_walk"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                "parity_p99.9_abs_dtheta": max(par[n]["serial_walk"]["p99.9_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                "parity_values_over_5e-5": sum(par[n]["serial_walk"]["values_over_5e-5"] for n in ("anipose_shipped", "df3d_1000")),
+                "parity_leg_frames_over_1e-4_outside_lf_window":
+                    sum(par[n]["serial_walk"]["leg_frames_over_1e-4_outside_lf_window"] for n in ("anipose_shipped", "df3d_1000")),
+                "parity_auto_max_abs_dtheta": max(par[n]["frame_chunks"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                "smooth_variant_value": dig(out, "variants", "smooth", "value"),
+                "single_recording_value": dig(out, "single_recording", "value"),
+                "strong_share_n8_ms_per_step": dig(out, "strong_projection", "by_n_gpus", "8", "ms_per_step"),
+                "strong_share_n8_lone_job_ms": dig(out, "strong_projection", "by_n_gpus", "8", "lone_job_ms"),
+                "strong_projected_speedup_n8": dig(out, "strong_projection", "by_n_gpus", "8", "speedup_vs_1"),
+                "roofline_frac": roofline.get("frac"), "roofline_traffic_bytes": roofline.get("traffic"),
+            })
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            out["cpu_baseline_value"] = out["cpu_baseline"]["value"]
+            out["cpu_baseline_cores"] = out["cpu_baseline"]["cores"]
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)

@@ -119,6 +119,30 @@ def main():
                 "trial (run_stage REUSE: stage 1 rejects 32 % / 10 % of its trials on RF / LF), and the product launch (lane pairs "
                 "on) also splits the two joints of a pass over two lanes: they issue fewer instructions than that stream, so their "
                 "fractions are upper estimates of how close they are to THEIR floors"}
+    # ---- the lone 1/8 share of BASELINE config 3 (launches E / F): what ONE rank of an 8-GPU strong-scaling run does per step
+    if "E_share_piped_ms" in run_line:
+        n_seq, n_ch = run_line["share_sequences"], run_line["share_chains"]
+        # the share's dispatches come AFTER config 4's in every CSV: E = the last `reps` pipe launches, F = the last `reps`
+        # launches of every stage kernel
+        e_ms = min(p_ms[-reps:])
+        sh = {}
+        for st in (1, 2, 3, 4):
+            s_sq = per_dispatch(sq, rf"seqik_stage_kernel<{st}, ")
+            s_f = per_dispatch(f64, rf"seqik_stage_kernel<{st}, ")
+            s_ms = trace[trace.Kernel_Name.str.contains(rf"seqik_stage_kernel<{st}, ", regex=True)]["ms"].tolist()
+            c = wave_counts(s_sq[-1], s_f[-1])
+            sh[str(st)] = {**c, "issue_floor_ms": floor_ms(c), "stage_kernel_alone_ms": float(min(s_ms[-reps:]))}
+        crit8 = max(sh, key=lambda k: sh[k]["issue_floor_ms"])
+        out["strong_share_8"] = {
+            "kernel": f"seqik_pipe_kernel<fk = 1> on {n_seq} sequences x 6 legs x 64 frames (synthetic iid, planar): {n_ch} chains, "
+                      "64 per workgroup of four stage wavefronts, one launch alone on the GPU",
+            "kernel_ms": e_ms, "per_stage_mean_wavefront": sh, "critical_stage": int(crit8),
+            "issue_floor_ms": sh[crit8]["issue_floor_ms"],
+            "sum_of_stage_floors_ms": sum(v["issue_floor_ms"] for v in sh.values()),
+            "latency_floor_frac": sh[crit8]["issue_floor_ms"] / e_ms,
+            "note": "floor = instruction stream of the MEAN stage-1 wavefront (SQ_INSTS_VALU / SQ_WAVES of the stage kernel) at the "
+                    "lone-wavefront issue rate; the launch lasts as long as its SLOWEST wavefront, so the fraction is a lower "
+                    "estimate of how close the launch is to its floor.  ideal share of the pipelined 1-GPU step: 1/8 of it"}
     dst = os.path.join(ROOT, "profiles", f"{rnd}_latency_floor.json")
     json.dump(out, open(dst, "w"), indent=1)
     trace[trace.Kernel_Name.str.contains("seqik_")][["Kernel_Name", "ms"]].to_csv(os.path.join(ROOT, "profiles", f"{rnd}_latency_kernel_trace.csv"), index=False)

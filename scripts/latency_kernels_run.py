@@ -7,6 +7,10 @@
   C  the same walk stage by stage (one seqik_stage_kernel<S> launch per stage, one wavefront per chain): the per-stage
      instruction counts of ONE wavefront without the pipeline's waiting loops -- the instruction stream B's waves issue
   D  the generic chain on the shipped recording (RF x 6000 frames): seqik_generic_kernel<diag = 0, grouped = 1>
+  E  the 1/8 share of the fixed config-3 problem (1 953 sequences x 6 legs x 64 frames, synthetic iid, planar layout) as a
+     LONE job, as the library runs it (automatic: stage pipeline, 64 chains per workgroup)
+  F  the same share stage by stage (one seqik_stage_kernel<S> launch per stage): the per-stage instruction streams of its
+     wavefronts without the pipeline's waiting loops
 
 Every launch runs `--reps` times; prints one JSON line with the host wall-clock of each (best of reps)."""
 import argparse
@@ -56,6 +60,24 @@ def main():
     gp = [params[0]]
     g_pose = np.ascontiguousarray(pose[:, :1])
     out["D_generic_ms"] = timed(lambda: _lib.solve_generic(g_pose, gp, want_fk=True))
+    # ---- E / F: the lone 1/8 share of BASELINE config 3 (what a rank of an 8-GPU strong-scaling run solves per step) ----
+    from seqikpy_amd import data, synthetic, utils
+    legs6 = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs6)
+    p6 = [_lib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs6]
+    S8, T = 15625 // 8, 64
+    sp = synthetic.synthetic_pose(S8, T, legs6, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION, variant="iid",
+                                  seed=synthetic.SEED_BASE)
+    s_pose = torch.from_numpy(np.ascontiguousarray(sp.transpose(0, 1, 3, 2, 4))).cuda()      # planar [S][L][5][T][3]
+    s_ang = torch.zeros((S8, 6, 7, T), dtype=torch.float64, device="cuda")
+    s_fk = torch.zeros((S8, 6, T, 9, 3), dtype=torch.float64, device="cuda")
+    lay = _lib.planar_layout(T)
+    out["share_sequences"], out["share_chains"] = S8, S8 * 6
+    out["E_share_piped_ms"] = timed(lambda: _lib.solve_seq_device(s_pose.data_ptr(), S8, 6, T, p6, s_ang.data_ptr(), s_fk.data_ptr(), layout=lay))
+    ref8 = s_ang.clone()
+    out["F_share_stage_kernels_ms"] = timed(lambda: _lib.solve_seq_device(s_pose.data_ptr(), S8, 6, T, p6, s_ang.data_ptr(), s_fk.data_ptr(),
+                                                                          layout=lay, pipeline=1, staged=1))
+    out["F_equals_E_bitwise"] = bool(torch.equal(ref8, s_ang))
     _lib.check_faults()
     print(json.dumps(out), flush=True)
 

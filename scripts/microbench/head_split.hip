@@ -7,6 +7,11 @@
 //   4 staged copy
 //   5 staged, non-temporal loads and stores            6 the same, copy only
 //   7 per-lane AoS loads as 0, non-temporal loads (16 B) and stores
+//   8 pair        TWO consecutive frames per lane (128 per wavefront and iteration): 12 staged non-temporal 16-byte loads, the
+//                 seven rows leave as 16-byte non-temporal stores (1 KiB contiguous per instruction)      9 the same, copy only
+//   10 staged as 5, the 64 x 7 results transposed through the wavefront's LDS block and stored 16 bytes per lane (two rows
+//                 per instruction: lanes 0-31 row j, lanes 32-63 row j + 1)                                 11 the same, copy only
+//   12 pair with the NEXT iteration's 12 loads issued before this iteration's arithmetic (register double buffer)
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o head_split head_split.hip && ./head_split [n_frames]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -98,6 +103,116 @@ __global__ void __launch_bounds__(256) head_variant(HeadArgs a)
     }
 }
 
+
+// modes 8 / 9 / 12: two consecutive frames per lane
+template <int MODE>
+__global__ void __launch_bounds__(256) head_pair(HeadArgs a)
+{
+    constexpr bool COPY = MODE == 9, PREFETCH = MODE == 12;
+    __shared__ d2 s_stage[4 * 768];  // per wave: 2 arrays x 6144 B = 768 x 16 B
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = a.n_frames, n_pair_waves = n / 128;      // whole 128-frame groups; the tail is left to mode 5's path
+    const int64_t wstride = (int64_t)gridDim.x * 4;
+    d2 *st = s_stage + wave * 768;
+    d2 buf[12];
+    int64_t g = (int64_t)blockIdx.x * 4 + wave;
+    auto issue = [&](int64_t grp) {
+        const d2 *gr = reinterpret_cast<const d2 *>(a.r_head + grp * 128 * 6);
+        const d2 *gl = reinterpret_cast<const d2 *>(a.l_head + grp * 128 * 6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            buf[k] = __builtin_nontemporal_load(gr + k * 64 + lane);
+            buf[6 + k] = __builtin_nontemporal_load(gl + k * 64 + lane);
+        }
+    };
+    if (PREFETCH && g < n_pair_waves) issue(g);
+    for (; g < n_pair_waves; g += wstride) {
+        if (!PREFETCH) issue(g);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { st[k * 64 + lane] = buf[k]; st[384 + k * 64 + lane] = buf[6 + k]; }
+        wave_lds_fence();
+        if (PREFETCH && g + wstride < n_pair_waves) issue(g + wstride);
+        d2 o[7];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const double *sr = reinterpret_cast<const double *>(st) + (2 * lane + f) * 6;
+            const double *sl = reinterpret_cast<const double *>(st + 384) + (2 * lane + f) * 6;
+            double out[7];
+            if (COPY) { for (int j = 0; j < 6; ++j) out[j] = sr[j] + sl[j]; out[6] = sr[0] - sl[5]; }
+            else seqik::head_angles_compute(sr, sl, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { if (f == 0) o[j].x = out[j]; else o[j].y = out[j]; }
+        }
+        wave_lds_fence();
+        const int64_t t = g * 128 + 2 * lane;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) __builtin_nontemporal_store(o[j], reinterpret_cast<d2 *>(a.angles + j * n + t));
+    }
+}
+
+// modes 10 / 11: one frame per lane, results transposed through LDS, 16-byte stores (two rows per instruction)
+template <int MODE>
+__global__ void __launch_bounds__(256) head_tstore(HeadArgs a)
+{
+    constexpr bool COPY = MODE == 11;
+    __shared__ d2 s_stage[4 * 384];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n = a.n_frames;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t t0 = (int64_t)blockIdx.x * blockDim.x; t0 + 256 <= n; t0 += stride) {
+        const int64_t w0 = t0 + wave * 64;
+        d2 *st = s_stage + wave * 384;
+        const d2 *gr = reinterpret_cast<const d2 *>(a.r_head + w0 * 6);
+        const d2 *gl = reinterpret_cast<const d2 *>(a.l_head + w0 * 6);
+        const d2 r0 = __builtin_nontemporal_load(gr + lane), r1 = __builtin_nontemporal_load(gr + 64 + lane),
+                 r2 = __builtin_nontemporal_load(gr + 128 + lane);
+        const d2 l0 = __builtin_nontemporal_load(gl + lane), l1 = __builtin_nontemporal_load(gl + 64 + lane),
+                 l2 = __builtin_nontemporal_load(gl + 128 + lane);
+        st[lane] = r0; st[64 + lane] = r1; st[128 + lane] = r2;
+        st[192 + lane] = l0; st[256 + lane] = l1; st[320 + lane] = l2;
+        wave_lds_fence();
+        const double *sr = reinterpret_cast<const double *>(st) + lane * 6;
+        const double *sl = reinterpret_cast<const double *>(st + 192) + lane * 6;
+        double out[7];
+        if (COPY) { for (int j = 0; j < 6; ++j) out[j] = sr[j] + sl[j]; out[6] = sr[0] - sl[5]; }
+        else seqik::head_angles_compute(sr, sl, a.neck, a.rest_head_pitch, a.rest_antenna_pitch, true, out);
+        wave_lds_fence();
+        double *so = reinterpret_cast<double *>(st);           // [8][64] doubles = 4 KiB of the wave's 6 KiB block
+#pragma unroll
+        for (int j = 0; j < 7; ++j) so[j * 64 + lane] = out[j];
+        wave_lds_fence();
+        const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 2 * jj + half;                        // lanes 0-31: row 2 jj, lanes 32-63: row 2 jj + 1
+            const d2 v = *reinterpret_cast<const d2 *>(so + j * 64 + 2 * l32);
+            if (j < 7) __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(a.angles + j * n + w0 + 2 * l32));
+        }
+        wave_lds_fence();
+    }
+}
+
+template <int MODE>
+static float run_new(const HeadArgs &a, int reps, int per_cu)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const int64_t per_block = (MODE == 8 || MODE == 9 || MODE == 12) ? 512 : 256;
+    int64_t blocks = (a.n_frames + per_block - 1) / per_block;
+    if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;
+    auto launch = [&] {
+        if (MODE == 8 || MODE == 9 || MODE == 12) hipLaunchKernelGGL(head_pair<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+        else hipLaunchKernelGGL(head_tstore<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, a);
+    };
+    for (int i = 0; i < 2; ++i) launch();
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch();
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / reps;
+}
+
 static int g_per_cu = 8;
 
 template <int MODE>
@@ -119,6 +234,7 @@ static float run(const HeadArgs &a, int reps)
 
 int main(int argc, char **argv)
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     const int64_t n = argc > 1 ? atoll(argv[1]) : 64000000;
     if (getenv("BLOCKS_PER_CU")) g_per_cu = atoi(getenv("BLOCKS_PER_CU"));
     double *r, *l, *neck, *out;
@@ -142,7 +258,8 @@ int main(int argc, char **argv)
         (void)hipMemcpy(neck, nk, 24, hipMemcpyHostToDevice);
         free(h);
     }
-    HeadArgs a;
+    HeadArgs a = {};
+    a.rec = 6; a.roll_in = nullptr;
     a.r_head = r; a.l_head = l; a.neck = neck; a.neck_stride = 0; a.rest_head_pitch = 0.1; a.rest_antenna_pitch = 0.2;
     a.angles = out; a.n_frames = n; a.compute_ant = 1;
     // accuracy of the device arithmetic (hardware seeds + Newton steps) against the same formulas evaluated on the host
@@ -177,5 +294,37 @@ int main(int argc, char **argv)
            "\"staged_copy\": %.2f, \"staged_nt\": %.2f, \"staged_nt_copy\": %.2f}}\n",
            (long long)n, g_per_cu, SEQIK_HEAD_NEWTON, max_diff, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7],
            gb / t[0], gb / t[1], gb / t[3], gb / t[4], gb / t[5], gb / t[6]);
+    // ---- round 5: 16-byte stores.  Results of every new variant against variant 5's (same arithmetic: must be equal) ----
+    {
+        const int64_t m = (n / 512) * 512;  // the new variants cover whole groups only
+        double *ref = (double *)malloc(sizeof(double) * 7 * 4096), *got = (double *)malloc(sizeof(double) * 7 * 4096);
+        hipLaunchKernelGGL(head_variant<5>, dim3(2048), dim3(256), 0, 0, a);
+        (void)hipDeviceSynchronize();
+        for (int j = 0; j < 7; ++j) (void)hipMemcpy(ref + j * 4096, out + j * n + (m - 4096), 4096 * 8, hipMemcpyDeviceToHost);
+        int same[3] = {1, 1, 1};
+        for (int v = 0; v < 3; ++v) {
+            (void)hipMemset(out, 0, n * 56);
+            if (v == 0) hipLaunchKernelGGL(head_pair<8>, dim3(2048), dim3(256), 0, 0, a);
+            else if (v == 1) hipLaunchKernelGGL(head_tstore<10>, dim3(2048), dim3(256), 0, 0, a);
+            else hipLaunchKernelGGL(head_pair<12>, dim3(2048), dim3(256), 0, 0, a);
+            (void)hipDeviceSynchronize();
+            for (int j = 0; j < 7; ++j) (void)hipMemcpy(got + j * 4096, out + j * n + (m - 4096), 4096 * 8, hipMemcpyDeviceToHost);
+            for (int i = 0; i < 7 * 4096; ++i) if (got[i] != ref[i]) same[v] = 0;
+        }
+        const int per_cus[5] = {3, 4, 6, 8, 16};
+        for (int pc = 0; pc < 5; ++pc) {
+            float u[6] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
+            g_per_cu = per_cus[pc];
+            for (int round = 0; round < 5; ++round) {
+                u[0] = fminf(u[0], run<5>(a, 10)); u[1] = fminf(u[1], run_new<8>(a, 10, per_cus[pc])); u[2] = fminf(u[2], run_new<9>(a, 10, per_cus[pc]));
+                u[3] = fminf(u[3], run_new<10>(a, 10, per_cus[pc])); u[4] = fminf(u[4], run_new<11>(a, 10, per_cus[pc]));
+                u[5] = fminf(u[5], run_new<12>(a, 10, per_cus[pc]));
+            }
+            printf("{\"blocks_per_cu\": %d, \"equal_to_variant_5\": [%d, %d, %d], \"staged_nt_ms\": %.3f, \"pair_ms\": %.3f, \"pair_copy_ms\": %.3f, "
+                   "\"tstore_ms\": %.3f, \"tstore_copy_ms\": %.3f, \"pair_prefetch_ms\": %.3f, \"TBps\": {\"staged_nt\": %.2f, \"pair\": %.2f, \"pair_copy\": %.2f, "
+                   "\"tstore\": %.2f, \"tstore_copy\": %.2f, \"pair_prefetch\": %.2f}}\n", per_cus[pc], same[0], same[1], same[2], u[0], u[1], u[2], u[3], u[4], u[5],
+                   gb / u[0], gb / u[1], gb / u[2], gb / u[3], gb / u[4], gb / u[5]);
+        }
+    }
     return 0;
 }

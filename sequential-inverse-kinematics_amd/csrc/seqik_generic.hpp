@@ -524,6 +524,26 @@ struct GenericIO {
     int64_t n_frames;
 };
 
+// Chain queue of ONE leg (batches of generic chains; seqik_hip.hip seqik_generic_queue_kernel).  A wavefront of the
+// one-lane-per-chain instantiation lives as long as its slowest lane and the launch as long as its slowest wavefront; the
+// iteration counts of the 7-unknown problem are heavy-tailed (mean lane 2 010 passes, mean wavefront 4 030, slowest chain
+// 11 243 on windows of the shipped recording), so in a batch with several times more chains than the GPU has lanes half of
+// the lane-passes are spent waiting.  With a queue a lane that has finished its chain takes the next sequence of its leg
+// from an atomic counter (submission order) and exits when there is none: the chains are independent, every chain is
+// walked by the same code from the same start, so the results are the static launch's bit for bit.  Every lane reaches the
+// exit (the counter only grows), so the grid drains.  Reference: one run_ik_and_fk call per recording and leg
+// (seqikpy/leg_inverse_kinematics.py:545-613); the queue is the batching of many such calls.
+struct GenericQueue {
+    int32_t *counter;        // next sequence of this leg (device memory, zeroed by the launcher)
+    int64_t n_seq;           // sequences of the batch; chain of (sequence s, leg l) = s * n_legs + l
+    int32_t n_legs, leg;
+    const double *pose; int64_t pose_chain;   // bases and per-chain strides of the batch's buffers
+    double *angles; int64_t ang_chain;
+    double *fk;              // nullable, [chain][n_frames][9][3]
+    int32_t *status, *nfev;  // nullable, [chain][n_frames]
+    const double *init;      // nullable, [chain][7]
+};
+
 // link index -> DOF index of the ABI (yaw, pitch, roll, CTr_pitch, CTr_roll, FTi, TiTa)
 SEQIK_HD int generic_link_dof(int link)
 {
@@ -531,27 +551,51 @@ SEQIK_HD int generic_link_dof(int link)
 }
 
 // gc must live in addressable memory (LDS): the GROUPED code reads gc.lb[j] / gc.ub[j] with a lane-dependent j
-template <bool WANT_DIAG, bool GROUPED = false>
-SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const GenericIO &io)
+// QUEUED: `io_in` only carries n_frames and the strides; the lane takes its chains from `queue` (GenericQueue above) until
+// the leg's counter is exhausted.  One lane per chain only (a lane group would have to pull as a group).
+template <bool WANT_DIAG, bool GROUPED = false, bool QUEUED = false>
+SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const GenericIO &io_in, const GenericQueue *queue = nullptr)
 {
+    static_assert(!(GROUPED && QUEUED), "the chain queue is for the one-lane-per-chain instantiation");
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
     const int jm = GROUPED ? group8_joint() : 0;  // the joint this lane takes in grouped sections
+    GenericIO io = io_in;
     double x[GN], f[3] = {0.0, 0.0, 0.0}, sn[GN], cs[GN], target[3] = {0.0, 0.0, 0.0};
     for (int i = 0; i < GN; ++i) {
-        x[i] = io.init ? io.init[generic_link_dof(i)] : gc.seed[i];
+        x[i] = (!QUEUED && io.init) ? io.init[generic_link_dof(i)] : gc.seed[i];
         sn[i] = 0.0; cs[i] = 1.0;
     }
     double cost = 0.0, Delta = 0.0, alpha = 0.0;
     int nfev = 0, status = STATUS_NONE;
     bool first_pass = true, new_solve = true;
-    int64_t t = 0;
+    int64_t t = QUEUED ? io.n_frames : 0;   // QUEUED: "my chain is finished" -- the first pass pulls the first chain
 
     // (diagnostic build only, -DSEQIK_BLOCK_CYCLES=1: the s_memtime stamps of run_stage, scripts/generic_block_cycles.py;
     // block names as used here: new_solve, fd_jacobian = step + sin / cos + chain + gather of the columns, scaling_gtol =
     // gradient, Coleman-Li scaling, radius, d, J_h, tr_step = solve_tr_woodbury, in_bounds = select_step7, reflective =
     // trial point + its sin / cos + gather, trial_eval = chain + cost, post_trial, finished)
     SEQIK_BLK_DECL
-    while (t < io.n_frames) {
+    while (QUEUED || t < io.n_frames) {
+        if constexpr (QUEUED) {
+            if (t >= io.n_frames) {     // this lane's chain is done (or it has none yet): take the next sequence of the leg
+#ifdef __HIP_DEVICE_COMPILE__
+                const int64_t sq = (int64_t)atomicAdd(queue->counter, 1);
+#else
+                const int64_t sq = (int64_t)(*queue->counter)++;
+#endif
+                if (sq >= queue->n_seq) break;   // none left: the lane retires (every lane gets here: the counter only grows)
+                const int64_t c = sq * queue->n_legs + queue->leg;
+                io.pose = queue->pose + c * queue->pose_chain;
+                io.angles = queue->angles + c * queue->ang_chain;
+                io.fk = queue->fk ? queue->fk + c * io.n_frames * 27 : nullptr;
+                io.status = queue->status ? queue->status + c * io.n_frames : nullptr;
+                io.nfev = queue->nfev ? queue->nfev + c * io.n_frames : nullptr;
+                io.init = queue->init ? queue->init + c * 7 : nullptr;
+                for (int i = 0; i < GN; ++i) x[i] = io.init ? io.init[generic_link_dof(i)] : gc.seed[i];
+                t = 0;
+                new_solve = true;
+            }
+        }
         SEQIK_BLK_PASS();
         SEQIK_BLK_END_OF(BLK_LOOP);
         if (new_solve) {

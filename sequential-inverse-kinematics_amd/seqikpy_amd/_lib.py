@@ -490,9 +490,11 @@ def device_attributes(device=0):
 
 
 def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_size=0, affine=None, init_angles=None,
-                  lanes_per_wave=0, lane_groups=True):
+                  lanes_per_wave=0, lane_groups=True, chain_queue=0):
     """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
-    fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None)."""
+    fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None).  ``chain_queue`` (``SeqikOptions.reserved[1]``): batches
+    of full wavefronts on persistent wavefronts whose lanes pull chains from a per-leg counter -- 0 = automatic (at least
+    two chains per lane of the GPU), 1 = never, 2 = whenever full wavefronts are used; same bits either way."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
         raise ValueError(f"pose must have shape (S, L, N, 5, 3), got {pose.shape}")
@@ -512,6 +514,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_si
     opt.device = device
     opt.block_size = block_size
     opt.reserved[0] = lanes_per_wave
+    opt.reserved[1] = chain_queue
     opt.reserved[3] = 0 if lane_groups else 3  # measurements: thin waves without the split over groups of 8 lanes
     rc = load().seqik_solve_generic(pose.ctypes.data_as(_dp), S, L, N, (SeqikLegParams * L)(*legs),
                                     angles.ctypes.data_as(_dp), fk.ctypes.data_as(_dp) if fk is not None else None,

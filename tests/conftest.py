@@ -167,6 +167,37 @@ class HostHarness:
             raise ValueError(f"harness rc={rc}")
         return dict(angles=ang, fk=fk, status=st, nfev=nf)
 
+    def run_generic_queue(self, pose, leg_index, seg, bounds, seeds, init=None, start=0, diag=True):
+        """The chain-queue instantiation on a batch ``pose`` (S, L, N, 5, 3): one host lane takes the sequences of leg
+        ``leg_index`` from the counter (starting at ``start``) -> angles (S, L, N, 7), fk, status, nfev; rows of the other
+        legs / of sequences below ``start`` stay NaN / -1."""
+        dp = ctypes.POINTER(ctypes.c_double)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        pose = np.ascontiguousarray(pose, dtype=np.float64)
+        S, L, n = pose.shape[:3]
+        ang, fk = np.full((S, L, n, 7), np.nan), np.full((S, L, n, 9, 3), np.nan)
+        st, nf = np.full((S, L, n), -1, np.int32), np.full((S, L, n), -1, np.int32)
+        lp = LegParamsC()
+        for i in range(4):
+            lp.seg[i] = seg[i]
+        for i in range(7):
+            lp.bounds[i][0] = bounds[i][0]
+            lp.bounds[i][1] = bounds[i][1]
+        for i in range(27):
+            lp.seeds[i] = seeds[i]
+        counter = ctypes.c_int32(start)
+        fn = self.lib.harness_run_generic_queue
+        fn.restype = ctypes.c_int
+        fn.argtypes = [dp, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(LegParamsC), dp, dp,
+                       ip, ip, dp, ctypes.POINTER(ctypes.c_int32)]
+        rc = fn(pose.ctypes.data_as(dp), S, L, leg_index, n, ctypes.byref(lp), ang.ctypes.data_as(dp), fk.ctypes.data_as(dp),
+                st.ctypes.data_as(ip) if diag else None, nf.ctypes.data_as(ip) if diag else None,
+                np.ascontiguousarray(init, dtype=np.float64).ctypes.data_as(dp) if init is not None else None,
+                ctypes.byref(counter))
+        if rc != 0:
+            raise ValueError(f"harness rc={rc}")
+        return dict(angles=ang, fk=fk, status=st, nfev=nf, counter=counter.value)
+
     def head_angles(self, r_head, l_head, neck, rest_head_pitch, rest_antenna_pitch, compute_ant=True, head_roll=None):
         dp = ctypes.POINTER(ctypes.c_double)
         r_head = np.ascontiguousarray(r_head, dtype=np.float64)

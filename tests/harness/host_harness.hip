@@ -205,6 +205,31 @@ extern "C" int harness_run_generic(const double *pose, int64_t n_frames, const S
     return SEQIK_OK;
 }
 
+// the chain-queue instantiation of the same function (seqik_generic.hpp GenericQueue): ONE host "lane" takes the n_seq
+// sequences of leg `leg` of a batch laid out [seq][n_legs][frames][...] one after the other from the counter
+extern "C" int harness_run_generic_queue(const double *pose, int64_t n_seq, int32_t n_legs, int32_t leg_index, int64_t n_frames,
+                                         const SeqikLegParams *leg, double *angles, double *fk, int32_t *status,
+                                         int32_t *nfev, const double *init, int32_t *counter)
+{
+    int rc = seqik::validate_leg_generic(*leg);
+    if (rc != SEQIK_OK) return rc;
+    seqik::GenericConst gc;
+    seqik::make_generic_consts(*leg, gc);
+    seqik::LegAffine aff;
+    aff.enabled = 0;
+    seqik::GenericIO io;
+    io.pose = nullptr; io.pose_row = 3; io.pose_frame = 15;
+    io.angles = nullptr; io.ang_dof = 1; io.ang_frame = 7;
+    io.fk = nullptr; io.status = nullptr; io.nfev = nullptr; io.init = nullptr; io.n_frames = n_frames;
+    seqik::GenericQueue q;
+    q.counter = counter; q.n_seq = n_seq; q.n_legs = n_legs; q.leg = leg_index;
+    q.pose = pose; q.pose_chain = n_frames * 15; q.angles = angles; q.ang_chain = n_frames * 7;
+    q.fk = fk; q.status = status; q.nfev = nfev; q.init = init;
+    if (status || nfev) seqik::run_generic<true, false, true>(gc, aff, io, &q);
+    else seqik::run_generic<false, false, true>(gc, aff, io, &q);
+    return SEQIK_OK;
+}
+
 // The reflective select_step in its two forms (seqik_core.hpp): compact (lane-per-chain kernels) and written for latency
 // (run_stage<..., LAT>): out = {step[2], step_h[2], predicted_reduction}.  tests/test_core_bitexact_host.py feeds both the same
 // made-up inputs and compares the bits.

@@ -437,7 +437,8 @@ def test_bench_launcher_propagates_rank_failure(tmp_path):
 def test_bench_launches_its_own_ranks(tmp_path):
     """The driver's command form, `python3 bench.py --gpus 2 ...` (no torchrun): the process launches its two ranks
     itself (sharing the box's one GPU, so the process group falls back to gloo), relays ONE JSON line, rc 0; the line
-    carries the N > 1 extras: ranks seen, per-rank step times, both gathers, the strong leg."""
+    carries the N > 1 extras: ranks seen, per-rank step times, both gathers, the one-GPU reference of the same run and the
+    efficiencies against it, the weak leg.  The HEADLINE is config 3 literally: the fixed problem split over the ranks."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
@@ -448,7 +449,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     b = json.loads(lines[0])
-    assert b["n_gpus"] == 2 and b["scaling"] == "weak" and b["roofline"]["frac"] > 0
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["roofline"]["frac"] > 0
+    assert "FIXED problem" in b["config"]["workload"] and b["config"]["frames_total"] == 8192
+    assert b["config"]["sequences_per_gpu"] == 64 and b["config"]["leg_frames_per_step_all_ranks"] == 8192 * 6
     cal = b["config"]["gather_calibration"]
     assert cal["chosen"] in ("rccl", "peer") and cal["rccl"]["ms_per_step"] > 0 and ("ms_per_step" in cal["peer"] or "unavailable" in cal["peer"])
     assert ("peer writes" in b["config"]["gather"]) == (cal["chosen"] == "peer")
@@ -457,9 +460,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert m["rank_ms_per_step"]["min"] <= m["rank_ms_per_step"]["max"]
     assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"])
     assert "peer writes" in m["gather_compare"]["peer"]["ran_as"]
-    assert m["strong"]["sequences_per_gpu"] == 64 and m["strong"]["leg_frames_per_step_all_ranks"] == 8192 * 6
+    assert m["weak"]["sequences_per_gpu"] == 128 and m["weak"]["leg_frames_per_step_all_ranks"] == 2 * 8192 * 6
+    assert len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 2 and m["weak"]["efficiency_vs_n1"] > 0
+    assert m["n1_reference"]["leg_frames_per_step"] == 8192 * 6 and m["n1_reference"]["value"] > 0
+    assert abs(m["efficiency_vs_n1"] - b["value"] / (2 * m["n1_reference"]["value"])) < 1e-9
     assert sum(m["one_recording"]["frames_per_rank"]) == 8192 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
-    assert abs(b["value"] - 2 * 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]
+    assert m["one_recording"]["n1_reference_ms"] > 0 and m["one_recording"]["efficiency_vs_n1"] > 0
+    assert abs(b["value"] - 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]       # the fixed problem / time
 
 
 @pytest.mark.gpu
@@ -468,7 +475,9 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     """Round-3 review, item 4a: the N > 1 path at the largest rank count the GPU box allows beside the test process (the
     pool's process guard admits 6 processes on a card; an 8-rank rehearsal is not possible there -- the 8-rank host logic
     runs in the CPU tier on gloo).  Four ranks share the GPU: launcher, process group, calibrated gather choice, library,
-    IPC, streams, both scalings, the one-recording leg -- rc 0, every rank seen."""
+    IPC, streams, both scalings, the one-recording leg -- rc 0, every rank seen.  Round-4 review, item 1: the headline of
+    an N > 1 line is BASELINE config 3 literally -- `config.workload` names the fixed problem, `value` = its leg-frames x
+    steps / time -- with weak scaling and the truly frame-sharded recording as named legs."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
@@ -481,8 +490,13 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     b = json.loads(lines[0])
     m = b["multi_gpu"]
     assert b["n_gpus"] == 4 and sorted(r_["rank"] for r_ in m["ranks_seen"]) == [0, 1, 2, 3]
-    assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"]) and "strong" in m and "error" not in m["strong"]
-    assert sum(m["one_recording"]["frames_per_rank"]) == 32000
+    assert b["scaling"] == "strong" and "FIXED problem" in b["config"]["workload"] and "4 ranks" in b["config"]["workload"]
+    assert b["config"]["frames_total"] == 32000 and b["config"]["sequences_per_gpu"] == 125
+    assert abs(b["value"] - 32000 * 6 * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) < 1e-6 * b["value"]
+    assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"]) and "weak" in m and "error" not in m["weak"]
+    assert m["weak"]["leg_frames_per_step_all_ranks"] == 4 * 32000 * 6 and len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 4
+    assert "error" not in m["n1_reference"] and m["efficiency_vs_n1"] > 0 and m["speedup_vs_n1"] > 0
+    assert sum(m["one_recording"]["frames_per_rank"]) == 32000 and "error" not in m["one_recording"]
     assert b["config"]["gather_calibration"]["chosen"] in ("rccl", "peer")
 
 

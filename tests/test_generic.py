@@ -195,3 +195,68 @@ def test_woodbury_form_1_is_as_well_conditioned_as_form_0(oracle):
     assert t1["nfev"].sum() < 1.10 * t0["nfev"].sum(), (t1["nfev"].sum(), t0["nfev"].sum())
     assert np.mean(residual(t1)) < 1.02 * np.mean(residual(t0)) + 1e-9   # the constrained optimum is found as well
     assert abs((t1["status"] == 1).mean() - (t0["status"] == 1).mean()) < 0.1
+
+
+def test_chain_queue_instantiation_equals_chain_by_chain_runs(oracle, host_harness):
+    """run_generic<.., QUEUED> (batches of generic chains: a lane takes the next sequence of its leg from a counter when it
+    has finished one): on the host one lane walks the whole queue of a leg; every chain must come out as the plain
+    instantiation's run of that chain alone -- angles, FK, status, nfev bit for bit -- with and without per-chain warm
+    starts, the other leg's rows untouched, the counter past the end exactly once per pull that found nothing."""
+    z = load_golden("generic_rf_100")
+    legs = ["RF", "LF"]
+    T, S = 12, 7
+    pose = np.stack([np.stack([z[f"{l}_pose"][7 * s:7 * s + T] for l in legs]) for s in range(S)])     # (S, 2, T, 5, 3)
+    rng = np.random.default_rng(5)
+    for li, leg in enumerate(legs):
+        _, seg, b, seeds = _leg(z, leg)
+        init = np.stack([np.stack([np.clip(z[f"{l}_angles"][7 * s] + 0.01 * rng.normal(size=7), z[f"{l}_bounds"][:, 0], z[f"{l}_bounds"][:, 1])
+                                   for l in legs]) for s in range(S)])                                  # (S, 2, 7)
+        for use_init in (False, True):
+            got = host_harness.run_generic_queue(pose, li, seg, b, seeds, init=init if use_init else None)
+            assert got["counter"] == S + 1
+            for s in range(S):
+                one = host_harness.run_generic(pose[s, li], seg, b, seeds, init=init[s, li] if use_init else None)
+                for k in ("angles", "fk", "status", "nfev"):
+                    assert np.array_equal(got[k][s, li], one[k]), (leg, s, k)
+                ref = oracle.generic_leg(pose[s, li], seg, b, seeds[18:27]) if not use_init else None
+                if ref is not None:
+                    assert np.array_equal(got["angles"][s, li], ref["angles"]) and np.array_equal(got["nfev"][s, li], ref["nfev"])
+            other = 1 - li
+            assert np.isnan(got["angles"][:, other]).all() and (got["status"][:, other] == -1).all()
+        # a lane that starts in the middle of the queue (others have taken the first sequences) and one that finds it empty
+        late = host_harness.run_generic_queue(pose, li, seg, b, seeds, start=5)
+        assert np.isnan(late["angles"][:5, li]).all() and not np.isnan(late["angles"][5:, li]).any() and late["counter"] == S + 1
+        none = host_harness.run_generic_queue(pose, li, seg, b, seeds, start=S)
+        assert np.isnan(none["angles"]).all() and none["counter"] == S + 1
+        nodiag = host_harness.run_generic_queue(pose, li, seg, b, seeds, diag=False)
+        assert np.array_equal(nodiag["angles"][:, li], host_harness.run_generic_queue(pose, li, seg, b, seeds)["angles"][:, li])
+
+
+@pytest.mark.gpu
+def test_chain_queue_on_gpu_equals_the_static_launch(hiplib, oracle):
+    """seqik_generic_queue_kernel == seqik_generic_kernel bit for bit (angles, FK, status, nfev): a small batch with the
+    queue forced (fewer wavefronts than the GPU holds), and a batch with more than two chains per lane of the GPU, where
+    the queue is the AUTOMATIC choice and the persistent wavefronts really pull (one wavefront per SIMD); sampled chains
+    against the oracle."""
+    z = load_golden("generic_rf_100")
+    legs = ["RF", "LF"]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    rec = np.stack([z[f"{l}_pose"] for l in legs])                               # (2, 100, 5, 3)
+    for S, T, mode in ((300, 16, 2), (70_000, 3, 0)):
+        offs = (np.arange(S) * 7) % (100 - T)
+        pose = np.ascontiguousarray(rec[:, offs[:, None] + np.arange(T)[None, :]].transpose(1, 0, 2, 3, 4))   # (S, 2, T, 5, 3)
+        static = hiplib.solve_generic(pose, params, want_diag=True, chain_queue=1)
+        queued = hiplib.solve_generic(pose, params, want_diag=True, chain_queue=mode)
+        for k in ("angles", "fk", "status", "nfev"):
+            assert np.array_equal(static[k], queued[k]), (S, k)
+        plain = hiplib.solve_generic(pose, params, want_diag=False, chain_queue=mode)
+        assert np.array_equal(plain["angles"], static["angles"]) and np.array_equal(plain["fk"], static["fk"])
+        for s in (0, S // 2, S - 1):
+            for i, leg in enumerate(legs):
+                ref = oracle.generic_leg(pose[s, i], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"][18:27])
+                assert np.array_equal(queued["angles"][s, i], ref["angles"]) and np.array_equal(queued["nfev"][s, i], ref["nfev"])
+    # warm starts per chain go through the queue too
+    init = np.stack([np.stack([z[f"{l}_angles"][o] for l in legs]) for o in offs[:500]])
+    a = hiplib.solve_generic(pose[:500], params, init_angles=init, chain_queue=1)
+    b = hiplib.solve_generic(pose[:500], params, init_angles=init, chain_queue=2)
+    assert np.array_equal(a["angles"], b["angles"]) and np.array_equal(a["fk"], b["fk"])
