@@ -59,7 +59,10 @@ from concurrent.futures import ThreadPoolExecutor
 # share a queue run one after the other.  Three solver streams fit -- until RCCL adds its own: measured on one MI355X,
 # 4.13e8 -> 3.0e8 solves/s as soon as a process group exists (same as GPU_MAX_HW_QUEUES=2 without one); with 8
 # queues both cases run at 4.13e8.  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Round 5: the per-rank shares of the fixed problem (strong scaling) only fill the GPU with MANY steps in flight -- 16 streams on
+# 16 queues: 1/8 share 3.4 -> 1.9-2.1 ms per step; more streams than queues, or more than 16 queues, collapse to ~16 ms per
+# step (profiles/r05_share_streams.jsonl) -- so the default here is 16 queues and the depth is calibrated in the run.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and hipIpc handles across processes need it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -157,11 +160,17 @@ def parse():
     ap.add_argument("--lanes-per-wave", type=int, default=0, help="chains per wavefront (0 = automatic)")
     ap.add_argument("--interleave-legs", type=int, default=0,
                     help="1 = consecutive chains per wave (legs interleaved) instead of leg-pure, longest-leg-first waves")
+    ap.add_argument("--stage-pipeline", type=int, default=-1,
+                    help="SeqikOptions.reserved[3]: 0 = the library's choice (stage pipeline up to 40 000 chains: right for ONE call, "
+                         "whose latency it halves), 1 = never (lane per chain kernels: right when many steps are in flight), 2 = always; "
+                         "-1 (default) = 0 with an explicit --streams, calibrated together with the depth otherwise")
     ap.add_argument("--staged", action="store_true",
                     help="one launch per stage (SeqikOptions.reserved[1] = 1) instead of the default single launch in "
                          "which every wave takes its chains through the four stages in turn")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the steps are issued on round-robin (consecutive batches overlap)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the steps are issued on round-robin (consecutive steps overlap).  0 (default) = calibrated in "
+                         "the run: (3 streams, library's kernel choice), (8 / 12 / 16 streams, lane-per-chain kernels) are each timed "
+                         "for a few steps on this rank's batch with the gather running, the fastest on the slowest rank is taken")
     ap.add_argument("--one-recording", action="store_true",
                     help="config 3 literally: ONE recording of --frames frames x 6 legs (real locomotion poses repeated), "
                          "frame-sharded over the ranks on the library's frame chunks, end states exchanged, angles all-gathered")
@@ -250,16 +259,24 @@ def cpu_baseline(pose, legs, body, n_seq_sample, python_pool=True):
 class Batch:
     """One rank's batch resident in HBM (planar layout) + the launch of one step on a given stream."""
 
-    def __init__(self, pose, params, args, n_streams):
-        self.S, self.L, self.T = pose.shape[:3]
+    def __init__(self, pose, params, args, n_streams, pipeline=None, like=None):
+        """`like`: another Batch of the SAME key points (its device copy and streams are shared, only FK buffers are added)."""
         self.params, self.args = params, args
-        self.layout = _lib.planar_layout(self.T)
-        # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
-        self.d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
-        self.main = torch.cuda.current_stream()
-        self.streams = [self.main] + [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
-        self.d_fks = [torch.zeros((self.S, self.L, self.T, 9, 3), dtype=torch.float64, device="cuda")
-                      for _ in self.streams]
+        self.pipeline = max(0, getattr(args, "stage_pipeline", 0)) if pipeline is None else pipeline
+        if like is not None:
+            self.S, self.L, self.T, self.layout, self.d_pose, self.main = like.S, like.L, like.T, like.layout, like.d_pose, like.main
+            self.streams = list(like.streams[:n_streams]) + [torch.cuda.Stream() for _ in range(max(0, n_streams - len(like.streams)))]
+            self.d_fks = list(like.d_fks[:n_streams])
+        else:
+            self.S, self.L, self.T = pose.shape[:3]
+            self.layout = _lib.planar_layout(self.T)
+            # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
+            self.d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+            self.main = torch.cuda.current_stream()
+            self.streams = [self.main] + [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
+            self.d_fks = []
+        while len(self.d_fks) < len(self.streams):
+            self.d_fks.append(torch.zeros((self.S, self.L, self.T, 9, 3), dtype=torch.float64, device="cuda"))
         self.units = self.S * self.L * self.T
 
     def angle_buffer(self):
@@ -273,8 +290,12 @@ class Batch:
         _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.T, self.params, buf.data_ptr(),
                               self.d_fks[k].data_ptr(), stream=stream.cuda_stream, block_size=a.block, layout=self.layout,
                               lanes_per_wave=a.lanes_per_wave, staged=int(a.staged), interleave_legs=a.interleave_legs,
+                              pipeline=self.pipeline,
                               stage_events=[e.cuda_event for e in events] if events else None)
         return stream
+
+
+DEPTH_CANDIDATES = ((3, 0), (8, 1), (12, 1), (16, 1))   # (steps in flight, SeqikOptions.reserved[3]); see parse(): --streams 0
 
 
 def timed_steps(batch, bufs, steps, n_streams, warmup=2):
@@ -580,7 +601,7 @@ def generic_batches(za, frames=32, sizes=(32768, 262144)):
     per chain, device-resident, 7 angles + FK.  For every size the static launch (a wavefront owns 64 chains and lives as
     long as its slowest lane) against the chain queue (persistent wavefronts, one per SIMD; a lane that has finished its
     chain takes the next one of its leg) -- same bits, checked -- with the pass counts that explain the difference (from a
-    diagnostics run: nfev per frame).  The library's automatic choice is the queue from two chains per GPU lane on."""
+    diagnostics run: nfev per frame).  The library's automatic choice is the queue from four chains per GPU lane on."""
     import ctypes
     legs = ["RF", "LF"]
     params = [_lib.leg_params_from_arrays(za[f"{l}_seg"], za[f"{l}_bounds"], za[f"{l}_seeds"]) for l in legs]
@@ -644,7 +665,8 @@ def generic_batches(za, frames=32, sizes=(32768, 262144)):
     big = res["sizes"][str(2 * sizes[-1])]
     res["leg_frames_per_s"] = max(big["queue"]["leg_frames_per_s"], big["static"]["leg_frames_per_s"])
     res["queue_speedup_over_static_largest"] = big["queue_speedup_over_static"]
-    res["bound"] = "profiles/r05_generic_queue_bound.json (oracle pass counts, list scheduling): 1.00 / 1.21 / 1.38 / 1.57 at 1 / 2 / 4 / 8 chains per lane"
+    res["bound"] = ("profiles/r05_generic_queue_bound.json (oracle pass counts, list scheduling at a constant pass time): 1.00 / 1.21 / "
+                    "1.38 / 1.57 at 1 / 2 / 4 / 8 chains per lane; the static launch beats that model because its passes get faster as the GPU drains")
     _lib.check_faults()
     return res
 
@@ -791,7 +813,30 @@ def reference_configs(time_box_s=240.0):
                 traffic = json.load(fh)["traffic_bytes_per_frame"] * n_h
         except (OSError, KeyError, ValueError, StopIteration):
             pass
+        # what THIS box's memory system gives a plain copy of the same byte volume right now (torch's vectorised copy kernel,
+        # 76 B per frame each way, same events): the boxes of the pool differ by 15 % in this figure, and the head kernel
+        # cannot be faster than a copy of its bytes (scripts/microbench/head_split.hip has the same-mix calibration kernels)
+        box = None
+        try:
+            n_cp = n_h * 76 // 8
+            c_src = torch.zeros(n_cp, dtype=torch.float64, device="cuda")
+            c_dst = torch.empty_like(c_src)
+            for _ in range(5):
+                c_dst.copy_(c_src)
+            cev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+            cev[0].record()
+            for i in range(20):
+                c_dst.copy_(c_src)
+                cev[i + 1].record()
+            torch.cuda.synchronize()
+            c_each = np.array([cev[i].elapsed_time(cev[i + 1]) for i in range(20)])
+            box = 152.0 * n_h / float(c_each.mean()) / 1e6
+            del c_src, c_dst
+        except Exception:  # noqa: BLE001
+            pass
         e4["head_kernel"] = {"kernel": "seqik_head_kernel<true>", "frames": n_h, "launches": k_h, "ms": float(each.mean()),
+                             "box_copy_same_bytes_GBps": round(box, 1) if box else None,
+                             "frac_of_box_copy": round(gbps / box, 3) if box else None,
                              "ms_best": float(each.min()), "frames_per_s": n_h / float(each.mean()) * 1e3,
                              "roofline": {"bound": "hbm", "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
                                           "frac": round(gbps / 8000.0, 3), "algorithmic_bytes_per_frame": 152,
@@ -947,7 +992,6 @@ def main():
 
     T = args.frames_per_seq
     S_total = args.frames // T
-    n_streams = args.streams
 
     whole = {}   # rank 0 of an N > 1 job keeps the whole fixed problem: the one-GPU reference of the same run
 
@@ -970,16 +1014,14 @@ def main():
     pose, legs, body, params, units_all = workload_for(args.scaling)
     S = pose.shape[0]
     L = len(legs)
-    batch = Batch(pose, params, args, n_streams)
+    explicit_depth = args.streams > 0
+    first_depth = (args.streams, max(0, args.stage_pipeline)) if explicit_depth else DEPTH_CANDIDATES[0]
+    batch = Batch(pose, params, args, first_depth[0], pipeline=first_depth[1])
     units_per_step = batch.units  # leg-frames per step on this rank
-    streams = batch.streams
     main_stream = batch.main
-    # angle buffers: one per batch in flight + two spare, so that a gather that is still draining (it only gets
-    # CU slots as solver waves retire) does not hold back the launch that wants to reuse its buffer
-    n_buf = max(2, len(streams) + (2 if use_dist else 0))
-    d_ang = [batch.angle_buffer() for _ in range(n_buf)]
     # final joint-angle gather: chosen below (choose_gather), once timed_region exists
     gather, gather_how, gather_calibration = None, None, None
+    depth_calibration = None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -1019,6 +1061,62 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tmax = float(t.item())
         return tmax, mine
+
+    def buffers_for(bt):
+        # angle buffers: one per step in flight + two spare, so that a gather that is still draining (it only gets CU slots
+        # as solver waves retire) does not hold back the launch that wants to reuse its buffer
+        return [bt.angle_buffer() for _ in range(max(2, len(bt.streams) + (2 if use_dist else 0)))]
+
+    if not explicit_depth:
+        # How many steps to keep in flight, and on which kernel family: measured here, on this rank's batch, with the gather
+        # running (its streams take hardware queues too), a few steps per candidate; every rank takes the candidate that is
+        # fastest on the SLOWEST rank (timed_region returns the max over ranks).  One job on one GPU gains 2 % from depth
+        # 16; the 1/8 share of the fixed problem 1.8 x (3.4 -> 1.9 ms per step): the lane-per-chain kernels need ~4 400
+        # wavefronts in flight to fill 1 024 SIMDs, and a share only brings 183 per step.
+        depth_calibration = {"candidates": [], "steps": args.steps, "warmup": args.warmup,
+                             "rule": "fastest ms per step on the slowest rank over the SAME region as the headline (warm-up + steps between "
+                                     "two synchronisations, fill and drain included); (streams, stage_pipeline): stage_pipeline 0 = the "
+                                     "library's choice for ONE call, 1 = lane-per-chain kernels"}
+        best = None
+        for n_st, pipe in DEPTH_CANDIDATES:
+            try:
+                bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch)
+                bufs = buffers_for(bt)
+                g = None
+                if use_dist:
+                    g, _ = peer_gather.make_gather(dist, world, rank, bufs[0], n_buffers=len(bufs), min_gbps=8.0,
+                                                   prefer=os.environ.get("SEQIK_GATHER") or ("rccl" if backend == "nccl" else None))
+                # exactly the region that will be measured: args.warmup untimed + args.steps timed steps between two full
+                # synchronisations -- the pipeline's fill and drain are INSIDE it, so with few steps a deep pipeline loses what
+                # it gains in steady state (20 steps of the whole problem: 3 in flight 11.8 ms per step, 12 in flight 15.5)
+                k = args.steps
+                tm, _ = timed_region(bt, bufs, g, k, args.warmup)
+                if g is not None and hasattr(g, "close"):
+                    g.close()
+                ms = tm / k * 1e3
+                ok_flag = 1.0
+            except Exception as exc:  # noqa: BLE001  (e.g. no memory for 16 FK buffers: the candidate is skipped on all ranks)
+                sys.stderr.write(f"bench.py rank {rank}: depth candidate {(n_st, pipe)} failed ({type(exc).__name__}: {exc})\n")
+                bt, bufs, ms, ok_flag = None, None, float("inf"), 0.0
+            if use_dist:
+                okt = torch.tensor([ok_flag], dtype=torch.float64, device=coll_dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                ok_flag = float(okt.item())
+            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe,
+                                                    "ms_per_step": ms if ok_flag > 0.5 and ms != float("inf") else None})
+            if ok_flag > 0.5 and (best is None or ms < best[0]):
+                best = (ms, n_st, pipe, bt)
+            del bufs
+        if best is None:
+            raise SystemExit("bench: no pipeline depth could be run")
+        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2]}
+        batch = best[3]
+        del batch.d_fks[len(batch.streams):]
+        torch.cuda.empty_cache()
+    streams = batch.streams
+    n_streams = len(streams)
+    n_buf = max(2, len(streams) + (2 if use_dist else 0))
+    d_ang = [batch.angle_buffer() for _ in range(n_buf)]
 
     def choose_gather():
         """The final joint-angle gather of the headline.  BASELINE.json's north star names it: "RCCL over xGMI only for the
@@ -1173,10 +1271,10 @@ def main():
                 # scaling efficiencies of THIS run are measured against
                 res = None
                 if rank == 0:
-                    b1 = Batch(whole["pose"], params, args, n_streams)
+                    b1 = Batch(whole["pose"], params, args, n_streams, pipeline=batch.pipeline)
                     bufs1 = [b1.angle_buffer() for _ in range(len(b1.streams))]
-                    k1 = max(6, min(30, args.steps))
-                    dt1 = timed_steps(b1, bufs1, k1, len(b1.streams), warmup=3)
+                    k1 = args.steps
+                    dt1 = timed_steps(b1, bufs1, k1, len(b1.streams), warmup=args.warmup)
                     res = {"value": b1.units * k1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
                            "streams": len(b1.streams), "leg_frames_per_step": int(b1.units),
                            "what": "the whole fixed problem on rank 0's GPU alone (the other ranks idle), same run"}
@@ -1207,7 +1305,7 @@ def main():
                 # the other scaling mode beside the headline: strong = config 3 literally (the fixed 1M-frame problem split
                 # over the ranks), weak = 1M frames per GPU
                 pose2, _, _, _, units_all2 = workload_for(other_scaling)
-                b2 = Batch(pose2, params, args, n_streams)
+                b2 = Batch(pose2, params, args, n_streams, pipeline=batch.pipeline)
                 bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
                 g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=headline_kind)
                 k2 = max(4, min(40, args.steps))
@@ -1277,6 +1375,8 @@ def main():
                                        if args.variant == "iid" else
                                        "temporally continuous poses (the realistic variant); `parity` holds the shipped recordings"),
                        "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
+                       "stage_pipeline": batch.pipeline,
+                       **({"depth_calibration": depth_calibration} if depth_calibration else {}),
                        **({"gather": gather_how} if gather_how else {}),
                        **({"gather_calibration": gather_calibration} if gather_calibration else {})},
             "roofline": roofline,
@@ -1288,31 +1388,34 @@ def main():
         if world == 1 and not args.no_extras:
             # ---- one launch at a time --------------------------------------------------------------------------
             n1 = max(4, min(16, args.steps // 6))
-            dt1 = timed_steps(batch, d_ang, n1, 1)
+            lone = Batch(None, params, args, 1, pipeline=0, like=batch)       # ONE call at a time: the library's own kernel choice
+            dt1 = timed_steps(lone, d_ang, n1, 1)
             out["single_job"] = {"value": units_per_step * n1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / n1 * 1e3,
                                  "steps": n1, "streams": 1,
                                  "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
                                          "FP64 latency; `value` above is the pipelined rate"}
             # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU ----------------------
             proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU; no gather; "
-                            "projected_value = 6M leg-frames / that time.  `streams`: launches in flight -- a share of "
-                            "1/N fills 1/N of the wave slots, so as many more independent steps can overlap (3 at N = 1)",
+                            "projected_value = 6M leg-frames / that time.  `streams` / `stage_pipeline`: the fastest of the depth "
+                            "candidates for that share (what an N-GPU run calibrates for itself): a share of 1/N brings 1/N of the "
+                            "wavefronts per step, so as many more steps must be in flight to fill the GPU; lone_job_ms = ONE launch at "
+                            "a time (the library's own kernel choice), what a rank gets when every step waits for the one before",
                     "by_n_gpus": {}}
             for n in (2, 4, 8):
                 best = None
-                for n_streams in (args.streams, min(8, args.streams * n)):
-                    sub = Batch(pose[: S // n], params, args, n_streams)
+                for n_st, pipe in (DEPTH_CANDIDATES if not explicit_depth else ((n_streams, batch.pipeline),)):
+                    sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
                     bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
-                    k = max(4 * n_streams, min(60, args.steps // 2))
-                    dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=n_streams)
-                    row = {"streams": n_streams, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                    k = args.steps             # the same region as the headline's: fill and drain of the pipeline included
+                    dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=args.warmup)
+                    row = {"streams": n_st, "stage_pipeline": pipe, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
                            "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
                     if best is None or row["ms_per_step"] < best["ms_per_step"]:
                         best = row
                     del sub, bufs
                 # the floor of a share: ONE launch at a time, no second step to overlap with (what a rank can do at best when
                 # every step has to wait for the one before it)
-                sub = Batch(pose[: S // n], params, args, 1)
+                sub = Batch(pose[: S // n], params, args, 1, pipeline=0)     # ONE call: the library's own choice of kernel
                 bufs = [sub.angle_buffer()]
                 k = max(8, min(40, args.steps // 2))
                 dt = timed_steps(sub, bufs, k, 1, warmup=2)
@@ -1331,9 +1434,9 @@ def main():
             # ---- the other synthetic variant -------------------------------------------------------------------
             other = "smooth" if args.variant == "iid" else "iid"
             _, _, pose_o, _ = make_workload(S, T, other, synthetic.SEED_BASE)
-            bo = Batch(pose_o, params, args, args.streams)
-            ko = max(12, min(40, args.steps // 2))
-            dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=3)
+            bo = Batch(pose_o, params, args, n_streams, pipeline=batch.pipeline)
+            ko = args.steps
+            dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=args.warmup)
             ms_o = dto / ko * 1e3
             _, valu_o, fp64_o, match_o, file_o = pmc_roofline(other, args.staged, key, bo.units, ms_o, device_index)
             roof_o = {"pmc_matches_build": match_o, "pmc_file": file_o}
@@ -1389,6 +1492,7 @@ def main():
                 "generic_6000_frames_s": (dig(cf, "generic", "ms") or 0.0) / 1e3 or None,
                 "generic_batch_leg_frames_per_s": dig(cf, "generic", "batch", "leg_frames_per_s"),
                 "head_kernel_hbm_frac": dig(cf, "4", "head_kernel", "roofline", "frac"),
+                "head_kernel_frac_of_box_copy": dig(cf, "4", "head_kernel", "frac_of_box_copy"),
                 "parity_max_abs_dtheta": max(par[n]["serial_walk"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
                 "parity_p99.9_abs_dtheta": max(par[n]["serial_walk"]["p99.9_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
                 "parity_values_over_5e-5": sum(par[n]["serial_walk"]["values_over_5e-5"] for n in ("anipose_shipped", "df3d_1000")),

@@ -85,7 +85,7 @@ typedef struct SeqikOptions {
                              AUTOMATIC stage pipeline of [3] off; an explicit [3] >= 2 and frame chunks still use it);
                              seqik_solve_generic*: chain queue of a batch of full wavefronts (persistent wavefronts whose
                              lanes take the next chain of their leg from a counter when they have finished one): 0 =
-                             automatic (batches with at least two chains per lane of the GPU), 1 = never, 2 = always;
+                             automatic (batches with at least four chains per lane of the GPU), 1 = never, 2 = always;
                              [2]: 0 = all lanes of a wavefront carry the same leg, 1 = consecutive chains (legs
                              interleaved);
                              [3]: stage pipeline -- a workgroup of four wavefronts per group of chains, wavefront k

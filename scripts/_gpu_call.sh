@@ -1,23 +1,18 @@
 set -o pipefail
-mkdir -p gpurun_out/r05c
-timeout -k 10 300 ./scripts/microbench/head_split 16000000 > gpurun_out/r05c/head_split16.jsonl 2>&1; echo "split16 rc=$?"
-cat gpurun_out/r05c/head_split16.jsonl
-timeout -k 10 300 ./scripts/microbench/head_split 64000000 > gpurun_out/r05c/head_split64.jsonl 2>&1; echo "split64 rc=$?"
-cat gpurun_out/r05c/head_split64.jsonl
-timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lanes_per_wave or single_launch or full_size or streams" > gpurun_out/r05c/gputests.log 2>&1; echo "pytest rc=$?"
-tail -3 gpurun_out/r05c/gputests.log
-# lone job of the full config-3 problem: chains per wavefront x lane pairs in the fused kernel
-for W in 64 48 32 24; do
-  for P in 1 0; do
-    SEQIK_FUSED_PAIRS=$P timeout -k 10 200 python bench.py --steps 12 --warmup 3 --streams 1 --lanes-per-wave $W --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lone W=$W pairs=$P', round(b['ms_per_step'],3), 'ms', b['value'])"
-  done
-done | tee gpurun_out/r05c/lone_job_lanes.txt
-for W in 32 24; do
-  for P in 1 0; do
-    SEQIK_FUSED_PAIRS=$P timeout -k 10 200 python bench.py --steps 20 --warmup 5 --streams 3 --lanes-per-wave $W --no-extras --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('3 streams W=$W pairs=$P', round(b['ms_per_step'],3), 'ms', b['value'])"
-  done
-done | tee -a gpurun_out/r05c/lone_job_lanes.txt
+mkdir -p gpurun_out/r05g
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05g/gputests.log 2>&1; echo "pytest rc=$?"
+tail -4 gpurun_out/r05g/gputests.log
+timeout -k 10 700 python bench.py --steps 20 --warmup 5 > gpurun_out/r05g/bench.json 2> gpurun_out/r05g/bench.err; echo "bench rc=$?"
+tail -3 gpurun_out/r05g/bench.err
+python - <<'PY'
+import json
+b=json.loads(open('gpurun_out/r05g/bench.json').read().strip().splitlines()[-1])
+print({k:v for k,v in b.items() if not isinstance(v,(dict,list))})
+print(json.dumps(b['config'].get('depth_calibration')))
+print(json.dumps({k:{kk:vv for kk,vv in v.items() if kk in ('streams','stage_pipeline','ms_per_step','speedup_vs_1','lone_job_ms','efficiency')} for k,v in b['strong_projection']['by_n_gpus'].items()}))
+print(json.dumps(b['configs']['4']['head_kernel']))
+PY
+bash scripts/gpu_profile.sh r05 > gpurun_out/r05g/profile.log 2>&1; echo "profile rc=$?"
+bash scripts/gpu_profile.sh r05s --variant smooth > gpurun_out/r05g/profile_smooth.log 2>&1; echo "profile smooth rc=$?"
+bash scripts/gpu_latency_profile.sh r05 > gpurun_out/r05g/latprofile.log 2>&1; echo "latency profile rc=$?"
+bash scripts/gpu_head_profile.sh r05 16000000 > gpurun_out/r05g/headprofile.log 2>&1; echo "head profile rc=$?"

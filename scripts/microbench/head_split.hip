@@ -191,6 +191,54 @@ __global__ void __launch_bounds__(256) head_tstore(HeadArgs a)
     }
 }
 
+// calibration of the box: (13) a plain 16-byte-per-lane copy of the same byte volume (76 n bytes each way, one stream in, one
+// out -- the guide's "float4 copy"), (14) the kernel's read : write mix as contiguous planes (12 x 16 B read, 7 x 16 B written
+// per lane and iteration), (15 / 16) the same two with non-temporal accesses
+template <int MODE>
+__global__ void __launch_bounds__(256) cal_copy(const d2 *__restrict__ in, d2 *__restrict__ out, int64_t n16_in, int64_t n16_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr bool NT = MODE >= 15;
+    if (MODE == 13 || MODE == 15) {
+        for (int64_t i = i0; i < n16_out; i += stride) {
+            const d2 v = NT ? __builtin_nontemporal_load(in + i) : in[i];
+            if (NT) __builtin_nontemporal_store(v, out + i); else out[i] = v;
+        }
+    } else {
+        const int64_t plane_in = n16_in / 12, plane_out = n16_out / 7;   // equal by construction (n / 2 each)
+        for (int64_t i = i0; i < plane_out; i += stride) {
+            d2 acc = {0.0, 0.0};
+#pragma unroll
+            for (int p = 0; p < 12; ++p) { const d2 v = NT ? __builtin_nontemporal_load(in + p * plane_in + i) : in[p * plane_in + i]; acc += v; }
+#pragma unroll
+            for (int p = 0; p < 7; ++p) { if (NT) __builtin_nontemporal_store(acc, out + p * plane_out + i); else out[p * plane_out + i] = acc; }
+        }
+    }
+}
+
+template <int MODE>
+static float run_cal(const double *in, double *out, int64_t n, int reps, int per_cu)
+{
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    // 13 / 15: 76 n bytes each way (in: the first 76 n bytes of the 96 n-byte input); 14 / 16: 96 n in, 56 n out
+    const int64_t n16_in = (MODE == 13 || MODE == 15) ? n * 76 / 16 : n * 96 / 16;
+    const int64_t n16_out = (MODE == 13 || MODE == 15) ? n * 76 / 16 : n * 56 / 16;
+    const int64_t work = (MODE == 13 || MODE == 15) ? n16_out : n16_out / 7;
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;
+    auto launch = [&] { hipLaunchKernelGGL(cal_copy<MODE>, dim3((unsigned)blocks), dim3(256), 0, 0, reinterpret_cast<const d2 *>(in), reinterpret_cast<d2 *>(out), n16_in, n16_out); };
+    for (int i = 0; i < 2; ++i) launch();
+    (void)hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch();
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / reps;
+}
+
 template <int MODE>
 static float run_new(const HeadArgs &a, int reps, int per_cu)
 {
@@ -325,6 +373,25 @@ int main(int argc, char **argv)
                    "\"tstore\": %.2f, \"tstore_copy\": %.2f, \"pair_prefetch\": %.2f}}\n", per_cus[pc], same[0], same[1], same[2], u[0], u[1], u[2], u[3], u[4], u[5],
                    gb / u[0], gb / u[1], gb / u[2], gb / u[3], gb / u[4], gb / u[5]);
         }
+    }
+    // ---- what THIS box's memory system gives a plain copy of the same byte volume (r is 48 n bytes, l the next allocation:
+    // the calibration kernels read r / l as one 96 n-byte array only if they are adjacent, so they get their own buffers)
+    {
+        double *cin, *cout;
+        (void)hipMalloc(&cin, n * 96); (void)hipMalloc(&cout, n * 76);
+        (void)hipMemset(cin, 0, n * 96);
+        const int per_cus[4] = {4, 8, 16, 64};
+        for (int pc = 0; pc < 4; ++pc) {
+            float c[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+            for (int round = 0; round < 5; ++round) {
+                c[0] = fminf(c[0], run_cal<13>(cin, cout, n, 10, per_cus[pc])); c[1] = fminf(c[1], run_cal<14>(cin, cout, n, 10, per_cus[pc]));
+                c[2] = fminf(c[2], run_cal<15>(cin, cout, n, 10, per_cus[pc])); c[3] = fminf(c[3], run_cal<16>(cin, cout, n, 10, per_cus[pc]));
+            }
+            printf("{\"calibration_blocks_per_cu\": %d, \"copy16_1to1_ms\": %.3f, \"planes_96to56_ms\": %.3f, \"copy16_1to1_nt_ms\": %.3f, \"planes_96to56_nt_ms\": %.3f, "
+                   "\"TBps\": {\"copy16_1to1\": %.2f, \"planes_96to56\": %.2f, \"copy16_1to1_nt\": %.2f, \"planes_96to56_nt\": %.2f}}\n",
+                   per_cus[pc], c[0], c[1], c[2], c[3], gb / c[0], gb / c[1], gb / c[2], gb / c[3]);
+        }
+        (void)hipFree(cin); (void)hipFree(cout);
     }
     return 0;
 }

@@ -20,6 +20,28 @@ variant = json.loads(bench_line)["config"]["variant"]
 vtag = "" if variant == "iid" else "_" + variant
 stats.to_csv(f"{dst}/{rnd}_bench{vtag}_kernel_stats.csv", index=False)
 open(f"{dst}/{rnd}_bench{vtag}_under_rocprof.json", "w").write(bench_line)
+# Round 5: the default run calibrates its pipeline depth first (3 / 8 / 12 / 16 steps in flight), and a launch lasts as many
+# times longer as launches share the GPU -- so rocprofv3's per-kernel average mixes four depths.  The figure that must agree
+# with the bench line's `roofline.avg_launch_ms` is the average over the launches of the TIMED REGION: with --no-extras the
+# solver kernel's dispatches are [calibration ...][warm-up][`steps` timed launches][one launch alone = the verification], so
+# the timed region is the `steps` launches in front of the last one (kernel trace, in dispatch order).
+try:
+    tr = pd.read_csv(newest(f"{src}/{tag}_stats/*/*_kernel_trace.csv")).sort_values("Start_Timestamp")
+    k = tr[tr.Kernel_Name.str.contains("seqik_fused_kernel|seqik_pipe_kernel")]
+    b_ = json.loads(bench_line)
+    timed = k.iloc[-(b_["steps"] + 1):-1]
+    dur = (timed.End_Timestamp - timed.Start_Timestamp) / 1e6
+    region = {"kernel": str(timed.Kernel_Name.iloc[0])[:120], "launches": int(len(timed)), "avg_launch_ms": float(dur.mean()),
+              "min_launch_ms": float(dur.min()), "max_launch_ms": float(dur.max()),
+              "span_ms_first_start_to_last_end": float((timed.End_Timestamp.max() - timed.Start_Timestamp.min()) / 1e6),
+              "bench_line_avg_launch_ms": b_["roofline"].get("avg_launch_ms"), "bench_line_ms_per_step": b_["ms_per_step"],
+              "all_launches_of_the_run": int(len(k)), "streams": b_["config"].get("streams"),
+              "source": "rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-baseline --no-extras`: the `steps` launches in front of the "
+                        "last one (the verification launch made alone)"}
+    json.dump(region, open(f"{dst}/{rnd}_bench{vtag}_timed_region_kernel.json", "w"), indent=1)
+    print(json.dumps(region))
+except Exception as exc:  # noqa: BLE001
+    print("timed-region summary skipped:", exc)
 
 def pmc(kind):
     d = pd.read_csv(newest(f"{src}/{tag}_{kind}/*/*_counter_collection.csv"))

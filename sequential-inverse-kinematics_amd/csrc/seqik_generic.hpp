@@ -529,14 +529,25 @@ struct GenericIO {
 // iteration counts of the 7-unknown problem are heavy-tailed (mean lane 2 010 passes, mean wavefront 4 030, slowest chain
 // 11 243 on windows of the shipped recording), so in a batch with several times more chains than the GPU has lanes half of
 // the lane-passes are spent waiting.  With a queue a lane that has finished its chain takes the next sequence of its leg
-// from an atomic counter (submission order) and exits when there is none: the chains are independent, every chain is
-// walked by the same code from the same start, so the results are the static launch's bit for bit.  Every lane reaches the
-// exit (the counter only grows), so the grid drains.  Reference: one run_ik_and_fk call per recording and leg
+// from an atomic counter (submission order); when its leg has none left it moves on to the next leg (a lane never returns
+// to a leg it found exhausted) and exits when all are exhausted: the chains are independent, every chain is walked by the
+// same code from the same start, so the results are the static launch's bit for bit.  Every lane reaches the exit (the
+// counters only grow, a lane tries every leg at most once more), so the grid drains.  Reference: one run_ik_and_fk call per recording and leg
 // (seqikpy/leg_inverse_kinematics.py:545-613); the queue is the batching of many such calls.
+struct GenericLeg {          // one leg's constants as the kernels keep them in LDS
+    GenericConst gc;
+    LegAffine aff;
+};
+
+SEQIK_HD const GenericConst *leg_consts(const GenericLeg *table, int leg) { return &table[leg].gc; }
+SEQIK_HD const LegAffine *leg_affine(const GenericLeg *table, int leg) { return &table[leg].aff; }
+
 struct GenericQueue {
-    int32_t *counter;        // next sequence of this leg (device memory, zeroed by the launcher)
+    int32_t *counters;       // [n_legs] next sequence of every leg (device memory, zeroed by the launcher)
     int64_t n_seq;           // sequences of the batch; chain of (sequence s, leg l) = s * n_legs + l
-    int32_t n_legs, leg;
+    int32_t n_legs, first;   // the lane starts on leg order[first] and moves on, leg by leg, when a leg's counter is exhausted
+    uint8_t order[8];        // dispatch order of the legs
+    const GenericLeg *table; // [n_legs] constants of every leg (LDS): the lane's leg changes while it runs
     const double *pose; int64_t pose_chain;   // bases and per-chain strides of the batch's buffers
     double *angles; int64_t ang_chain;
     double *fk;              // nullable, [chain][n_frames][9][3]
@@ -554,9 +565,15 @@ SEQIK_HD int generic_link_dof(int link)
 // QUEUED: `io_in` only carries n_frames and the strides; the lane takes its chains from `queue` (GenericQueue above) until
 // the leg's counter is exhausted.  One lane per chain only (a lane group would have to pull as a group).
 template <bool WANT_DIAG, bool GROUPED = false, bool QUEUED = false>
-SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const GenericIO &io_in, const GenericQueue *queue = nullptr)
+SEQIK_HD void run_generic(const GenericConst &gc0, const LegAffine &aff0, const GenericIO &io_in, const GenericQueue *queue = nullptr)
 {
     static_assert(!(GROUPED && QUEUED), "the chain queue is for the one-lane-per-chain instantiation");
+    // (QUEUED: the lane's leg -- and with it the constants -- changes while it runs; otherwise these never move)
+    const GenericConst *gcp = &gc0;
+    const LegAffine *affp = &aff0;
+#define gc (*gcp)
+#define aff (*affp)
+    int legs_tried = 0;
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
     const int jm = GROUPED ? group8_joint() : 0;  // the joint this lane takes in grouped sections
     GenericIO io = io_in;
@@ -577,14 +594,24 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
     SEQIK_BLK_DECL
     while (QUEUED || t < io.n_frames) {
         if constexpr (QUEUED) {
-            if (t >= io.n_frames) {     // this lane's chain is done (or it has none yet): take the next sequence of the leg
+            if (t >= io.n_frames) {     // this lane's chain is done (or it has none yet): take the next sequence of its leg,
+                int64_t sq = -1;        // or of the next leg that still has one
+                int leg = 0;
+                while (legs_tried < queue->n_legs) {
+                    leg = queue->order[(queue->first + legs_tried) % queue->n_legs];
 #ifdef __HIP_DEVICE_COMPILE__
-                const int64_t sq = (int64_t)atomicAdd(queue->counter, 1);
+                    sq = (int64_t)atomicAdd(queue->counters + leg, 1);
 #else
-                const int64_t sq = (int64_t)(*queue->counter)++;
+                    sq = (int64_t)(queue->counters[leg])++;
 #endif
-                if (sq >= queue->n_seq) break;   // none left: the lane retires (every lane gets here: the counter only grows)
-                const int64_t c = sq * queue->n_legs + queue->leg;
+                    if (sq < queue->n_seq) break;
+                    sq = -1;
+                    legs_tried += 1;
+                }
+                if (sq < 0) break;      // every leg exhausted: the lane retires (reached by every lane: the counters only grow)
+                gcp = leg_consts(queue->table, leg);
+                affp = leg_affine(queue->table, leg);
+                const int64_t c = sq * queue->n_legs + leg;
                 io.pose = queue->pose + c * queue->pose_chain;
                 io.angles = queue->angles + c * queue->ang_chain;
                 io.fk = queue->fk ? queue->fk + c * io.n_frames * 27 : nullptr;
@@ -806,6 +833,8 @@ SEQIK_HD void run_generic(const GenericConst &gc, const LegAffine &aff, const Ge
         SEQIK_BLK_END_OF(BLK_FINISHED);
     }
     SEQIK_BLK_END(1);
+#undef gc
+#undef aff
 }
 
 }  // namespace seqik

@@ -184,13 +184,6 @@ struct KernelArgs {
     int64_t ang_chain, ang_dof, ang_frame;
 };
 
-// host twin of use_pairs() below (W <= 32: lane_replication(W) is even, so lanes 2k / 2k + 1 carry the same chain)
-inline bool use_pairs_host(const KernelArgs &a)
-{
-    const int W = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
-    return a.lane_pairs != 0 && W <= 32;
-}
-
 
 // Lane -> chain mapping.  A wavefront carries W <= 64 chains OF THE SAME LEG (W consecutive sequences;
 // chain = seq * n_legs + leg), and the waves of one leg are adjacent in the grid, legs in the order of
@@ -375,9 +368,10 @@ seqik_stage_kernel(KernelArgs a)
 // The hand-off frames a lane writes are read back by the same lane.  Saves three kernel drains per call:
 // a stage kernel ends with a tail in which ever fewer waves are resident, and the next stage cannot start
 // before the last wave is gone; here every wave simply carries on.
-// SPLIT: wavefronts that carry at most 32 chains run each chain on two (or more) adjacent lanes; the pair splits the two
-// finite-difference columns and the trial point's two sin / cos of a pass (run_stage SPLIT, "Lane pairs"): same bits.
-template <bool WANT_FK, bool SPLIT = false>
+// (Round 5: a SPLIT instantiation -- 32 chains per wavefront on lane pairs, run_stage SPLIT -- was built and measured for
+// ONE job of 93 750 chains: 26.2 ms against 19.5 ms with full wavefronts; pairs save 6 % of a thin wavefront's
+// instructions, halving the chains per wavefront costs 40 %.  Not kept: EXPERIMENTS.md 5.3.)
+template <bool WANT_FK>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
 seqik_fused_kernel(KernelArgs a)
 {
@@ -406,9 +400,9 @@ seqik_fused_kernel(KernelArgs a)
     io.frames = a.frames + c * a.n_frames * 12;
     io.n_frames = a.n_frames;
     const seqik::LegConst &lc = s_legs[leg];
-    seqik::run_stage<1, false, false, false, true, false, false, SPLIT>(lc, io);
-    seqik::run_stage<2, WANT_FK, false, false, true, false, false, SPLIT>(lc, io);
-    seqik::run_stage<3, WANT_FK, false, false, true, false, false, SPLIT>(lc, io);
+    seqik::run_stage<1, false, false, false, true>(lc, io);
+    seqik::run_stage<2, WANT_FK, false, false, true>(lc, io);
+    seqik::run_stage<3, WANT_FK, false, false, true>(lc, io);
     seqik::run_stage<4, WANT_FK, false, false, false>(lc, io);
 }
 
@@ -889,10 +883,7 @@ void launch_stage(const KernelArgs &a, bool fk, bool diag, bool from_angles, boo
     }
 }
 
-struct GenericLegTable {
-    seqik::GenericConst gc;
-    seqik::LegAffine aff;
-};
+using GenericLegTable = seqik::GenericLeg;   // { GenericConst gc; LegAffine aff; } (seqik_generic.hpp)
 
 struct GenericKernelArgs {
     const double *pose;
@@ -945,9 +936,10 @@ seqik_generic_kernel(GenericKernelArgs a)
 
 // BATCHES of generic chains with more chains than the GPU has lanes: persistent wavefronts, one lane per chain, a lane
 // that has finished its chain takes the next sequence of its leg from a per-leg counter (seqik_generic.hpp GenericQueue).
-// Wavefront w starts on leg  order[w mod n_legs]  and moves on to the next leg (as a whole wavefront: the lanes reconverge
-// behind run_generic) when that leg's counter is exhausted, so every wavefront helps to finish every leg.  The grid is at
-// most one wavefront per SIMD (the kernel's register budget), each wavefront ends when all counters are exhausted.
+// The lanes of wavefront w start on leg  order[w mod n_legs]; a LANE that finds its leg's counter exhausted moves on to the
+// next leg by itself (its constants come from LDS by a per-lane address), so no lane waits for its wavefront at a leg
+// boundary and every wavefront helps to finish every leg.  The grid is at most one wavefront per SIMD (the kernel's
+// register budget); a wavefront ends when all counters are exhausted.
 template <bool WANT_DIAG>
 __global__ void __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(SEQIK_GENERIC_WAVES_PER_EU, SEQIK_GENERIC_WAVES_PER_EU)))
 seqik_generic_queue_kernel(GenericKernelArgs a, int32_t *counters)
@@ -966,14 +958,13 @@ seqik_generic_queue_kernel(GenericKernelArgs a, int32_t *counters)
     io.angles = nullptr; io.ang_dof = a.ang_dof; io.ang_frame = a.ang_frame;
     io.fk = nullptr; io.status = nullptr; io.nfev = nullptr; io.init = nullptr;
     io.n_frames = a.n_frames;
-    for (int k = 0; k < a.n_legs; ++k) {
-        const int leg = a.leg_order.leg[(int)((wave + k) % a.n_legs)];
-        seqik::GenericQueue q;
-        q.counter = counters + leg; q.n_seq = a.n_seq; q.n_legs = a.n_legs; q.leg = leg;
-        q.pose = a.pose; q.pose_chain = a.pose_chain; q.angles = a.angles; q.ang_chain = a.ang_chain;
-        q.fk = a.fk; q.status = a.status; q.nfev = a.nfev; q.init = a.init;
-        seqik::run_generic<WANT_DIAG, false, true>(s_legs[leg].gc, s_legs[leg].aff, io, &q);
-    }
+    seqik::GenericQueue q;
+    q.counters = counters; q.n_seq = a.n_seq; q.n_legs = a.n_legs; q.first = (int32_t)(wave % a.n_legs);
+    for (int l = 0; l < 8; ++l) q.order[l] = a.leg_order.leg[l];
+    q.table = s_legs;
+    q.pose = a.pose; q.pose_chain = a.pose_chain; q.angles = a.angles; q.ang_chain = a.ang_chain;
+    q.fk = a.fk; q.status = a.status; q.nfev = a.nfev; q.init = a.init;
+    seqik::run_generic<WANT_DIAG, false, true>(s_legs[0].gc, s_legs[0].aff, io, &q);
 }
 
 // Device copies of the per-leg constant tables.  Callers almost always pass the same legs on every call, so the
@@ -1282,7 +1273,6 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         else if (int rc = workspace_for(stream, ws_bytes, &a.frames)) return rc;
     }
     const bool fused = (piped || !staged) && first_stage == 1 && last_stage == 4 && !diag;
-    static const bool fused_pairs = !(getenv("SEQIK_FUSED_PAIRS") && atoi(getenv("SEQIK_FUSED_PAIRS")) == 0);  // A/B switch (measurements)
     if (chunked) {
         ChunkArgs ca;
         ca.n_chunks = n_chunks; ca.n_vseq = n_seq * n_chunks; ca.chunk = chunk; ca.halo = halo; ca.lead = lead;
@@ -1372,9 +1362,6 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
                 else hipLaunchKernelGGL((seqik_pipe_kernel<false, 2>), pipe_grid, pipe_blk, 0, stream, a);
             } else if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
             else hipLaunchKernelGGL((seqik_pipe_kernel<false, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
-        } else if (use_pairs_host(a) && fused_pairs) {   // thin wavefronts (<= 32 chains each): the replicas work as lane pairs
-            if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true, true>), grid, blk, 0, stream, a);
-            else hipLaunchKernelGGL((seqik_fused_kernel<false, true>), grid, blk, 0, stream, a);
         } else if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
         else hipLaunchKernelGGL((seqik_fused_kernel<false>), grid, blk, 0, stream, a);
         HIP_TRY(hipGetLastError());
@@ -1595,16 +1582,20 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
     const int W_abs = a.lanes_per_wave < 0 ? -a.lanes_per_wave : a.lanes_per_wave;
     const bool grouped = a.lane_groups != 0 && W_abs <= 8;  // lane_groups(W): the replication is then a multiple of 8
     // Chain queue (SeqikOptions.reserved[1]: 0 = automatic, 1 = never, 2 = whenever full wavefronts are used): pays when the
-    // batch has at least twice as many chains as the GPU has lanes for this kernel (one wavefront per SIMD) -- with fewer
-    // there is nothing to pull and the launch lasts as long as its slowest chain either way (profiles/
-    // r05_generic_queue_bound.json: 0 % at one chain per lane, 21 / 38 / 57 % at 2 / 4 / 8).
+    // batch has several times more chains than the GPU has lanes for this kernel (one wavefront per SIMD) -- with fewer
+    // there is nothing to pull and the launch lasts as long as its slowest chain either way.  Measured on windows of the
+    // shipped recording (bench.py generic_batches, static -> queue): 1 chain per lane 120.2 -> 120.8 ms, 2: 142.8 -> 156.8,
+    // 4: 220.8 -> 191.4 (1.15 x), 8: 358.3 -> 261.1 (1.37 x); the bound from the oracle's pass counts at a constant pass time
+    // says 1.00 / 1.21 / 1.38 / 1.57 (profiles/r05_generic_queue_bound.json) -- the static launch does better than that
+    // model at 2 because its passes get faster as the GPU drains (7.5 us with 128 wavefronts resident, 10.5 with 1 024),
+    // while the queue keeps every wavefront alive to the end.  Automatic: from 4 chains per lane on.
     const int queue_opt = opt ? opt->reserved[1] : 0;
     if (W_abs == 64 && a.lanes_per_wave > 0 && queue_opt != 1) {
         int dev = 0, cus = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         const int64_t slots = (int64_t)cus * 4 * SEQIK_GENERIC_WAVES_PER_EU;   // resident wavefronts of this kernel
-        if (queue_opt == 2 || a.n_chains >= 2 * 64 * slots) {
+        if (queue_opt == 2 || a.n_chains >= 4 * 64 * slots) {
             double *ws = nullptr;
             if (int rc2 = workspace_for(stream, 256, &ws)) return rc2;
             int32_t *counters = reinterpret_cast<int32_t *>(ws);

@@ -494,7 +494,7 @@ def solve_generic(pose, legs, want_fk=True, want_diag=False, device=-1, block_si
     """``seqik_solve_generic`` on host arrays: pose (S, L, N, 5, 3) -> dict(angles (S, L, N, 7),
     fk (S, L, N, 9, 3) or None, status / nfev (S, L, N) or None).  ``chain_queue`` (``SeqikOptions.reserved[1]``): batches
     of full wavefronts on persistent wavefronts whose lanes pull chains from a per-leg counter -- 0 = automatic (at least
-    two chains per lane of the GPU), 1 = never, 2 = whenever full wavefronts are used; same bits either way."""
+    four chains per lane of the GPU), 1 = never, 2 = whenever full wavefronts are used; same bits either way."""
     pose = np.ascontiguousarray(pose, dtype=np.float64)
     if pose.ndim != 5 or pose.shape[3:] != (5, 3):
         raise ValueError(f"pose must have shape (S, L, N, 5, 3), got {pose.shape}")

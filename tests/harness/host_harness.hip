@@ -213,20 +213,27 @@ extern "C" int harness_run_generic_queue(const double *pose, int64_t n_seq, int3
 {
     int rc = seqik::validate_leg_generic(*leg);
     if (rc != SEQIK_OK) return rc;
-    seqik::GenericConst gc;
-    seqik::make_generic_consts(*leg, gc);
-    seqik::LegAffine aff;
-    aff.enabled = 0;
+    // a table of n_legs legs of which only `leg_index` has sequences left (the counters of the others start exhausted):
+    // the lane walks over the exhausted legs to its own, as a lane of the kernel does at the end of a leg
+    std::vector<seqik::GenericLeg> table((size_t)n_legs);
+    std::vector<int32_t> counters((size_t)n_legs, (int32_t)n_seq);
+    for (int l = 0; l < n_legs; ++l) { seqik::make_generic_consts(*leg, table[(size_t)l].gc); table[(size_t)l].aff.enabled = 0; }
+    counters[(size_t)leg_index] = *counter;
     seqik::GenericIO io;
     io.pose = nullptr; io.pose_row = 3; io.pose_frame = 15;
     io.angles = nullptr; io.ang_dof = 1; io.ang_frame = 7;
     io.fk = nullptr; io.status = nullptr; io.nfev = nullptr; io.init = nullptr; io.n_frames = n_frames;
     seqik::GenericQueue q;
-    q.counter = counter; q.n_seq = n_seq; q.n_legs = n_legs; q.leg = leg_index;
+    q.counters = counters.data(); q.n_seq = n_seq; q.n_legs = n_legs; q.first = 0;
+    for (int l = 0; l < 8; ++l) q.order[l] = (uint8_t)l;
+    q.table = table.data();
     q.pose = pose; q.pose_chain = n_frames * 15; q.angles = angles; q.ang_chain = n_frames * 7;
     q.fk = fk; q.status = status; q.nfev = nfev; q.init = init;
-    if (status || nfev) seqik::run_generic<true, false, true>(gc, aff, io, &q);
-    else seqik::run_generic<false, false, true>(gc, aff, io, &q);
+    if (status || nfev) seqik::run_generic<true, false, true>(table[0].gc, table[0].aff, io, &q);
+    else seqik::run_generic<false, false, true>(table[0].gc, table[0].aff, io, &q);
+    *counter = counters[(size_t)leg_index];
+    for (int l = 0; l < n_legs; ++l)   // every other leg was tried exactly once (found exhausted, never revisited)
+        if (l != leg_index && counters[(size_t)l] != (int32_t)n_seq + 1) return -99;
     return SEQIK_OK;
 }
 

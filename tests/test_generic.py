@@ -235,14 +235,14 @@ def test_chain_queue_instantiation_equals_chain_by_chain_runs(oracle, host_harne
 @pytest.mark.gpu
 def test_chain_queue_on_gpu_equals_the_static_launch(hiplib, oracle):
     """seqik_generic_queue_kernel == seqik_generic_kernel bit for bit (angles, FK, status, nfev): a small batch with the
-    queue forced (fewer wavefronts than the GPU holds), and a batch with more than two chains per lane of the GPU, where
+    queue forced (fewer wavefronts than the GPU holds), and a batch with more than four chains per lane of the GPU, where
     the queue is the AUTOMATIC choice and the persistent wavefronts really pull (one wavefront per SIMD); sampled chains
     against the oracle."""
     z = load_golden("generic_rf_100")
     legs = ["RF", "LF"]
     params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
     rec = np.stack([z[f"{l}_pose"] for l in legs])                               # (2, 100, 5, 3)
-    for S, T, mode in ((300, 16, 2), (70_000, 3, 0)):
+    for S, T, mode in ((300, 16, 2), (135_000, 2, 0)):
         offs = (np.arange(S) * 7) % (100 - T)
         pose = np.ascontiguousarray(rec[:, offs[:, None] + np.arange(T)[None, :]].transpose(1, 0, 2, 3, 4))   # (S, 2, T, 5, 3)
         static = hiplib.solve_generic(pose, params, want_diag=True, chain_queue=1)
