@@ -256,6 +256,20 @@ def cpu_baseline(pose, legs, body, n_seq_sample, python_pool=True):
     return out
 
 
+_STREAMS = []
+
+
+def stream_pool(n):
+    """The first n streams of ONE pool per process (the current stream first): every batch of a run launches on the same
+    streams, so the process never holds more streams than the deepest pipeline asks for -- the library keeps a hand-off
+    workspace per (device, stream), at most 16 of them, and the hardware queues are as few."""
+    if not _STREAMS:
+        _STREAMS.append(torch.cuda.current_stream())
+    while len(_STREAMS) < n:
+        _STREAMS.append(torch.cuda.Stream())
+    return list(_STREAMS[:n])
+
+
 class Batch:
     """One rank's batch resident in HBM (planar layout) + the launch of one step on a given stream."""
 
@@ -263,17 +277,17 @@ class Batch:
         """`like`: another Batch of the SAME key points (its device copy and streams are shared, only FK buffers are added)."""
         self.params, self.args = params, args
         self.pipeline = max(0, getattr(args, "stage_pipeline", 0)) if pipeline is None else pipeline
+        self.streams = stream_pool(n_streams)
+        self.main = self.streams[0]
+        self.tail_from = None
         if like is not None:
-            self.S, self.L, self.T, self.layout, self.d_pose, self.main = like.S, like.L, like.T, like.layout, like.d_pose, like.main
-            self.streams = list(like.streams[:n_streams]) + [torch.cuda.Stream() for _ in range(max(0, n_streams - len(like.streams)))]
+            self.S, self.L, self.T, self.layout, self.d_pose = like.S, like.L, like.T, like.layout, like.d_pose
             self.d_fks = list(like.d_fks[:n_streams])
         else:
             self.S, self.L, self.T = pose.shape[:3]
             self.layout = _lib.planar_layout(self.T)
             # planar device layout (include/seqik.h, SeqikLayout): pose [S][L][5][T][3], angles [S][L][7][T]
             self.d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
-            self.main = torch.cuda.current_stream()
-            self.streams = [self.main] + [torch.cuda.Stream() for _ in range(max(0, n_streams - 1))]
             self.d_fks = []
         while len(self.d_fks) < len(self.streams):
             self.d_fks.append(torch.zeros((self.S, self.L, self.T, 9, 3), dtype=torch.float64, device="cuda"))
@@ -282,24 +296,58 @@ class Batch:
     def angle_buffer(self):
         return torch.zeros((self.S, self.L, 7, self.T), dtype=torch.float64, device="cuda")
 
-    def launch(self, i, buf, events=None, n_streams=None):
+    def launch(self, i, buf, events=None, n_streams=None, tail=False):
         k = i % (n_streams or len(self.streams))
         stream = self.streams[k]
         a = self.args
         # ONE C-ABI call = the whole hot path; the library records the given HIP events around its kernels
+        # (steps behind `tail_from` -- the last, partial round of a deep pipeline, which runs on a draining GPU -- are launched
+        # with the library's own kernel choice: for a share that is the stage pipeline, whose launch is over in half the time)
+        pipe = 0 if tail else self.pipeline
         _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.T, self.params, buf.data_ptr(),
                               self.d_fks[k].data_ptr(), stream=stream.cuda_stream, block_size=a.block, layout=self.layout,
                               lanes_per_wave=a.lanes_per_wave, staged=int(a.staged), interleave_legs=a.interleave_legs,
-                              pipeline=self.pipeline,
+                              pipeline=pipe,
                               stage_events=[e.cuda_event for e in events] if events else None)
         return stream
 
 
-DEPTH_CANDIDATES = ((3, 0), (8, 1), (12, 1), (16, 1))   # (steps in flight, SeqikOptions.reserved[3]); see parse(): --streams 0
+def depth_candidates(steps):
+    """(steps in flight, SeqikOptions.reserved[3], tail_from) the run calibrates among (parse(): --streams 0).  Beside the fixed
+    depths: the BALANCED depth -- `steps` cut into the fewest rounds of at most 16, all of the same size (20 steps: 2 x 10
+    instead of 16 + 4) -- and depth 16 with the last, partial round (at most 8 steps, which run on a draining GPU) launched with
+    the library's own kernel choice instead of the lane-per-chain kernels."""
+    cands = [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
+    rounds = -(-steps // 16)
+    balanced = -(-steps // rounds)
+    if balanced > 3 and balanced not in (8, 12, 16):
+        cands.append((balanced, 1, None))
+    rest = steps % 16
+    if steps > 16 and 0 < rest <= 8:
+        cands.append((16, 1, steps - rest))
+    return cands
+
+
+DEPTH_CANDIDATES = depth_candidates(10 ** 6)   # the fixed depths (a long run has no partial round worth a special case)
+
+
+def setup_streams(batch, bufs, n_streams):
+    """SETUP, not warm-up: the library allocates a stream's stage hand-off workspace (96 B per leg-frame) at the first launch
+    it sees on that stream, with a device-wide synchronisation; one launch per stream that has not carried this batch size
+    yet keeps those allocations out of every timed region, however few warm-up steps the caller asks for."""
+    done = getattr(batch, "_streams_set_up", 0)
+    if done >= n_streams:
+        return
+    for k in range(done, n_streams):
+        with torch.cuda.stream(batch.streams[k]):
+            batch.launch(k, bufs[k % len(bufs)], n_streams=n_streams)
+    torch.cuda.synchronize()
+    batch._streams_set_up = n_streams
 
 
 def timed_steps(batch, bufs, steps, n_streams, warmup=2):
     """`steps` launches round-robin over `n_streams` streams; returns seconds (host clock around a full drain)."""
+    setup_streams(batch, bufs, n_streams)
     for i in range(warmup):
         with torch.cuda.stream(batch.streams[i % n_streams]):
             batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams)
@@ -307,7 +355,7 @@ def timed_steps(batch, bufs, steps, n_streams, warmup=2):
     t0 = time.perf_counter()
     for i in range(steps):
         with torch.cuda.stream(batch.streams[i % n_streams]):
-            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams)
+            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams, tail=batch.tail_from is not None and i >= batch.tail_from)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -1015,7 +1063,7 @@ def main():
     S = pose.shape[0]
     L = len(legs)
     explicit_depth = args.streams > 0
-    first_depth = (args.streams, max(0, args.stage_pipeline)) if explicit_depth else DEPTH_CANDIDATES[0]
+    first_depth = (args.streams, max(0, args.stage_pipeline)) if explicit_depth else DEPTH_CANDIDATES[0][:2]
     batch = Batch(pose, params, args, first_depth[0], pipeline=first_depth[1])
     units_per_step = batch.units  # leg-frames per step on this rank
     main_stream = batch.main
@@ -1034,15 +1082,16 @@ def main():
         one), bracketed by barrier + synchronize.  Returns (max over ranks, this rank's) seconds."""
         nb = len(bufs)
 
-        def step(i, evs=None):
+        def step(i, evs=None, tail=False):
             b = i % nb
             with torch.cuda.stream(bt.streams[i % len(bt.streams)]):
                 if g:
                     g.wait_buffer(b)  # the gather that last read this buffer has completed
-                bt.launch(i, bufs[b], evs)
+                bt.launch(i, bufs[b], evs, tail=tail)
                 if g:
                     g.submit(b, bufs[b])
 
+        setup_streams(bt, bufs, len(bt.streams))     # allocations of the library, once per stream: outside every timed region
         for i in range(warmup):
             step(i)
         if g:
@@ -1050,7 +1099,7 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, events[i] if events else None)
+            step(i, events[i] if events else None, tail=bt.tail_from is not None and i >= bt.tail_from)
         if g:
             g.drain()
         sync_all()
@@ -1078,9 +1127,10 @@ def main():
                                      "two synchronisations, fill and drain included); (streams, stage_pipeline): stage_pipeline 0 = the "
                                      "library's choice for ONE call, 1 = lane-per-chain kernels"}
         best = None
-        for n_st, pipe in DEPTH_CANDIDATES:
+        for n_st, pipe, tail_from in depth_candidates(args.steps):
             try:
                 bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch)
+                bt.tail_from = tail_from
                 bufs = buffers_for(bt)
                 g = None
                 if use_dist:
@@ -1102,14 +1152,14 @@ def main():
                 okt = torch.tensor([ok_flag], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
                 ok_flag = float(okt.item())
-            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe,
+            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from,
                                                     "ms_per_step": ms if ok_flag > 0.5 and ms != float("inf") else None})
             if ok_flag > 0.5 and (best is None or ms < best[0]):
-                best = (ms, n_st, pipe, bt)
+                best = (ms, n_st, pipe, bt, tail_from)
             del bufs
         if best is None:
             raise SystemExit("bench: no pipeline depth could be run")
-        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2]}
+        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2], "tail_from": best[4]}
         batch = best[3]
         del batch.d_fks[len(batch.streams):]
         torch.cuda.empty_cache()
@@ -1191,7 +1241,9 @@ def main():
     del chk_ang, chk_fk
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
-    stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(args.steps)])
+    # (steps of a latency-kernel tail run another kernel: the dominant kernel's figures come from the steps in front of it)
+    n_main = batch.tail_from if batch.tail_from is not None else args.steps
+    stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(n_main)])
     mean_stage_ms = stage_ms.mean(0)
     ms_per_step = elapsed / args.steps * 1e3
     if args.staged:
@@ -1402,17 +1454,20 @@ def main():
                             "a time (the library's own kernel choice), what a rank gets when every step waits for the one before",
                     "by_n_gpus": {}}
             for n in (2, 4, 8):
-                best = None
-                for n_st, pipe in (DEPTH_CANDIDATES if not explicit_depth else ((n_streams, batch.pipeline),)):
+                best, tried = None, []
+                for n_st, pipe, tail_from in (depth_candidates(args.steps) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
                     sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
+                    sub.tail_from = tail_from
                     bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
                     k = args.steps             # the same region as the headline's: fill and drain of the pipeline included
                     dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=args.warmup)
-                    row = {"streams": n_st, "stage_pipeline": pipe, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                    row = {"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
                            "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
+                    tried.append({"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from, "ms_per_step": row["ms_per_step"]})
                     if best is None or row["ms_per_step"] < best["ms_per_step"]:
                         best = row
                     del sub, bufs
+                best["candidates"] = tried
                 # the floor of a share: ONE launch at a time, no second step to overlap with (what a rank can do at best when
                 # every step has to wait for the one before it)
                 sub = Batch(pose[: S // n], params, args, 1, pipeline=0)     # ONE call: the library's own choice of kernel

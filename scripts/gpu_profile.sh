@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-extras $*"   # default --steps / --warmup: the command the driver runs
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $*"   # --steps / --warmup of the command the driver runs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- $BENCH > "$OUT/${TAG}_stats.log" 2>&1 || exit 1
 # counters in their own runs (no tracing options), one pass each
 rocprofv3 --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --output-format csv -d "$OUT/${TAG}_fetch" -- $BENCH > "$OUT/${TAG}_fetch.log" 2>&1 || exit 1
