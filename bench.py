@@ -520,8 +520,16 @@ def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index
         if not os.path.exists(tpath):
             continue
         tj = json.load(open(tpath))
-        if tj.get("units_per_launch") != units_per_step or tj.get("variant") != variant:
+        if tj.get("variant") != variant or not tj.get("units_per_launch"):
             continue
+        # A rank of an N > 1 run (or a --frames run) solves a SHARE of the same synthetic distribution with the same kernel:
+        # the per-launch counters are scaled by the number of leg-frames (the instruction mix per leg-frame is a property of
+        # the data distribution and the kernel; `pmc_scaled_from_units` says when that was done)
+        scale = units_per_step / float(tj["units_per_launch"])
+        if scale != 1.0:
+            tj = {k: (v * scale if isinstance(v, (int, float)) and k.endswith("_per_launch") and k != "units_per_launch" else v)
+                  for k, v in tj.items()}
+            tj["scaled_from_units"] = tj["units_per_launch"]
         matches = tj.get("csrc_sha256") == _lib.csrc_sha256()
         traffic = tj.get(f"{key}_hbm_bytes_per_launch")
         if not matches:   # counters of another build say nothing about this one
@@ -558,6 +566,8 @@ def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index
                             for i in range(len(names)))
                 fp64 = {"flops_per_step": flops, "f64_insts_per_step": {c: sum(vs) for c, vs in mix.items()},
                         "note": "lane share taken from all VALU instructions (SQ_THREAD_CYCLES_VALU)"}
+        if fp64 is not None and tj.get("scaled_from_units"):
+            fp64["pmc_scaled_from_units"] = tj["scaled_from_units"]
         return traffic, valu, fp64, True, os.path.basename(tpath)
     return None, None, None, None, None
 

@@ -230,3 +230,25 @@ def test_output_side_converters_and_resampling():
     assert data.SKELETON[:2] == ["base_anten_R", "tip_anten_R"] and len(data.SKELETON) == 17
     assert "RF_leg" not in data.get_pts2align("rec_RF_x") and "LF_leg" in data.get_pts2align("rec_RF_x")
     assert set(data.get_pts2align("rec_RLF")) == {"R_head", "Thorax", "L_head"} and "RF_leg" in data.PTS2ALIGN
+
+
+def test_bench_depth_candidates_cover_the_measured_region():
+    """bench.py calibrates how many steps it keeps in flight over exactly the region it measures: the candidate
+    list is a function of the step count -- the fixed depths, the balanced depth (fewest rounds of at most 16, equal size) and
+    depth 16 with a short last round on the latency kernel; never more than 16 (more streams than hardware queues collapse)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
+    c20 = bench.depth_candidates(20)
+    assert c20[:4] == [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
+    assert (10, 1, None) in c20 and (16, 1, 16) in c20          # 2 x 10; 16 + a tail of 4 on the library's kernel choice
+    assert (16, 1, 96) in bench.depth_candidates(100) and (15, 1, None) in bench.depth_candidates(100)
+    for k in (1, 4, 6, 16, 17, 20, 32, 33, 100, 1000):
+        for streams, pipe, tail in bench.depth_candidates(k):
+            assert 1 <= streams <= 16 and pipe in (0, 1)
+            assert tail is None or (streams == 16 and 16 <= tail < k and k - tail <= 8)
+    assert all(t is None for _, _, t in bench.depth_candidates(16)) and all(t is None for _, _, t in bench.depth_candidates(4))

@@ -49,13 +49,16 @@ def main():
     ap.add_argument("--seqs", type=int, default=160, help="recordings per leg in the one-lane-per-chain launches (8 x seqs >= 1024)")
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--queue", action="store_true",
+                    help="every one-lane-per-chain launch also on the chain queue (SeqikOptions.reserved[1] = 2): same bits wanted")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     c_oracle.lib()
     bad, n_lf, t_cpu, t_gpu = [], 0, 0.0, 0.0
     status_hist = np.zeros(5, dtype=np.int64)
     nfev_max = 0
-    launches = {"lane groups (thin waves)": 0, "one lane per chain": 0}
+    launches = {"lane groups (thin waves)": 0, "one lane per chain": 0, "chain queue": 0}
+    bad_queue = []
     for g0 in range(0, a.legs, 8):
         legs = [generic_case(rng, a.frames) for _ in range(8)]
         # recordings: the leg's own nasty poses first, then the poses of other made-up legs (any key points are a valid input)
@@ -79,6 +82,11 @@ def main():
         out = _lib.solve_generic(pose, params, want_fk=True, want_diag=True)
         t_gpu += time.perf_counter() - t0
         launches["one lane per chain" if S * 8 >= 1024 else "lane groups (thin waves)"] += 1
+        if a.queue and S * 8 >= 1024:
+            outq = _lib.solve_generic(pose, params, want_fk=True, want_diag=True, chain_queue=2)
+            launches["chain queue"] += 1
+            if not all(np.array_equal(outq[k], out[k]) for k in ("angles", "fk", "status", "nfev")):
+                bad_queue.append(g0)
         for idx, r in enumerate(refs):
             s, li = divmod(idx, 8)
             ok = (np.array_equal(out["angles"][s, li], r["angles"]) and np.array_equal(out["fk"][s, li], r["fk"]) and
@@ -90,6 +98,7 @@ def main():
         n_lf += S * 8 * a.frames
     print(json.dumps({"legs": a.legs, "frames_per_recording": a.frames, "leg_frames": n_lf, "mismatching_recordings": len(bad),
                       "first_mismatches": bad[:10], "launches": launches,
+                      "chain_queue_launches_differing_from_the_static_launch": len(bad_queue),
                       "status_histogram": {int(i): int(v) for i, v in enumerate(status_hist)}, "max_nfev": nfev_max,
                       "cpu_oracle_seconds": t_cpu, "gpu_seconds_incl_transfers": t_gpu}))
 
