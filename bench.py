@@ -279,7 +279,7 @@ class Batch:
         self.pipeline = max(0, getattr(args, "stage_pipeline", 0)) if pipeline is None else pipeline
         self.streams = stream_pool(n_streams)
         self.main = self.streams[0]
-        self.tail_from = None
+        self.lat_range = None     # [lo, hi) steps of a timed region launched with the library's own kernel choice (depth_candidates)
         if like is not None:
             self.S, self.L, self.T, self.layout, self.d_pose = like.S, like.L, like.T, like.layout, like.d_pose
             self.d_fks = list(like.d_fks[:n_streams])
@@ -301,8 +301,8 @@ class Batch:
         stream = self.streams[k]
         a = self.args
         # ONE C-ABI call = the whole hot path; the library records the given HIP events around its kernels
-        # (steps behind `tail_from` -- the last, partial round of a deep pipeline, which runs on a draining GPU -- are launched
-        # with the library's own kernel choice: for a share that is the stage pipeline, whose launch is over in half the time)
+        # (`tail`: a step of `lat_range` -- the partial round of a deep pipeline -- is launched with the library's own kernel
+        # choice: for a share that is the stage pipeline, whose launch is over in half the time)
         pipe = 0 if tail else self.pipeline
         _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.T, self.params, buf.data_ptr(),
                               self.d_fks[k].data_ptr(), stream=stream.cuda_stream, block_size=a.block, layout=self.layout,
@@ -313,10 +313,12 @@ class Batch:
 
 
 def depth_candidates(steps):
-    """(steps in flight, SeqikOptions.reserved[3], tail_from) the run calibrates among (parse(): --streams 0).  Beside the fixed
-    depths: the BALANCED depth -- `steps` cut into the fewest rounds of at most 16, all of the same size (20 steps: 2 x 10
-    instead of 16 + 4) -- and depth 16 with the last, partial round (at most 8 steps, which run on a draining GPU) launched with
-    the library's own kernel choice instead of the lane-per-chain kernels."""
+    """(steps in flight, SeqikOptions.reserved[3], latency-kernel steps [lo, hi) or None) the run calibrates among (parse():
+    --streams 0).  Beside the fixed depths: the BALANCED depth -- `steps` cut into the fewest rounds of at most 16, all of the
+    same size (20 steps: 2 x 10 instead of 16 + 4) -- and depth 16 with the partial round (at most 8 steps) launched with the
+    library's own kernel choice instead of the lane-per-chain kernels: it is the LAST round, which runs on a draining GPU, and
+    the stage pipeline's launch is over in half the time (1/8 share, 20 steps: 2.9 -> 2.3 ms per step; the same launches put
+    FIRST, to make room early, lose: 3.1; profiles/r05_depth_calibration_k20_k100.jsonl)."""
     cands = [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
     rounds = -(-steps // 16)
     balanced = -(-steps // rounds)
@@ -324,8 +326,12 @@ def depth_candidates(steps):
         cands.append((balanced, 1, None))
     rest = steps % 16
     if steps > 16 and 0 < rest <= 8:
-        cands.append((16, 1, steps - rest))
+        cands.append((16, 1, (steps - rest, steps)))
     return cands
+
+
+def in_lat_range(batch, i):
+    return batch.lat_range is not None and batch.lat_range[0] <= i < batch.lat_range[1]
 
 
 DEPTH_CANDIDATES = depth_candidates(10 ** 6)   # the fixed depths (a long run has no partial round worth a special case)
@@ -355,7 +361,7 @@ def timed_steps(batch, bufs, steps, n_streams, warmup=2):
     t0 = time.perf_counter()
     for i in range(steps):
         with torch.cuda.stream(batch.streams[i % n_streams]):
-            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams, tail=batch.tail_from is not None and i >= batch.tail_from)
+            batch.launch(i, bufs[i % len(bufs)], n_streams=n_streams, tail=in_lat_range(batch, i))
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -1109,7 +1115,7 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i, events[i] if events else None, tail=bt.tail_from is not None and i >= bt.tail_from)
+            step(i, events[i] if events else None, tail=in_lat_range(bt, i))
         if g:
             g.drain()
         sync_all()
@@ -1137,10 +1143,10 @@ def main():
                                      "two synchronisations, fill and drain included); (streams, stage_pipeline): stage_pipeline 0 = the "
                                      "library's choice for ONE call, 1 = lane-per-chain kernels"}
         best = None
-        for n_st, pipe, tail_from in depth_candidates(args.steps):
+        for n_st, pipe, lat in depth_candidates(args.steps):
             try:
                 bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch)
-                bt.tail_from = tail_from
+                bt.lat_range = lat
                 bufs = buffers_for(bt)
                 g = None
                 if use_dist:
@@ -1162,14 +1168,14 @@ def main():
                 okt = torch.tensor([ok_flag], dtype=torch.float64, device=coll_dev)
                 dist.all_reduce(okt, op=dist.ReduceOp.MIN)
                 ok_flag = float(okt.item())
-            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from,
+            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat,
                                                     "ms_per_step": ms if ok_flag > 0.5 and ms != float("inf") else None})
             if ok_flag > 0.5 and (best is None or ms < best[0]):
-                best = (ms, n_st, pipe, bt, tail_from)
+                best = (ms, n_st, pipe, bt, lat)
             del bufs
         if best is None:
             raise SystemExit("bench: no pipeline depth could be run")
-        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2], "tail_from": best[4]}
+        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2], "latency_kernel_steps": best[4]}
         batch = best[3]
         del batch.d_fks[len(batch.streams):]
         torch.cuda.empty_cache()
@@ -1251,9 +1257,9 @@ def main():
     del chk_ang, chk_fk
 
     # per-kernel durations from the HIP events recorded on the launch stream inside the timed region
-    # (steps of a latency-kernel tail run another kernel: the dominant kernel's figures come from the steps in front of it)
-    n_main = batch.tail_from if batch.tail_from is not None else args.steps
-    stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in range(n_main)])
+    # (the steps of `lat_range` run another kernel: the dominant kernel's figures come from the other steps)
+    main_steps = [i for i in range(args.steps) if not in_lat_range(batch, i)]
+    stage_ms = np.array([[ev[i][k].elapsed_time(ev[i][k + 1]) for k in range(4)] for i in main_steps])
     mean_stage_ms = stage_ms.mean(0)
     ms_per_step = elapsed / args.steps * 1e3
     if args.staged:
@@ -1465,15 +1471,15 @@ def main():
                     "by_n_gpus": {}}
             for n in (2, 4, 8):
                 best, tried = None, []
-                for n_st, pipe, tail_from in (depth_candidates(args.steps) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
+                for n_st, pipe, lat in (depth_candidates(args.steps) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
                     sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
-                    sub.tail_from = tail_from
+                    sub.lat_range = lat
                     bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
                     k = args.steps             # the same region as the headline's: fill and drain of the pipeline included
                     dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=args.warmup)
-                    row = {"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                    row = {"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
                            "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
-                    tried.append({"streams": n_st, "stage_pipeline": pipe, "tail_from": tail_from, "ms_per_step": row["ms_per_step"]})
+                    tried.append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": row["ms_per_step"]})
                     if best is None or row["ms_per_step"] < best["ms_per_step"]:
                         best = row
                     del sub, bufs

@@ -1,5 +1,7 @@
 set -o pipefail
-mkdir -p gpurun_out/r05k
-timeout -k 10 400 python tests/tools/soak_parity.py --cases 40000 --seed 105 > gpurun_out/r05k/soak_parity.json 2> gpurun_out/r05k/soak_parity.err; echo "soak parity rc=$?"; tail -c 600 gpurun_out/r05k/soak_parity.json
-timeout -k 10 400 python tests/tools/soak_chunks.py --cases 3000 --seed 106 > gpurun_out/r05k/soak_chunks.json 2> gpurun_out/r05k/soak_chunks.err; echo "soak chunks rc=$?"; tail -c 600 gpurun_out/r05k/soak_chunks.json
-timeout -k 10 400 python tests/tools/soak_generic.py --legs 256 --seed 107 --queue > gpurun_out/r05k/soak_generic.json 2> gpurun_out/r05k/soak_generic.err; echo "soak generic rc=$?"; tail -c 800 gpurun_out/r05k/soak_generic.json
+mkdir -p gpurun_out/r05m
+for FR in 125000 250000 500000; do
+  timeout -k 10 300 python bench.py --frames $FR --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+b=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({'frames': $FR, 'steps': 20, 'ms_per_step': round(b['ms_per_step'],3), 'cal': [(c['streams'], c['stage_pipeline'], c['latency_kernel_steps'], round(c['ms_per_step'],3)) for c in b['config']['depth_calibration']['candidates']], 'chosen': b['config']['depth_calibration']['chosen']}))"
+done | tee gpurun_out/r05m/k20_depths_head.jsonl

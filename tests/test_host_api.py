@@ -245,10 +245,11 @@ def test_bench_depth_candidates_cover_the_measured_region():
     assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
     c20 = bench.depth_candidates(20)
     assert c20[:4] == [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
-    assert (10, 1, None) in c20 and (16, 1, 16) in c20          # 2 x 10; 16 + a tail of 4 on the library's kernel choice
-    assert (16, 1, 96) in bench.depth_candidates(100) and (15, 1, None) in bench.depth_candidates(100)
+    # 2 x 10; 16 + a last, partial round of 4 on the library's kernel choice
+    assert (10, 1, None) in c20 and (16, 1, (16, 20)) in c20 and len(c20) == 6
+    assert (16, 1, (96, 100)) in bench.depth_candidates(100) and (15, 1, None) in bench.depth_candidates(100)
     for k in (1, 4, 6, 16, 17, 20, 32, 33, 100, 1000):
-        for streams, pipe, tail in bench.depth_candidates(k):
+        for streams, pipe, lat in bench.depth_candidates(k):
             assert 1 <= streams <= 16 and pipe in (0, 1)
-            assert tail is None or (streams == 16 and 16 <= tail < k and k - tail <= 8)
+            assert lat is None or (streams == 16 and 0 <= lat[0] < lat[1] <= k and lat[1] - lat[0] <= 8)
     assert all(t is None for _, _, t in bench.depth_candidates(16)) and all(t is None for _, _, t in bench.depth_candidates(4))
