@@ -273,9 +273,12 @@ def stream_pool(n):
 class Batch:
     """One rank's batch resident in HBM (planar layout) + the launch of one step on a given stream."""
 
-    def __init__(self, pose, params, args, n_streams, pipeline=None, like=None):
-        """`like`: another Batch of the SAME key points (its device copy and streams are shared, only FK buffers are added)."""
+    def __init__(self, pose, params, args, n_streams, pipeline=None, like=None, s_pad=None):
+        """`like`: another Batch of the SAME key points (its device copy and streams are shared, only FK buffers are added).
+        `s_pad`: sequences the ANGLE buffers are allocated for (>= this rank's own): the shares of the fixed problem differ by
+        one sequence between ranks (15 625 = 8 x 1 953 + 1), and the gather moves equal blocks from every rank."""
         self.params, self.args = params, args
+        self.s_pad = s_pad if s_pad is not None else (like.s_pad if like is not None else None)
         self.pipeline = max(0, getattr(args, "stage_pipeline", 0)) if pipeline is None else pipeline
         self.streams = stream_pool(n_streams)
         self.main = self.streams[0]
@@ -294,7 +297,7 @@ class Batch:
         self.units = self.S * self.L * self.T
 
     def angle_buffer(self):
-        return torch.zeros((self.S, self.L, 7, self.T), dtype=torch.float64, device="cuda")
+        return torch.zeros((max(self.S, self.s_pad or 0), self.L, 7, self.T), dtype=torch.float64, device="cuda")
 
     def launch(self, i, buf, events=None, n_streams=None, tail=False):
         k = i % (n_streams or len(self.streams))
@@ -1080,7 +1083,11 @@ def main():
     L = len(legs)
     explicit_depth = args.streams > 0
     first_depth = (args.streams, max(0, args.stage_pipeline)) if explicit_depth else DEPTH_CANDIDATES[0][:2]
-    batch = Batch(pose, params, args, first_depth[0], pipeline=first_depth[1])
+    # every rank's angle blocks have the size of the LARGEST share (the gather moves equal blocks; the solver fills this
+    # rank's own sequences, the padding -- at most one sequence -- stays zero)
+    s_pad = max(sharding.rank_share(S_total, world, r, args.scaling)[1] - sharding.rank_share(S_total, world, r, args.scaling)[0]
+                for r in range(world))
+    batch = Batch(pose, params, args, first_depth[0], pipeline=first_depth[1], s_pad=s_pad)
     units_per_step = batch.units  # leg-frames per step on this rank
     main_stream = batch.main
     # final joint-angle gather: chosen below (choose_gather), once timed_region exists
@@ -1373,7 +1380,9 @@ def main():
                 # the other scaling mode beside the headline: strong = config 3 literally (the fixed 1M-frame problem split
                 # over the ranks), weak = 1M frames per GPU
                 pose2, _, _, _, units_all2 = workload_for(other_scaling)
-                b2 = Batch(pose2, params, args, n_streams, pipeline=batch.pipeline)
+                pad2 = max(sharding.rank_share(S_total, world, r, other_scaling)[1] - sharding.rank_share(S_total, world, r, other_scaling)[0]
+                           for r in range(world))
+                b2 = Batch(pose2, params, args, n_streams, pipeline=batch.pipeline, s_pad=pad2)
                 bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
                 g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=headline_kind)
                 k2 = max(4, min(40, args.steps))

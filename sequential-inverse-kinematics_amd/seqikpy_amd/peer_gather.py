@@ -166,6 +166,13 @@ def make_gather(dist, world: int, rank: int, like, n_buffers: int, dst: int = 0,
     variable SEQIK_GATHER or "auto" (peer writes for device buffers, point-to-point of the process group otherwise).
     Returns (pipeline, description)."""
     prefer = prefer or os.environ.get("SEQIK_GATHER", "auto")
+    # both pipelines move EQUAL blocks (one receive buffer shape / one slot size for every peer): a rank with another block
+    # shape would make the point-to-point sizes disagree -- a hang on RCCL -- so that is refused here, on every rank alike
+    if world > 1:
+        shapes = [None] * world
+        dist.all_gather_object(shapes, (tuple(like.shape), str(like.dtype)))
+        if any(sh != shapes[0] for sh in shapes):
+            raise ValueError(f"make_gather: the ranks' angle blocks differ in shape ({shapes}); pad them to the largest share")
     # (gloo process groups over device buffers are the one-GPU rehearsal: the peer path works there too -- the flags
     # then travel over gloo -- and RCCL's stand-in would stage every block through the host)
     want_peer = prefer == "peer" or (prefer == "auto" and like.is_cuda)

@@ -445,13 +445,15 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"   # the calibration a real RCCL job runs before its headline (choose_gather)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                        "--frames", "8192"], env=env, capture_output=True, text=True, timeout=800)
+                        "--frames", "8256"], env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["roofline"]["frac"] > 0
-    assert "FIXED problem" in b["config"]["workload"] and b["config"]["frames_total"] == 8192
-    assert b["config"]["sequences_per_gpu"] == 64 and b["config"]["leg_frames_per_step_all_ranks"] == 8192 * 6
+    assert "FIXED problem" in b["config"]["workload"] and b["config"]["frames_total"] == 8256
+    # 129 sequences: the shares are UNEVEN (65 + 64), as those of the real problem are (15 625 = 8 x 1 953 + 1); the gather
+    # moves equal, padded blocks
+    assert b["config"]["sequences_per_gpu"] == 65 and b["config"]["leg_frames_per_step_all_ranks"] == 8256 * 6
     cal = b["config"]["gather_calibration"]
     assert cal["chosen"] in ("rccl", "peer") and cal["rccl"]["ms_per_step"] > 0 and ("ms_per_step" in cal["peer"] or "unavailable" in cal["peer"])
     assert ("peer writes" in b["config"]["gather"]) == (cal["chosen"] == "peer")
@@ -460,13 +462,13 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert m["rank_ms_per_step"]["min"] <= m["rank_ms_per_step"]["max"]
     assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"])
     assert "peer writes" in m["gather_compare"]["peer"]["ran_as"]
-    assert m["weak"]["sequences_per_gpu"] == 128 and m["weak"]["leg_frames_per_step_all_ranks"] == 2 * 8192 * 6
+    assert m["weak"]["sequences_per_gpu"] == 129 and m["weak"]["leg_frames_per_step_all_ranks"] == 2 * 8256 * 6
     assert len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 2 and m["weak"]["efficiency_vs_n1"] > 0
-    assert m["n1_reference"]["leg_frames_per_step"] == 8192 * 6 and m["n1_reference"]["value"] > 0
+    assert m["n1_reference"]["leg_frames_per_step"] == 8256 * 6 and m["n1_reference"]["value"] > 0
     assert abs(m["efficiency_vs_n1"] - b["value"] / (2 * m["n1_reference"]["value"])) < 1e-9
-    assert sum(m["one_recording"]["frames_per_rank"]) == 8192 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
+    assert sum(m["one_recording"]["frames_per_rank"]) == 8256 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
     assert m["one_recording"]["n1_reference_ms"] > 0 and m["one_recording"]["efficiency_vs_n1"] > 0
-    assert abs(b["value"] - 8192 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]       # the fixed problem / time
+    assert abs(b["value"] - 8256 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]       # the fixed problem / time
 
 
 @pytest.mark.gpu
@@ -484,19 +486,19 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "1",
-                        "--frames", "32000"], env=env, capture_output=True, text=True, timeout=800)
+                        "--frames", "32064"], env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
     b = json.loads(lines[0])
     m = b["multi_gpu"]
     assert b["n_gpus"] == 4 and sorted(r_["rank"] for r_ in m["ranks_seen"]) == [0, 1, 2, 3]
     assert b["scaling"] == "strong" and "FIXED problem" in b["config"]["workload"] and "4 ranks" in b["config"]["workload"]
-    assert b["config"]["frames_total"] == 32000 and b["config"]["sequences_per_gpu"] == 125
-    assert abs(b["value"] - 32000 * 6 * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) < 1e-6 * b["value"]
+    assert b["config"]["frames_total"] == 32064 and b["config"]["sequences_per_gpu"] == 126      # 501 = 126 + 3 x 125
+    assert abs(b["value"] - 32064 * 6 * b["steps"] / (b["ms_per_step"] * 1e-3 * b["steps"])) < 1e-6 * b["value"]
     assert {"peer", "rccl", "no_gather"} <= set(m["gather_compare"]) and "weak" in m and "error" not in m["weak"]
-    assert m["weak"]["leg_frames_per_step_all_ranks"] == 4 * 32000 * 6 and len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 4
+    assert m["weak"]["leg_frames_per_step_all_ranks"] == 4 * 32064 * 6 and len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 4
     assert "error" not in m["n1_reference"] and m["efficiency_vs_n1"] > 0 and m["speedup_vs_n1"] > 0
-    assert sum(m["one_recording"]["frames_per_rank"]) == 32000 and "error" not in m["one_recording"]
+    assert sum(m["one_recording"]["frames_per_rank"]) == 32064 and "error" not in m["one_recording"]
     assert b["config"]["gather_calibration"]["chosen"] in ("rccl", "peer")
 
 
@@ -691,3 +693,57 @@ def test_frame_sharding_under_a_one_rank_rccl_group_with_the_default_device(hipl
         assert np.array_equal(out["angles"], one["angles"]) and np.array_equal(out["fk"], one["fk"])
     finally:
         dist.destroy_process_group()
+
+
+def _uneven_gather_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    from seqikpy_amd import peer_gather, sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S_total = 7                                                  # 7 sequences over 2 / 3 ranks: shares differ by one
+    lo, hi, _ = sharding.rank_share(S_total, world, rank, "strong")
+    own = torch.full((hi - lo, 2, 7, 4), float(rank + 1), dtype=torch.float64)
+    refused = False
+    try:
+        peer_gather.make_gather(dist, world, rank, own, n_buffers=2, prefer="rccl")
+    except ValueError as exc:
+        refused = "differ in shape" in str(exc)
+    # the remedy bench.py uses: every rank's block padded to the largest share
+    s_pad = max(sharding.rank_share(S_total, world, r, "strong")[1] - sharding.rank_share(S_total, world, r, "strong")[0] for r in range(world))
+    bufs = [torch.zeros((s_pad, 2, 7, 4), dtype=torch.float64) for _ in range(2)]
+    pipe, how = peer_gather.make_gather(dist, world, rank, bufs[0], n_buffers=2, prefer="rccl")
+    for step in range(3):
+        b = step % 2
+        pipe.wait_buffer(b)
+        bufs[b].zero_()
+        bufs[b][: hi - lo] = 10.0 * step + rank
+        pipe.submit(b, bufs[b])
+    pipe.drain()
+    if rank == 0:
+        got = [[float(t[0, 0, 0, 0]), int((t != 0).any(-1).any(-1).any(-1).sum())] for t in pipe.recv[0]]
+        np.save(os.path.join(out_dir, "got.npy"), np.array(got))
+    np.save(os.path.join(out_dir, f"refused{rank}.npy"), np.array([int(refused)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_refuses_uneven_blocks_and_works_on_padded_ones(tmp_path, world):
+    """The shares of the fixed problem differ by one sequence between ranks (15 625 = 8 x 1 953 + 1).  Both gather
+    pipelines move equal blocks: blocks of different shape are refused on every rank alike (on RCCL a size mismatch of a
+    point-to-point transfer hangs), and blocks padded to the largest share -- what bench.py allocates -- gather correctly."""
+    port = free_port()
+    mp.spawn(_uneven_gather_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert int(np.load(tmp_path / f"refused{r}.npy")[0]) == 1, r
+    got = np.load(tmp_path / "got.npy")                          # buffer 0 last carried step 2
+    from seqikpy_amd.sharding import rank_share
+    for r in range(world):
+        lo, hi, _ = rank_share(7, world, r, "strong")
+        assert got[r, 0] == 20.0 + r and got[r, 1] == hi - lo, (r, got[r])
