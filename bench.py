@@ -47,6 +47,9 @@ and, at N > 1, `multi_gpu` (every leg with its per-rank ms, the gather it used a
   weak | strong      the other scaling mode, a short run beside the headline
   one_recording      config 3 as ONE recording of 1M frames, truly frame-sharded (contiguous frame slabs, boundary repair),
                      with its own one-GPU reference (`n1_reference_ms`)
+  config5            BASELINE config 5 on the N GPUs: 10M frames x 6 legs streamed from pinned host memory with the alignment
+                     fused (PCIe-inclusive): independent sequences split over the ranks, and ONE recording in contiguous slabs
+                     per rank with the warm start carried across slabs and ranks
 """
 import argparse
 import json
@@ -1409,10 +1412,42 @@ def main():
                 res["efficiency_vs_n1"] = got[0] / res["ms_per_step"] / world
                 return res
 
+            def leg_config5():
+                # BASELINE config 5 on N GPUs: 10 M frames x 6 legs streamed from pinned host memory with the alignment fused,
+                # PCIe-inclusive, every rank over its own PCIe link.  (a) independent 64-frame sequences: rank r streams its 1/N
+                # of them, no coordination; (b) ONE recording, contiguous slabs per rank, warm start carried from slab to slab
+                # and across the rank boundaries (stream_sharding), whole-recording alignment statistics on every rank.
+                import importlib.util
+                from types import SimpleNamespace
+                spec = importlib.util.spec_from_file_location("stream_config5", os.path.join(ROOT, "scripts", "stream_config5.py"))
+                sc5 = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(sc5)
+                torch.cuda.empty_cache()
+                frames5 = int(os.environ.get("SEQIK_BENCH_CONFIG5_FRAMES", "10000000"))
+                slab = min(500_000, max(64, (frames5 // world // 64) * 64))
+                a5 = SimpleNamespace(frames=max(slab, frames5 // world), slab_frames=slab, frames_per_seq=64, unique=1, slots=3, no_fk=False,
+                                     pageable=False, check=False, gpu_stats=False)
+                sync_all()
+                mine = sc5.synthetic_sequences(a5)
+                got = [None] * world
+                dist.all_gather_object(got, {"seconds": mine["seconds"], "leg_frames": mine["leg_frames"], "pcie_GBps": mine["pcie_GBps_total"]})
+                seq = {"value": sum(g_["leg_frames"] for g_ in got) / max(g_["seconds"] for g_ in got), "unit": "leg-frame solves/s",
+                       "leg_frames": sum(g_["leg_frames"] for g_ in got), "seconds_slowest_rank": max(g_["seconds"] for g_ in got),
+                       "by_rank": got, "what": "independent 64-frame sequences, 1/N of them per rank, each rank over its own PCIe link; "
+                                               "PCIe-inclusive (H2D 120 B, D2H 272 B per leg-frame), alignment fused"}
+                slab_r = max(1000, (frames5 // (2 * world) // 1000) * 1000)    # two slabs per rank; a multiple of the fixture's 1000 frames
+                a5r = SimpleNamespace(frames=frames5, slab_frames=slab_r, slots=3, no_fk=False, gpu_stats=False)
+                rec = sc5.one_recording_over_ranks_core(a5r, dist, world, rank, backend)
+                box = [rec]
+                dist.broadcast_object_list(box, src=0)
+                return {"workload": "config 5: %d frames x 6 legs streamed from pinned host memory, AlignPose.align_leg fused, N GPUs" % frames5,
+                        "synthetic_sequences": seq, "one_recording": box[0]}
+
             guarded("n1_reference", leg_n1_reference)
             guarded("gather_compare", leg_gather_compare)
             guarded(other_scaling, leg_other_scaling)
             guarded("one_recording", leg_one_recording)
+            guarded("config5", leg_config5)
             # scaling efficiencies against the one-GPU run of the SAME job in the SAME run: value / (N x value at N = 1)
             n1 = multi.get("n1_reference")
             if n1 and "value" in n1:

@@ -123,12 +123,22 @@ def one_recording_over_ranks(args):
     """Config 5 on N ranks: ONE recording of --frames frames x 6 legs, rank r streams its contiguous slabs from its own
     pinned buffers (seqikpy_amd.stream_sharding); pass 1 (alignment statistics from all RAW slabs) on every rank."""
     import torch.distributed as dist
-    from seqikpy_amd import stream_sharding
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     n_dev = torch.cuda.device_count()
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(n_dev, 1))
     backend = "nccl" if n_dev >= world else "gloo"     # ranks that share a GPU (rehearsal) talk over gloo
     dist.init_process_group(backend, rank=rank, world_size=world)
+    res = one_recording_over_ranks_core(args, dist, world, rank, backend)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def one_recording_over_ranks_core(args, dist, world, rank, backend):
+    """The body of one_recording_over_ranks on an EXISTING process group (bench.py's N > 1 line calls it as a leg).  Collective:
+    every rank calls it; rank 0 gets the result, the others None."""
+    from seqikpy_amd import stream_sharding
     coll = "cuda" if backend == "nccl" else "cpu"
     z = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
     legs = [str(l) for l in z["legs"]]
@@ -183,21 +193,24 @@ def one_recording_over_ranks(args):
     dist.all_gather_object(seen, {"rank": rank, "slabs": [int(k0), int(k1)], "seconds": st.get("seconds", 0.0),
                                   "h2d_GBps": st.get("h2d_GBps", 0.0), "d2h_GBps": st.get("d2h_GBps", 0.0),
                                   "boundary_rounds": st.get("boundary_rounds"), "restreams": st.get("restreams")})
+    res = None
     if rank == 0:
-        # check: slab 0 of rank 0 against the direct chunked call of those frames, and the serial walk of its first frames
         c, h, _ = _lib.frame_chunk_plan(T)
-        a0 = get_out(0)[0] if (k1 - k0) <= len(outs) else None
         units = n_slabs * L * T
-        print(json.dumps({"metric": "leg-IK solves/s, ONE recording streamed from host memory, frames sharded over the ranks "
-                                    "(PCIe-inclusive)", "value": units / dt, "unit": "leg-frame solves/s", "n_gpus": world,
-                          "backend": backend, "seconds": dt, "leg_frames": units, "frames_total": n_slabs * T, "legs": L,
-                          "slabs": n_slabs, "slab_frames": T, "frames_per_chunk": c, "run_in_frames": h,
-                          "outputs": "7 angles" + (" + 9x3 FK" if want_fk else ""), "ranks": seen,
-                          "alignment_statistics_pass": stats_pass,
-                          "data": "df3d locomotion recording (fixture) repeated, RAW key points through a made-up camera frame, "
-                                  "AlignPose.align_leg fused into the kernels"}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+        res = {"metric": "leg-IK solves/s, ONE recording streamed from host memory, frames sharded over the ranks "
+                         "(PCIe-inclusive)", "value": units / dt, "unit": "leg-frame solves/s", "n_gpus": world,
+               "backend": backend, "seconds": dt, "leg_frames": units, "frames_total": n_slabs * T, "legs": L,
+               "slabs": n_slabs, "slab_frames": T, "frames_per_chunk": c, "run_in_frames": h,
+               "outputs": "7 angles" + (" + 9x3 FK" if want_fk else ""), "ranks": seen,
+               "alignment_statistics_pass": stats_pass,
+               "data": "df3d locomotion recording (fixture) repeated, RAW key points through a made-up camera frame, "
+                       "AlignPose.align_leg fused into the kernels"}
+    p.free()
+    for a, f in outs:
+        a.free()
+        if f:
+            f.free()
+    return res
 
 
 def main():

@@ -444,6 +444,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"   # the calibration a real RCCL job runs before its headline (choose_gather)
+    env["SEQIK_BENCH_CONFIG5_FRAMES"] = "256000"  # the config-5 leg at a rehearsal size (10 M frames on a real node)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                         "--frames", "8256"], env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -469,6 +470,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert sum(m["one_recording"]["frames_per_rank"]) == 8256 and m["one_recording"]["check"]["max_abs_vs_serial"] < 2e-5
     assert m["one_recording"]["n1_reference_ms"] > 0 and m["one_recording"]["efficiency_vs_n1"] > 0
     assert abs(b["value"] - 8256 * 6 / (b["ms_per_step"] * 1e-3)) < 1e-6 * b["value"]       # the fixed problem / time
+    c5 = m["config5"]
+    assert "error" not in c5 and c5["synthetic_sequences"]["value"] > 0 and len(c5["synthetic_sequences"]["by_rank"]) == 2
+    assert c5["one_recording"]["n_gpus"] == 2 and c5["one_recording"]["frames_total"] == 256000 and c5["one_recording"]["value"] > 0
 
 
 @pytest.mark.gpu
@@ -485,6 +489,7 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     env["SEQIK_BENCH_CALIBRATE_GATHER"] = "1"
+    env["SEQIK_BENCH_CONFIG5_FRAMES"] = "256000"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "6", "--warmup", "1",
                         "--frames", "32064"], env=env, capture_output=True, text=True, timeout=800)
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -499,6 +504,7 @@ def test_bench_four_ranks_on_one_gpu_rehearsal(tmp_path):
     assert m["weak"]["leg_frames_per_step_all_ranks"] == 4 * 32064 * 6 and len(m["weak"]["rank_ms_per_step"]["by_rank"]) == 4
     assert "error" not in m["n1_reference"] and m["efficiency_vs_n1"] > 0 and m["speedup_vs_n1"] > 0
     assert sum(m["one_recording"]["frames_per_rank"]) == 32064 and "error" not in m["one_recording"]
+    assert "error" not in m["config5"] and len(m["config5"]["one_recording"]["ranks"]) == 4
     assert b["config"]["gather_calibration"]["chosen"] in ("rccl", "peer")
 
 
