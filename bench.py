@@ -1349,14 +1349,23 @@ def main():
                 # scaling efficiencies of THIS run are measured against
                 res = None
                 if rank == 0:
-                    b1 = Batch(whole["pose"], params, args, n_streams, pipeline=batch.pipeline)
-                    bufs1 = [b1.angle_buffer() for _ in range(len(b1.streams))]
-                    k1 = args.steps
-                    dt1 = timed_steps(b1, bufs1, k1, len(b1.streams), warmup=args.warmup)
-                    res = {"value": b1.units * k1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
-                           "streams": len(b1.streams), "leg_frames_per_step": int(b1.units),
-                           "what": "the whole fixed problem on rank 0's GPU alone (the other ranks idle), same run"}
-                    del b1, bufs1
+                    # at ITS best depth (what an N = 1 run calibrates for itself), not at the shares': a reference that is
+                    # slower than it could be would flatter the efficiencies
+                    k1, first, res = args.steps, None, None
+                    for n_st, pipe, lat in depth_candidates(args.steps):
+                        if lat is not None or n_st in (8, 12):
+                            continue            # (3, library's choice), (16, lane per chain) and the balanced depth
+                        b1 = Batch(whole["pose"], params, args, n_st, pipeline=pipe, like=first)
+                        first = first or b1
+                        bufs1 = [b1.angle_buffer() for _ in range(len(b1.streams))]
+                        dt1 = timed_steps(b1, bufs1, k1, len(b1.streams), warmup=args.warmup)
+                        if res is None or dt1 / k1 * 1e3 < res["ms_per_step"]:
+                            res = {"value": b1.units * k1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
+                                   "streams": len(b1.streams), "stage_pipeline": pipe, "leg_frames_per_step": int(b1.units),
+                                   "what": "the whole fixed problem on rank 0's GPU alone (the other ranks idle), same run, at the "
+                                           "best of the depths an N = 1 run calibrates among"}
+                        del bufs1
+                    del b1, first
                     torch.cuda.empty_cache()
                 got = [None] * world
                 dist.all_gather_object(got, res)
