@@ -19,7 +19,10 @@ frame-sharded": ONE fixed problem.
   --scaling weak   1,000,000 frames PER GPU (a named leg of the N > 1 line either way: `multi_gpu.weak`)
 A step is one pass of the hot path (one launch in which every wave takes its chains through stages 1-4;
 `--staged`: the 4 stage kernels) over the rank's batch with inputs resident in HBM; consecutive steps overlap on
-`--streams` HIP streams.  For N > 1 every step also sends the rank's joint angles to rank 0 (copy-engine peer writes
+`--streams` HIP streams -- by default (`--streams 0`) as many as a calibration over the very region that is about to be
+measured finds best (`config.depth_calibration`; depth_candidates(): up to 16 steps in flight on the lane-per-chain
+kernels -- a 1/8 share of the problem only fills the GPU that way --, the last partial round on the library's own kernel
+choice).  For N > 1 every step also sends the rank's joint angles to rank 0 (copy-engine peer writes
 over xGMI into rank 0's IPC-exported buffers, an 8-byte RCCL all-reduce as completion flag; grouped RCCL
 point-to-point if the peer path is unavailable, or when SEQIK_GATHER=rccl; `config.gather` says which ran).
 
@@ -29,7 +32,8 @@ HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figure
   variants           the other synthetic variant (smooth <-> iid), same pipeline
   single_recording   ONE recording of 1M frames x 6 legs (real locomotion poses repeated), walked as the reference
                      walks a recording, by frame chunks (SeqikOptions.frame_chunk)
-  strong_projection  the per-rank share of the fixed 1M-frame problem at N = 2, 4, 8, timed on this GPU
+  strong_projection  the per-rank share of the fixed 1M-frame problem at N = 2, 4, 8, timed on this GPU over the same region
+                     (same steps / warm-up) at every candidate depth, + one job at a time, + the issue floor of the 1/8 share
   parity             HIP vs the committed reference fixtures (shipped anipose outputs, df3d reference-source run):
                      max |d theta|, leg-frames over 1e-4 rad and where, for the serial walk and for frame chunks
   cpu_baseline       the C oracle on the host cores, bounded sample of the same workload (+ Python/scipy pool)
@@ -38,7 +42,10 @@ HIP-event timing; the bound that matters here is FP64 VALU issue, the HBM figure
                      Python API (default serial walk AND frame_parallel="auto": ms, leg-frames/s, max |d theta| vs the
                      fixture, chunk statistics, latency_floor_frac), 4 with the head / antenna angles in the same
                      submission, 3 = the headline, 5 streamed from pinned host slabs with the alignment fused
-                     (PCIe-inclusive, checked), and the generic chain on the shipped 6000-frame recording
+                     (PCIe-inclusive, checked), the generic chain on the shipped 6000-frame recording and in batches
+                     (static launch against the chain queue)
+  <scalars>          a handful of the figures above again as top-level scalars (config1_default_ms, ...,
+                     strong_projected_speedup_n8, head_kernel_frac_of_box_copy): they survive in the driver's own record
 and, at N > 1, `multi_gpu` (every leg with its per-rank ms, the gather it used and `efficiency_vs_n1`):
   ranks_seen, rank_ms_per_step   who took part (rank, host, device from the process group) and how even the ranks were
   n1_reference       the WHOLE fixed problem on rank 0's GPU alone, same run, same pipeline (the other ranks wait): what
