@@ -129,7 +129,9 @@ int seqik_head_angles_ex_device(const double *d_r_head, const double *d_l_head, 
     a.rest_head_pitch = rest_head_pitch; a.rest_antenna_pitch = rest_antenna_pitch;
     a.angles = d_angles; a.n_frames = n_frames; a.compute_ant = compute_ant;
     int64_t blocks = (n_frames + 255) / 256;
-    static const int per_cu = getenv("SEQIK_HEAD_BLOCKS_PER_CU") ? atoi(getenv("SEQIK_HEAD_BLOCKS_PER_CU")) : 8;
+    // (round 5: 64 workgroups per CU in the grid instead of 8 -- at most six are resident (LDS), the rest queue up and each
+    // makes fewer grid-stride rounds: 16 M frames 0.483 -> 0.473 ms, 64 M 1.955 -> 1.902 ms; profiles/r05_head_blocks_per_cu.txt)
+    static const int per_cu = getenv("SEQIK_HEAD_BLOCKS_PER_CU") ? atoi(getenv("SEQIK_HEAD_BLOCKS_PER_CU")) : 64;
     if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;  // grid-stride beyond per_cu blocks per CU
     // staged loads need 16-byte aligned records and read the antenna tips too (only worth it when they are used)
     const bool staged = compute_ant && n_points == 2 && ((reinterpret_cast<uintptr_t>(d_r_head) | reinterpret_cast<uintptr_t>(d_l_head)) & 15) == 0;
