@@ -69,10 +69,25 @@ from concurrent.futures import ThreadPoolExecutor
 # share a queue run one after the other.  Three solver streams fit -- until RCCL adds its own: measured on one MI355X,
 # 4.13e8 -> 3.0e8 solves/s as soon as a process group exists (same as GPU_MAX_HW_QUEUES=2 without one); with 8
 # queues both cases run at 4.13e8.  Must be set before the runtime initialises.
-# Round 5: the per-rank shares of the fixed problem (strong scaling) only fill the GPU with MANY steps in flight -- 16 streams on
-# 16 queues: 1/8 share 3.4 -> 1.9-2.1 ms per step; more streams than queues, or more than 16 queues, collapse to ~16 ms per
-# step (profiles/r05_share_streams.jsonl) -- so the default here is 16 queues and the depth is calibrated in the run.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Round 5: the per-rank shares of the fixed problem (strong scaling) only fill the GPU with MANY steps in flight -- 16-20 streams,
+# each on a hardware queue of its own: 1/8 share 3.4 -> 2.3 (16 in flight) -> 2.1 ms per step (20 in flight, 24 queues)
+# (profiles/r05_share_streams.jsonl, r05_stream_cliff.jsonl).  But a process that may use 24 queues pays ~10 % on its OTHER
+# long-running kernels (one-chain generic call 1.67 -> 1.85 s, config-5 stream 1.84e8 -> 1.65e8; the headline kernel does not:
+# profiles/r05_queues_ab_bench_legs.jsonl).  So: 24 queues and up to 20 steps in flight for a rank of an N > 1 job, whose
+# business is the headline; 16 and 16 at N = 1, whose line carries all the other legs.
+def _world_size_from_env_or_argv():
+    if "WORLD_SIZE" in os.environ:
+        return int(os.environ["WORLD_SIZE"])
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return int(sys.argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+MAX_DEPTH = 20 if _world_size_from_env_or_argv() > 1 else 16   # steps in flight at most (24 streams of a 1/8 share lose again)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if MAX_DEPTH > 16 else "16")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and hipIpc handles across processes need it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -325,21 +340,30 @@ class Batch:
         return stream
 
 
-def depth_candidates(steps):
+def depth_candidates(steps, chains=None):
     """(steps in flight, SeqikOptions.reserved[3], latency-kernel steps [lo, hi) or None) the run calibrates among (parse():
-    --streams 0).  Beside the fixed depths: the BALANCED depth -- `steps` cut into the fewest rounds of at most 16, all of the
-    same size (20 steps: 2 x 10 instead of 16 + 4) -- and depth 16 with the partial round (at most 8 steps) launched with the
-    library's own kernel choice instead of the lane-per-chain kernels: it is the LAST round, which runs on a draining GPU, and
-    the stage pipeline's launch is over in half the time (1/8 share, 20 steps: 2.9 -> 2.3 ms per step; the same launches put
-    FIRST, to make room early, lose: 3.1; profiles/r05_depth_calibration_k20_k100.jsonl)."""
-    cands = [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
-    rounds = -(-steps // 16)
+    --streams 0).  Beside the fixed depths: the BALANCED depth -- `steps` cut into the fewest rounds of at most MAX_DEPTH, all
+    of the same size (20 steps: all at once; 100 steps: 5 x 20) -- and depths 16 / 20 with the partial round (at most 8 steps)
+    launched with the library's own kernel choice instead of the lane-per-chain kernels: it is the LAST round, which runs on
+    a draining GPU, and the stage pipeline's launch is over in half the time (1/8 share, 20 steps at depth 16: 2.9 -> 2.3 ms
+    per step; the same launches put FIRST, to make room early, lose: 3.1; profiles/r05_depth_calibration_k20_k100.jsonl).
+    `chains`: chains per step -- depths that would put more than twice the GPU's wavefront slots in flight are left out (the
+    whole problem: 3 and 4; a 1/8 share: everything): deeper buys nothing there, and every stream is a hardware queue, of
+    which a process should not hold more than it needs (see the strong_projection leg)."""
+    cap = MAX_DEPTH if not chains else max(3, min(MAX_DEPTH, -(-2 * 3072 // max(1, -(-chains // 64)))))
+    return [c for c in _depth_candidates(steps) if c[0] <= cap]
+
+
+def _depth_candidates(steps):
+    cands = [c for c in ((3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None), (20, 1, None)) if c[0] <= MAX_DEPTH]
+    rounds = -(-steps // MAX_DEPTH)
     balanced = -(-steps // rounds)
-    if balanced > 3 and balanced not in (8, 12, 16):
+    if balanced > 3 and balanced not in (8, 12, 16, 20):
         cands.append((balanced, 1, None))
-    rest = steps % 16
-    if steps > 16 and 0 < rest <= 8:
-        cands.append((16, 1, (steps - rest, steps)))
+    for depth in (16, 20):
+        rest = steps % depth
+        if depth <= MAX_DEPTH and steps > depth and 0 < rest <= 8:
+            cands.append((depth, 1, (steps - rest, steps)))
     return cands
 
 
@@ -347,7 +371,7 @@ def in_lat_range(batch, i):
     return batch.lat_range is not None and batch.lat_range[0] <= i < batch.lat_range[1]
 
 
-DEPTH_CANDIDATES = depth_candidates(10 ** 6)   # the fixed depths (a long run has no partial round worth a special case)
+DEPTH_CANDIDATES = _depth_candidates(10 ** 6)   # the fixed depths (a long run has no partial round worth a special case)
 
 
 def setup_streams(batch, bufs, n_streams):
@@ -1160,7 +1184,7 @@ def main():
                                      "two synchronisations, fill and drain included); (streams, stage_pipeline): stage_pipeline 0 = the "
                                      "library's choice for ONE call, 1 = lane-per-chain kernels"}
         best = None
-        for n_st, pipe, lat in depth_candidates(args.steps):
+        for n_st, pipe, lat in depth_candidates(args.steps, S * L):
             try:
                 bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch)
                 bt.lat_range = lat
@@ -1359,9 +1383,9 @@ def main():
                     # at ITS best depth (what an N = 1 run calibrates for itself), not at the shares': a reference that is
                     # slower than it could be would flatter the efficiencies
                     k1, first, res = args.steps, None, None
-                    for n_st, pipe, lat in depth_candidates(args.steps):
-                        if lat is not None or n_st in (8, 12):
-                            continue            # (3, library's choice), (16, lane per chain) and the balanced depth
+                    for n_st, pipe, lat in depth_candidates(args.steps, S_total * L):
+                        if lat is not None:
+                            continue
                         b1 = Batch(whole["pose"], params, args, n_st, pipeline=pipe, like=first)
                         first = first or b1
                         bufs1 = [b1.angle_buffer() for _ in range(len(b1.streams))]
@@ -1522,7 +1546,9 @@ def main():
                                  "steps": n1, "streams": 1,
                                  "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
                                          "FP64 latency; `value` above is the pipelined rate"}
-            # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU ----------------------
+            # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU, BEFORE the legs that create streams of
+            # their own (config 5's pipeline, the pooled contexts of the host-buffer calls): run behind them the same pipelines
+            # share queues with those streams (1/8 share 2.1 -> 4.3 ms per step) ---------------------------------------------
             proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU; no gather; "
                             "projected_value = 6M leg-frames / that time.  `streams` / `stage_pipeline`: the fastest of the depth "
                             "candidates for that share (what an N-GPU run calibrates for itself): a share of 1/N brings 1/N of the "
@@ -1531,7 +1557,7 @@ def main():
                     "by_n_gpus": {}}
             for n in (2, 4, 8):
                 best, tried = None, []
-                for n_st, pipe, lat in (depth_candidates(args.steps) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
+                for n_st, pipe, lat in (depth_candidates(args.steps, (S // n) * L) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
                     sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
                     sub.lat_range = lat
                     bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]

@@ -479,8 +479,9 @@ def test_eight_legs_and_single_frame_sequences(lib, oracle):
 
 @pytest.mark.gpu
 def test_more_streams_than_remembered_workspaces(lib):
-    """The library remembers a hand-off workspace for 16 streams; launches on 20 streams (two rounds, so that evicted
-    streams come back) still return the bits of a launch made alone."""
+    """The library remembers a hand-off workspace for 64 streams; launches on 70 streams (two rounds, so that evicted
+    streams come back) still return the bits of a launch made alone.  (pipeline=1: the lane-per-chain kernels are the ones
+    that use the workspace.)"""
     import torch
     z = load_golden("df3d_100")
     legs = [str(l) for l in z["legs"]]
@@ -488,12 +489,12 @@ def test_more_streams_than_remembered_workspaces(lib):
     pose = np.stack([z[f"{l}_pose"][:30] for l in legs])[None]
     alone = lib.solve_seq(pose, params, want_fk=False)["angles"]
     d_pose = torch.from_numpy(np.ascontiguousarray(pose)).cuda()
-    streams = [torch.cuda.Stream() for _ in range(20)]
-    outs = [torch.zeros((1, 6, 30, 7), dtype=torch.float64, device="cuda") for _ in range(40)]
+    streams = [torch.cuda.Stream() for _ in range(70)]
+    outs = [torch.zeros((1, 6, 30, 7), dtype=torch.float64, device="cuda") for _ in range(140)]
     torch.cuda.synchronize()
-    for i in range(40):
+    for i in range(140):
         lib.solve_seq_device(d_pose.data_ptr(), 1, 6, 30, params, outs[i].data_ptr(), 0,
-                             stream=streams[i % 20].cuda_stream)
+                             stream=streams[i % 70].cuda_stream, pipeline=1 if i % 2 else 0)
     torch.cuda.synchronize()
     assert all(np.array_equal(o.cpu().numpy(), alone) for o in outs)
     lib.release_workspaces()
