@@ -70,24 +70,14 @@ from concurrent.futures import ThreadPoolExecutor
 # 4.13e8 -> 3.0e8 solves/s as soon as a process group exists (same as GPU_MAX_HW_QUEUES=2 without one); with 8
 # queues both cases run at 4.13e8.  Must be set before the runtime initialises.
 # Round 5: the per-rank shares of the fixed problem (strong scaling) only fill the GPU with MANY steps in flight -- 16-20 streams,
-# each on a hardware queue of its own: 1/8 share 3.4 -> 2.3 (16 in flight) -> 2.1 ms per step (20 in flight, 24 queues)
-# (profiles/r05_share_streams.jsonl, r05_stream_cliff.jsonl).  But a process that may use 24 queues pays ~10 % on its OTHER
-# long-running kernels (one-chain generic call 1.67 -> 1.85 s, config-5 stream 1.84e8 -> 1.65e8; the headline kernel does not:
-# profiles/r05_queues_ab_bench_legs.jsonl).  So: 24 queues and up to 20 steps in flight for a rank of an N > 1 job, whose
-# business is the headline; 16 and 16 at N = 1, whose line carries all the other legs.
-def _world_size_from_env_or_argv():
-    if "WORLD_SIZE" in os.environ:
-        return int(os.environ["WORLD_SIZE"])
-    for i, a in enumerate(sys.argv):
-        if a == "--gpus" and i + 1 < len(sys.argv):
-            return int(sys.argv[i + 1])
-        if a.startswith("--gpus="):
-            return int(a.split("=", 1)[1])
-    return 1
-
-
-MAX_DEPTH = 20 if _world_size_from_env_or_argv() > 1 else 16   # steps in flight at most (24 streams of a 1/8 share lose again)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if MAX_DEPTH > 16 else "16")
+# each on a hardware queue of its own: 1/8 share 3.4 -> 2.3 (16 in flight) -> 2.1 ms per step (20 in flight)
+# (profiles/r05_share_streams.jsonl, r05_stream_cliff.jsonl).  How many queues: torch hands out streams from a pool of 32, HIP
+# maps them onto at most GPU_MAX_HW_QUEUES hardware queues, and a process that HOLDS 24 of them pays ~10 % on its other
+# long-running kernels (one-chain generic call 1.67 -> 1.86 s, config-5 stream 1.84e8 -> 1.65e8; up to 22: nothing --
+# profiles/r05_queue_count_probe_touched.jsonl, r05_queues_ab_bench_legs.jsonl, r05_queues_22_depth20_bench_legs.jsonl).  So:
+# 22 queues, at most 20 steps in flight.
+MAX_DEPTH = int(os.environ.get("SEQIK_BENCH_MAX_DEPTH") or 20)   # steps in flight at most (24 streams of a 1/8 share lose again)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL and hipIpc handles across processes need it
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -243,29 +243,22 @@ def test_bench_depth_candidates_cover_the_measured_region():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
-    assert bench.MAX_DEPTH == 16            # this process is not a rank of an N > 1 job (those go up to 20 on 24 queues)
+    assert bench.MAX_DEPTH == 20
     c20 = bench.depth_candidates(20)
-    assert c20[:4] == [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None)]
-    # 20 steps: 2 x 10, or 16 + a last, partial round of 4 on the library's kernel choice
-    assert (10, 1, None) in c20 and (16, 1, (16, 20)) in c20 and len(c20) == 6
-    assert (16, 1, (96, 100)) in bench.depth_candidates(100) and (15, 1, None) in bench.depth_candidates(100)
+    assert c20[:5] == [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None), (20, 1, None)]
+    # 20 steps: all at once (depth 20), or 16 + a last, partial round of 4 on the library's kernel choice
+    assert (16, 1, (16, 20)) in c20 and len(c20) == 6
+    assert (20, 1, None) in bench.depth_candidates(100) and (17, 1, None) in bench.depth_candidates(50)       # 5 x 20; 3 x 17
+    assert (16, 1, (96, 100)) in bench.depth_candidates(100) and (20, 1, (40, 45)) in bench.depth_candidates(45)
     for k in (1, 4, 6, 16, 17, 20, 32, 33, 45, 100, 1000):
         for streams, pipe, lat in bench.depth_candidates(k):
             assert 1 <= streams <= bench.MAX_DEPTH and pipe in (0, 1)
-            assert lat is None or (streams == 16 and streams <= lat[0] < lat[1] == k and lat[1] - lat[0] <= 8)
+            assert lat is None or (streams in (16, 20) and streams <= lat[0] < lat[1] == k and lat[1] - lat[0] <= 8)
     assert all(t is None for _, _, t in bench.depth_candidates(16)) and all(t is None for _, _, t in bench.depth_candidates(4))
     # the whole problem brings 1 465 wavefronts per step: depths beyond 2 x 3 072 slots / that are left out; a 1/8 share keeps all
     assert bench.depth_candidates(20, 93750) == [(3, 0, None)] and len(bench.depth_candidates(20, 11718)) == 6
     assert [c[0] for c in bench.depth_candidates(20, 46872)] == [3, 8]
-    # a rank of an N > 1 job: up to 20 steps in flight, 24 hardware queues asked for before the HIP runtime starts
-    code = ("import os, sys, importlib.util\n"
-            "os.environ['WORLD_SIZE'] = '8'; os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
-            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec)\n"
-            "spec.loader.exec_module(b)\n"
-            "assert b.MAX_DEPTH == 20 and os.environ['GPU_MAX_HW_QUEUES'] == '24', (b.MAX_DEPTH, os.environ['GPU_MAX_HW_QUEUES'])\n"
-            "assert (20, 1, None) in b.depth_candidates(20, 11718) and (16, 1, (16, 20)) in b.depth_candidates(20, 11718)\n"
-            "print('ok')" % os.path.join(ROOT, "bench.py"))
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # (bench.py asks for 22 hardware queues before anything imports the HIP runtime -- 24 held queues cost the other kernels of
+    # a process 10 % --; in THIS process the package was imported first)
+    with open(os.path.join(ROOT, "bench.py")) as fh:
+        assert 'os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")' in fh.read()
