@@ -1327,6 +1327,46 @@ def main():
         roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
         roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
 
+    def make_out():
+        """The JSON line's headline part (everything that is known once the timed region and the roofline are done)."""
+        return {
+            "metric": "leg-IK solves/s (frames x 6 legs); max |d theta| vs reference in `parity`",
+            "value": units_all * args.steps / elapsed,
+            "unit": "leg-frame solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs, in-workspace targets" if world == 1 else
+                                    "config 3 (weak-scaling variant): synthetic 1M frames x 6 legs PER GPU, in-workspace targets"
+                                    if args.scaling == "weak" else
+                                    f"config 3 literally: the FIXED problem of synthetic 1M frames x 6 legs IN TOTAL ({S_total} "
+                                    f"sequences of {T} frames), sequences split over the {world} ranks, joint angles gathered on rank 0"),
+                       "frames_total": S_total * T * (world if args.scaling == "weak" else 1),
+                       "leg_frames_per_step_all_ranks": int(units_all),
+                       "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
+                       "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
+                       "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
+                       "streams": len(streams),
+                       "pipeline": f"{len(streams)} independent batches in flight (consecutive steps overlap); "
+                                   "`single_job` is one launch at a time",
+                       "launches_per_step": 4 if args.staged else 1,
+                       "parity_note": ("iid poses span several equivalent leg configurations: the reference itself moves 30 % of "
+                                       "such leg-frames by more than 1e-4 rad under a 1-ulp change of its input "
+                                       "(profiles/r02_perturbation_report.json), so on this variant parity means HIP == C restatement "
+                                       "bit for bit; `variants.smooth` is the realistic workload, `parity` the shipped recordings"
+                                       if args.variant == "iid" else
+                                       "temporally continuous poses (the realistic variant); `parity` holds the shipped recordings"),
+                       "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
+                       "stage_pipeline": batch.pipeline,
+                       **({"depth_calibration": depth_calibration} if depth_calibration else {}),
+                       **({"gather": gather_how} if gather_how else {}),
+                       **({"gather_calibration": gather_calibration} if gather_calibration else {})},
+            "roofline": roofline,
+            "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
+                        "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
+        }
+
     # ---- N > 1: who took part, how even the ranks were, both gathers, and the other scaling mode -- in the same run ----
     multi = None
     if dist and world > 1:
@@ -1339,6 +1379,30 @@ def main():
                  "rank_ms_per_step": {"min": min(r["ms_per_step"] for r in seen), "max": max(r["ms_per_step"] for r in seen),
                                       "by_rank": [r["ms_per_step"] for r in seen]}}
         if not args.no_extras:
+            # The headline is measured.  The legs below are collectives over all ranks: if one of them ever hangs (a rank that
+            # fails where the others do not and never enters the collective they wait in), the line must still come out --
+            # every rank runs the same timer from here; when it fires, rank 0 prints the headline with the legs finished so
+            # far and every rank leaves with exit code 0.
+            import threading
+            legs_deadline_s = float(os.environ.get("SEQIK_BENCH_LEGS_TIMEOUT", "600"))
+
+            def give_up():
+                try:
+                    if rank == 0:
+                        o = make_out()
+                        try:
+                            o["multi_gpu"] = dict(multi, legs_timed_out_after_s=legs_deadline_s)
+                        except RuntimeError:     # (the main thread was adding a leg at this very moment)
+                            o["multi_gpu"] = {"legs_timed_out_after_s": legs_deadline_s}
+                        os.write(json_fd, (json.dumps(o) + "\n").encode())
+                    sys.stderr.write(f"bench.py rank {rank}: extra legs did not finish within {legs_deadline_s:.0f} s -- headline printed, leaving\n")
+                finally:
+                    os._exit(0)
+
+            legs_timer = threading.Timer(legs_deadline_s, give_up)
+            legs_timer.daemon = True
+            legs_timer.start()
+
             def guarded(name, fn):
                 """One extra leg.  The headline above is measured and must survive whatever happens here: a leg that
                 raises on any rank is dropped on ALL ranks (consensus by all-reduce, so nobody waits in a collective the
@@ -1486,45 +1550,10 @@ def main():
                 oth = multi.get(other_scaling)
                 if oth and "value" in oth:
                     oth["efficiency_vs_n1"] = oth["value"] / (world * n1["value"])
+            legs_timer.cancel()
 
     if rank == 0:
-        out = {
-            "metric": "leg-IK solves/s (frames x 6 legs); max |d theta| vs reference in `parity`",
-            "value": units_all * args.steps / elapsed,
-            "unit": "leg-frame solves/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs, in-workspace targets" if world == 1 else
-                                    "config 3 (weak-scaling variant): synthetic 1M frames x 6 legs PER GPU, in-workspace targets"
-                                    if args.scaling == "weak" else
-                                    f"config 3 literally: the FIXED problem of synthetic 1M frames x 6 legs IN TOTAL ({S_total} "
-                                    f"sequences of {T} frames), sequences split over the {world} ranks, joint angles gathered on rank 0"),
-                       "frames_total": S_total * T * (world if args.scaling == "weak" else 1),
-                       "leg_frames_per_step_all_ranks": int(units_all),
-                       "variant": args.variant, "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S,
-                       "frames_per_sequence": T, "chains_per_gpu": S * L, "warm_start": "previous frame",
-                       "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
-                       "streams": len(streams),
-                       "pipeline": f"{len(streams)} independent batches in flight (consecutive steps overlap); "
-                                   "`single_job` is one launch at a time",
-                       "launches_per_step": 4 if args.staged else 1,
-                       "parity_note": ("iid poses span several equivalent leg configurations: the reference itself moves 30 % of "
-                                       "such leg-frames by more than 1e-4 rad under a 1-ulp change of its input "
-                                       "(profiles/r02_perturbation_report.json), so on this variant parity means HIP == C restatement "
-                                       "bit for bit; `variants.smooth` is the realistic workload, `parity` the shipped recordings"
-                                       if args.variant == "iid" else
-                                       "temporally continuous poses (the realistic variant); `parity` holds the shipped recordings"),
-                       "parallelism": f"sequence-sharded x{world}, angle gather to rank 0" if world > 1 else "1 GPU",
-                       "stage_pipeline": batch.pipeline,
-                       **({"depth_calibration": depth_calibration} if depth_calibration else {}),
-                       **({"gather": gather_how} if gather_how else {}),
-                       **({"gather_calibration": gather_calibration} if gather_calibration else {})},
-            "roofline": roofline,
-            "verified": "after timing: every angle / FK buffer written by the overlapped launches == one launch made "
-                        "alone, bit for bit (smoke() and tests/ compare that launch with the oracle)",
-        }
+        out = make_out()
         if multi:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_extras:

@@ -753,3 +753,25 @@ def test_gather_refuses_uneven_blocks_and_works_on_padded_ones(tmp_path, world):
     for r in range(world):
         lo, hi, _ = rank_share(7, world, r, "strong")
         assert got[r, 0] == 20.0 + r and got[r, 1] == hi - lo, (r, got[r])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_headline_survives_a_leg_that_does_not_finish(tmp_path):
+    """The extra legs of an N > 1 line are collectives over all ranks; should one of them ever hang (a rank that fails where
+    the others do not), the measured headline must still come out: every rank runs the same timer, rank 0 prints the line with
+    the legs finished so far and all ranks leave with exit code 0.  Here the limit is set below what the legs need."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEQIK_BENCH_BACKEND", "SEQIK_GATHER")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["SEQIK_BENCH_LEGS_TIMEOUT"] = "1.0"
+    env["SEQIK_BENCH_CONFIG5_FRAMES"] = "256000"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--frames", "8256"], env=env, capture_output=True, text=True, timeout=500)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-4000:]
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["value"] > 0 and b["roofline"]["frac"] > 0
+    assert b["multi_gpu"]["legs_timed_out_after_s"] == 1.0 and "ranks_seen" in b["multi_gpu"]
+    assert "headline printed, leaving" in r.stderr
