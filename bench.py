@@ -1557,136 +1557,146 @@ def main():
         if multi:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_extras:
-            # ---- one launch at a time --------------------------------------------------------------------------
-            n1 = max(4, min(16, args.steps // 6))
-            lone = Batch(None, params, args, 1, pipeline=0, like=batch)       # ONE call at a time: the library's own kernel choice
-            dt1 = timed_steps(lone, d_ang, n1, 1)
-            out["single_job"] = {"value": units_per_step * n1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / n1 * 1e3,
-                                 "steps": n1, "streams": 1,
-                                 "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
-                                         "FP64 latency; `value` above is the pipelined rate"}
-            # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU, BEFORE the legs that create streams of
-            # their own (config 5's pipeline, the pooled contexts of the host-buffer calls): run behind them the same pipelines
-            # share queues with those streams (1/8 share 2.1 -> 4.3 ms per step) ---------------------------------------------
-            proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU; no gather; "
-                            "projected_value = 6M leg-frames / that time.  `streams` / `stage_pipeline`: the fastest of the depth "
-                            "candidates for that share (what an N-GPU run calibrates for itself): a share of 1/N brings 1/N of the "
-                            "wavefronts per step, so as many more steps must be in flight to fill the GPU; lone_job_ms = ONE launch at "
-                            "a time (the library's own kernel choice), what a rank gets when every step waits for the one before",
-                    "by_n_gpus": {}}
-            for n in (2, 4, 8):
-                best, tried = None, []
-                for n_st, pipe, lat in (depth_candidates(args.steps, (S // n) * L) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
-                    sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
-                    sub.lat_range = lat
-                    bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
-                    k = args.steps             # the same region as the headline's: fill and drain of the pipeline included
-                    dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=args.warmup)
-                    row = {"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
-                           "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
-                    tried.append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": row["ms_per_step"]})
-                    if best is None or row["ms_per_step"] < best["ms_per_step"]:
-                        best = row
+            # (the headline above is measured and must be printed whatever happens below: a leg that raises ends the extras,
+            # the line carries what was finished and `extras_error`)
+            try:
+                # ---- one launch at a time --------------------------------------------------------------------------
+                n1 = max(4, min(16, args.steps // 6))
+                lone = Batch(None, params, args, 1, pipeline=0, like=batch)       # ONE call at a time: the library's own kernel choice
+                dt1 = timed_steps(lone, d_ang, n1, 1)
+                out["single_job"] = {"value": units_per_step * n1 / dt1, "unit": "leg-frame solves/s", "ms_per_step": dt1 / n1 * 1e3,
+                                     "steps": n1, "streams": 1,
+                                     "note": "one 1M-frame x 6-leg batch at a time: 1 465 full waves on 1 024 SIMDs cannot hide "
+                                             "FP64 latency; `value` above is the pipelined rate"}
+                # ---- fixed 1M-frame problem split N ways: the per-rank share timed on this GPU, BEFORE the legs that create streams of
+                # their own (config 5's pipeline, the pooled contexts of the host-buffer calls): run behind them the same pipelines
+                # share queues with those streams (1/8 share 2.1 -> 4.3 ms per step) ---------------------------------------------
+                proj = {"note": "per-rank share of the fixed problem (S/N sequences) timed on ONE GPU; no gather; "
+                                "projected_value = 6M leg-frames / that time.  `streams` / `stage_pipeline`: the fastest of the depth "
+                                "candidates for that share (what an N-GPU run calibrates for itself): a share of 1/N brings 1/N of the "
+                                "wavefronts per step, so as many more steps must be in flight to fill the GPU; lone_job_ms = ONE launch at "
+                                "a time (the library's own kernel choice), what a rank gets when every step waits for the one before",
+                        "by_n_gpus": {}}
+                for n in (2, 4, 8):
+                    best, tried = None, []
+                    for n_st, pipe, lat in (depth_candidates(args.steps, (S // n) * L) if not explicit_depth else ((n_streams, batch.pipeline, None),)):
+                        sub = Batch(pose[: S // n], params, args, n_st, pipeline=pipe)
+                        sub.lat_range = lat
+                        bufs = [sub.angle_buffer() for _ in range(len(sub.streams))]
+                        k = args.steps             # the same region as the headline's: fill and drain of the pipeline included
+                        dt = timed_steps(sub, bufs, k, len(sub.streams), warmup=args.warmup)
+                        row = {"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": dt / k * 1e3, "projected_value": units_per_step / (dt / k),
+                               "speedup_vs_1": (elapsed / args.steps) / (dt / k), "chains_per_gpu": sub.S * L}
+                        tried.append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "ms_per_step": row["ms_per_step"]})
+                        if best is None or row["ms_per_step"] < best["ms_per_step"]:
+                            best = row
+                        del sub, bufs
+                    best["candidates"] = tried
+                    # the floor of a share: ONE launch at a time, no second step to overlap with (what a rank can do at best when
+                    # every step has to wait for the one before it)
+                    sub = Batch(pose[: S // n], params, args, 1, pipeline=0)     # ONE call: the library's own choice of kernel
+                    bufs = [sub.angle_buffer()]
+                    k = max(8, min(40, args.steps // 2))
+                    dt = timed_steps(sub, bufs, k, 1, warmup=2)
+                    best["lone_job_ms"] = dt / k * 1e3
+                    best["lone_job_speedup_vs_single_job"] = out["single_job"]["ms_per_step"] / best["lone_job_ms"]
+                    best["ideal_ms"] = ms_per_step / n
+                    best["efficiency"] = best["speedup_vs_1"] / n
+                    fl = share_floor(n)
+                    if fl:
+                        best["lone_job_issue_floor_ms"] = fl["issue_floor_ms"]
+                        best["lone_job_issue_floor_frac"] = fl["issue_floor_ms"] / best["lone_job_ms"]
+                        best["floor_source"] = fl["source"]
                     del sub, bufs
-                best["candidates"] = tried
-                # the floor of a share: ONE launch at a time, no second step to overlap with (what a rank can do at best when
-                # every step has to wait for the one before it)
-                sub = Batch(pose[: S // n], params, args, 1, pipeline=0)     # ONE call: the library's own choice of kernel
-                bufs = [sub.angle_buffer()]
-                k = max(8, min(40, args.steps // 2))
-                dt = timed_steps(sub, bufs, k, 1, warmup=2)
-                best["lone_job_ms"] = dt / k * 1e3
-                best["lone_job_speedup_vs_single_job"] = out["single_job"]["ms_per_step"] / best["lone_job_ms"]
-                best["ideal_ms"] = ms_per_step / n
-                best["efficiency"] = best["speedup_vs_1"] / n
-                fl = share_floor(n)
-                if fl:
-                    best["lone_job_issue_floor_ms"] = fl["issue_floor_ms"]
-                    best["lone_job_issue_floor_frac"] = fl["issue_floor_ms"] / best["lone_job_ms"]
-                    best["floor_source"] = fl["source"]
-                del sub, bufs
-                proj["by_n_gpus"][str(n)] = best
-            out["strong_projection"] = proj
-            # ---- the other synthetic variant -------------------------------------------------------------------
-            other = "smooth" if args.variant == "iid" else "iid"
-            _, _, pose_o, _ = make_workload(S, T, other, synthetic.SEED_BASE)
-            bo = Batch(pose_o, params, args, n_streams, pipeline=batch.pipeline)
-            ko = args.steps
-            dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=args.warmup)
-            ms_o = dto / ko * 1e3
-            _, valu_o, fp64_o, match_o, file_o = pmc_roofline(other, args.staged, key, bo.units, ms_o, device_index)
-            roof_o = {"pmc_matches_build": match_o, "pmc_file": file_o}
-            if fp64_o:
-                tfl_o = fp64_o["flops_per_step"] / (ms_o * 1e-3) / 1e12
-                roof_o.update({"bound": "valu-fp64", "achieved": tfl_o, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": tfl_o / FP64_VECTOR_PEAK_TF, "frac_of_valu_issue_floor": valu_o["frac_of_valu_issue_floor"],
-                               "lane_utilisation": valu_o["lane_utilisation"], "valu_insts_per_step": valu_o["valu_insts_per_step"]})
-            out["variants"] = {other: {"value": bo.units * ko / dto, "unit": "leg-frame solves/s", "ms_per_step": ms_o,
-                                       "steps": ko, "streams": len(bo.streams), "roofline": roof_o},
-                               "note": "smooth = temporally continuous targets (band-limited random walk): the realistic "
-                                       "case; iid = every frame an unrelated pose"}
-            del bo
-            # ---- config 3 as ONE recording (frame chunks) ------------------------------------------------------
-            del d_ang[1:]
-            torch.cuda.empty_cache()
-            del pose_o
-            out["single_recording"] = single_recording(args.frames)
-            # ---- parity vs the committed reference fixtures ----------------------------------------------------
-            out["parity"] = parity_report()
-            out["value_single_job"] = out["single_job"]["value"]
-            # ---- every BASELINE config, reference-shaped calls, in this one line -------------------------------
-            if not args.no_configs:
-                del batch, d_ang
+                    proj["by_n_gpus"][str(n)] = best
+                out["strong_projection"] = proj
+                # ---- the other synthetic variant -------------------------------------------------------------------
+                other = "smooth" if args.variant == "iid" else "iid"
+                _, _, pose_o, _ = make_workload(S, T, other, synthetic.SEED_BASE)
+                bo = Batch(pose_o, params, args, n_streams, pipeline=batch.pipeline)
+                ko = args.steps
+                dto = timed_steps(bo, d_ang, ko, len(bo.streams), warmup=args.warmup)
+                ms_o = dto / ko * 1e3
+                _, valu_o, fp64_o, match_o, file_o = pmc_roofline(other, args.staged, key, bo.units, ms_o, device_index)
+                roof_o = {"pmc_matches_build": match_o, "pmc_file": file_o}
+                if fp64_o:
+                    tfl_o = fp64_o["flops_per_step"] / (ms_o * 1e-3) / 1e12
+                    roof_o.update({"bound": "valu-fp64", "achieved": tfl_o, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tfl_o / FP64_VECTOR_PEAK_TF, "frac_of_valu_issue_floor": valu_o["frac_of_valu_issue_floor"],
+                                   "lane_utilisation": valu_o["lane_utilisation"], "valu_insts_per_step": valu_o["valu_insts_per_step"]})
+                out["variants"] = {other: {"value": bo.units * ko / dto, "unit": "leg-frame solves/s", "ms_per_step": ms_o,
+                                           "steps": ko, "streams": len(bo.streams), "roofline": roof_o},
+                                   "note": "smooth = temporally continuous targets (band-limited random walk): the realistic "
+                                           "case; iid = every frame an unrelated pose"}
+                del bo
+                # ---- config 3 as ONE recording (frame chunks) ------------------------------------------------------
+                del d_ang[1:]
                 torch.cuda.empty_cache()
-                out["configs"] = reference_configs()
-                # config 3 is the headline of this line: the same figures under its key, so that all five configs read alike
-                out["configs"]["3"].update({
-                    "leg_frames": units_per_step, "ms_per_step_three_batches_in_flight": ms_per_step, "leg_frames_per_s": out["value"],
-                    "ms_one_job_at_a_time": out["single_job"]["ms_per_step"], "leg_frames_per_s_one_job_at_a_time": out["value_single_job"],
-                    "smooth_variant_leg_frames_per_s": out["variants"].get("smooth", {}).get("value"),
-                    "one_recording_1M_frames_leg_frames_per_s": out["single_recording"]["value"],
-                    "parity": "every buffer of the timed region == one launch made alone, bit for bit (`verified`); that launch == the C "
-                              "restatement bit for bit on sampled chains (tests/test_gpu_parity.py::test_full_size_synthetic_properties); "
-                              "against the reference itself see `parity_note` in `config`"})
-            _lib.check_faults()   # the device entry points do not synchronise: a kernel fault of any launch above raises here
-            # ---- a handful of scalars at the TOP level of the line: the driver's record keeps top-level scalars only --------
-            def dig(obj, *path):
-                for k in path:
-                    if not isinstance(obj, dict) or k not in obj:
-                        return None
-                    obj = obj[k]
-                return obj
-            cf = out.get("configs", {})
-            par = out["parity"]
-            out.update({
-                "config1_default_ms": dig(cf, "1", "default", "ms"), "config1_auto_ms": dig(cf, "1", "frame_parallel_auto", "ms"),
-                "config2_default_ms": dig(cf, "2", "default", "ms"), "config2_auto_ms": dig(cf, "2", "frame_parallel_auto", "ms"),
-                "config2_64_recordings_leg_frames_per_s": dig(cf, "2", "default_64_recordings_one_call", "leg_frames_per_s"),
-                "config4_default_ms": dig(cf, "4", "default", "ms"), "config4_auto_ms": dig(cf, "4", "frame_parallel_auto", "ms"),
-                "config5_leg_frames_per_s": dig(cf, "5", "one_recording", "value"),
-                "config5_sequences_leg_frames_per_s": dig(cf, "5", "synthetic_sequences", "value"),
-                "generic_6000_frames_s": (dig(cf, "generic", "ms") or 0.0) / 1e3 or None,
-                "generic_batch_leg_frames_per_s": dig(cf, "generic", "batch", "leg_frames_per_s"),
-                "head_kernel_hbm_frac": dig(cf, "4", "head_kernel", "roofline", "frac"),
-                "head_kernel_frac_of_box_copy": dig(cf, "4", "head_kernel", "frac_of_box_copy"),
-                "parity_max_abs_dtheta": max(par[n]["serial_walk"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
-                "parity_p99.9_abs_dtheta": max(par[n]["serial_walk"]["p99.9_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
-                "parity_values_over_5e-5": sum(par[n]["serial_walk"]["values_over_5e-5"] for n in ("anipose_shipped", "df3d_1000")),
-                "parity_leg_frames_over_1e-4_outside_lf_window":
-                    sum(par[n]["serial_walk"]["leg_frames_over_1e-4_outside_lf_window"] for n in ("anipose_shipped", "df3d_1000")),
-                "parity_auto_max_abs_dtheta": max(par[n]["frame_chunks"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
-                "smooth_variant_value": dig(out, "variants", "smooth", "value"),
-                "single_recording_value": dig(out, "single_recording", "value"),
-                "strong_share_n8_ms_per_step": dig(out, "strong_projection", "by_n_gpus", "8", "ms_per_step"),
-                "strong_share_n8_lone_job_ms": dig(out, "strong_projection", "by_n_gpus", "8", "lone_job_ms"),
-                "strong_projected_speedup_n8": dig(out, "strong_projection", "by_n_gpus", "8", "speedup_vs_1"),
-                "roofline_frac": roofline.get("frac"), "roofline_traffic_bytes": roofline.get("traffic"),
-            })
+                del pose_o
+                out["single_recording"] = single_recording(args.frames)
+                # ---- parity vs the committed reference fixtures ----------------------------------------------------
+                out["parity"] = parity_report()
+                out["value_single_job"] = out["single_job"]["value"]
+                # ---- every BASELINE config, reference-shaped calls, in this one line -------------------------------
+                if not args.no_configs:
+                    del batch, d_ang
+                    torch.cuda.empty_cache()
+                    out["configs"] = reference_configs()
+                    # config 3 is the headline of this line: the same figures under its key, so that all five configs read alike
+                    out["configs"]["3"].update({
+                        "leg_frames": units_per_step, "ms_per_step_three_batches_in_flight": ms_per_step, "leg_frames_per_s": out["value"],
+                        "ms_one_job_at_a_time": out["single_job"]["ms_per_step"], "leg_frames_per_s_one_job_at_a_time": out["value_single_job"],
+                        "smooth_variant_leg_frames_per_s": out["variants"].get("smooth", {}).get("value"),
+                        "one_recording_1M_frames_leg_frames_per_s": out["single_recording"]["value"],
+                        "parity": "every buffer of the timed region == one launch made alone, bit for bit (`verified`); that launch == the C "
+                                  "restatement bit for bit on sampled chains (tests/test_gpu_parity.py::test_full_size_synthetic_properties); "
+                                  "against the reference itself see `parity_note` in `config`"})
+                _lib.check_faults()   # the device entry points do not synchronise: a kernel fault of any launch above raises here
+                # ---- a handful of scalars at the TOP level of the line: the driver's record keeps top-level scalars only --------
+                def dig(obj, *path):
+                    for k in path:
+                        if not isinstance(obj, dict) or k not in obj:
+                            return None
+                        obj = obj[k]
+                    return obj
+                cf = out.get("configs", {})
+                par = out["parity"]
+                out.update({
+                    "config1_default_ms": dig(cf, "1", "default", "ms"), "config1_auto_ms": dig(cf, "1", "frame_parallel_auto", "ms"),
+                    "config2_default_ms": dig(cf, "2", "default", "ms"), "config2_auto_ms": dig(cf, "2", "frame_parallel_auto", "ms"),
+                    "config2_64_recordings_leg_frames_per_s": dig(cf, "2", "default_64_recordings_one_call", "leg_frames_per_s"),
+                    "config4_default_ms": dig(cf, "4", "default", "ms"), "config4_auto_ms": dig(cf, "4", "frame_parallel_auto", "ms"),
+                    "config5_leg_frames_per_s": dig(cf, "5", "one_recording", "value"),
+                    "config5_sequences_leg_frames_per_s": dig(cf, "5", "synthetic_sequences", "value"),
+                    "generic_6000_frames_s": (dig(cf, "generic", "ms") or 0.0) / 1e3 or None,
+                    "generic_batch_leg_frames_per_s": dig(cf, "generic", "batch", "leg_frames_per_s"),
+                    "head_kernel_hbm_frac": dig(cf, "4", "head_kernel", "roofline", "frac"),
+                    "head_kernel_frac_of_box_copy": dig(cf, "4", "head_kernel", "frac_of_box_copy"),
+                    "parity_max_abs_dtheta": max(par[n]["serial_walk"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                    "parity_p99.9_abs_dtheta": max(par[n]["serial_walk"]["p99.9_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                    "parity_values_over_5e-5": sum(par[n]["serial_walk"]["values_over_5e-5"] for n in ("anipose_shipped", "df3d_1000")),
+                    "parity_leg_frames_over_1e-4_outside_lf_window":
+                        sum(par[n]["serial_walk"]["leg_frames_over_1e-4_outside_lf_window"] for n in ("anipose_shipped", "df3d_1000")),
+                    "parity_auto_max_abs_dtheta": max(par[n]["frame_chunks"]["max_abs_dtheta"] for n in ("anipose_shipped", "df3d_1000")),
+                    "smooth_variant_value": dig(out, "variants", "smooth", "value"),
+                    "single_recording_value": dig(out, "single_recording", "value"),
+                    "strong_share_n8_ms_per_step": dig(out, "strong_projection", "by_n_gpus", "8", "ms_per_step"),
+                    "strong_share_n8_lone_job_ms": dig(out, "strong_projection", "by_n_gpus", "8", "lone_job_ms"),
+                    "strong_projected_speedup_n8": dig(out, "strong_projection", "by_n_gpus", "8", "speedup_vs_1"),
+                    "roofline_frac": roofline.get("frac"), "roofline_traffic_bytes": roofline.get("traffic"),
+                })
+            except Exception as exc:  # noqa: BLE001
+                import traceback
+                out["extras_error"] = f"{type(exc).__name__}: {exc}"
+                sys.stderr.write("bench.py: an extra leg failed, the headline is printed without the rest:\n" + traceback.format_exc())
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline_value"] = out["cpu_baseline"]["value"]
-            out["cpu_baseline_cores"] = out["cpu_baseline"]["cores"]
+            try:
+                out["cpu_baseline"] = cpu_baseline(pose, legs, body, args.cpu_sample_seqs, not args.no_python_baseline)
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                out["cpu_baseline_value"] = out["cpu_baseline"]["value"]
+                out["cpu_baseline_cores"] = out["cpu_baseline"]["cores"]
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
