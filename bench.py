@@ -340,8 +340,13 @@ def depth_candidates(steps, chains=None):
     `chains`: chains per step -- depths that would put more than twice the GPU's wavefront slots in flight are left out (the
     whole problem: 3 and 4; a 1/8 share: everything): deeper buys nothing there, and every stream is a hardware queue, of
     which a process should not hold more than it needs (see the strong_projection leg)."""
-    cap = MAX_DEPTH if not chains else max(3, min(MAX_DEPTH, -(-2 * 3072 // max(1, -(-chains // 64)))))
+    cap = depth_cap(chains)
     return [c for c in _depth_candidates(steps) if c[0] <= cap]
+
+
+def depth_cap(chains):
+    """Steps in flight beyond which a batch of `chains` chains has more than twice the GPU's 3 072 wavefront slots in flight."""
+    return MAX_DEPTH if not chains else max(3, min(MAX_DEPTH, -(-2 * 3072 // max(1, -(-chains // 64)))))
 
 
 def _depth_candidates(steps):
@@ -1479,13 +1484,18 @@ def main():
                 pose2, _, _, _, units_all2 = workload_for(other_scaling)
                 pad2 = max(sharding.rank_share(S_total, world, r, other_scaling)[1] - sharding.rank_share(S_total, world, r, other_scaling)[0]
                            for r in range(world))
-                b2 = Batch(pose2, params, args, n_streams, pipeline=batch.pipeline, s_pad=pad2)
-                bufs2 = [b2.angle_buffer() for _ in range(n_buf)]
-                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf, min_gbps=8.0, prefer=headline_kind)
+                # (its own depth: the headline's may be 20 steps of a 1/8 share in flight; 20 whole problems are 22 x 7 x 336 MB of
+                # receive buffers on rank 0 for nothing -- a batch that fills the GPU runs 3 deep on the library's kernel choice)
+                n_st2 = min(n_streams, depth_cap(int(pose2.shape[0]) * L))
+                pipe2 = batch.pipeline if n_st2 > 3 else 0
+                n_buf2 = max(2, n_st2 + 2)
+                b2 = Batch(pose2, params, args, n_st2, pipeline=pipe2, s_pad=pad2)
+                bufs2 = [b2.angle_buffer() for _ in range(n_buf2)]
+                g2, desc = peer_gather.make_gather(dist, world, rank, bufs2[0], n_buffers=n_buf2, min_gbps=8.0, prefer=headline_kind)
                 k2 = max(4, min(40, args.steps))
                 tm, mine2 = timed_region(b2, bufs2, g2, k2, min(3, args.warmup))
                 res = {"value": units_all2 * k2 / tm, "unit": "leg-frame solves/s", "ms_per_step": tm / k2 * 1e3,
-                       "steps": k2, "scaling": other_scaling, "sequences_per_gpu": int(pose2.shape[0]),
+                       "steps": k2, "scaling": other_scaling, "streams": n_st2, "stage_pipeline": pipe2, "sequences_per_gpu": int(pose2.shape[0]),
                        "leg_frames_per_step_all_ranks": int(units_all2), "gather": desc, "rank_ms_per_step": rank_ms(mine2, k2)}
                 if hasattr(g2, "close"):
                     g2.close()
