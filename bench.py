@@ -1332,6 +1332,8 @@ def main():
         roofline["stage_ms"] = [float(v) for v in mean_stage_ms]
         roofline["path_GBps"] = BYTES_PATH * units_per_step / (mean_stage_ms.sum() * 1e-3) / 1e9
 
+    frames_txt = "1M" if S_total * T == 1_000_000 else f"{S_total * T:,}".replace(",", " ")
+
     def make_out():
         """The JSON line's headline part (everything that is known once the timed region and the roofline are done)."""
         return {
@@ -1342,10 +1344,10 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("config 3: synthetic 1M frames x 6 legs, in-workspace targets" if world == 1 else
-                                    "config 3 (weak-scaling variant): synthetic 1M frames x 6 legs PER GPU, in-workspace targets"
+            "config": {"workload": (f"config 3: synthetic {frames_txt} frames x 6 legs, in-workspace targets" if world == 1 else
+                                    f"config 3 (weak-scaling variant): synthetic {frames_txt} frames x 6 legs PER GPU, in-workspace targets"
                                     if args.scaling == "weak" else
-                                    f"config 3 literally: the FIXED problem of synthetic 1M frames x 6 legs IN TOTAL ({S_total} "
+                                    f"config 3 literally: the FIXED problem of synthetic {frames_txt} frames x 6 legs IN TOTAL ({S_total} "
                                     f"sequences of {T} frames), sequences split over the {world} ranks, joint angles gathered on rank 0"),
                        "frames_total": S_total * T * (world if args.scaling == "weak" else 1),
                        "leg_frames_per_step_all_ranks": int(units_all),
