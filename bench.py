@@ -1018,6 +1018,38 @@ def reference_configs(time_box_s=240.0):
     return out
 
 
+class Lifeline:
+    """What an N > 1 run prints if it gets stuck.  Everything such a run does is a collective over the ranks, and a rank that
+    fails where the others do not leaves them waiting for ever: the measurement that IS already made must still come out.
+    Every rank arms the same deadline at the same points of the program (behind a collective); when it passes, rank 0 prints
+    the best line there is so far -- `line_fn()` -- and every rank leaves with exit code 0."""
+
+    def __init__(self, rank, json_fd):
+        import threading
+        self.rank, self.json_fd, self.deadline, self.line_fn, self.what = rank, json_fd, None, None, ""
+        t = threading.Thread(target=self._watch, daemon=True)
+        t.start()
+
+    def arm(self, seconds, line_fn, what):
+        self.line_fn, self.what, self.deadline = line_fn, what, time.time() + seconds
+
+    def disarm(self):
+        self.deadline = None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.25)
+            d = self.deadline
+            if d is not None and time.time() > d:
+                try:
+                    if self.rank == 0 and self.line_fn is not None:
+                        os.write(self.json_fd, (json.dumps(self.line_fn()) + "\n").encode())
+                    sys.stderr.write(f"bench.py rank {self.rank}: {self.what} did not finish in time -- the line measured so far "
+                                     "is printed, leaving\n")
+                finally:
+                    os._exit(0)
+
+
 def main():
     args = parse()
     # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to fd 1 when its communicator
@@ -1167,6 +1199,27 @@ def main():
         # angle buffers: one per step in flight + two spare, so that a gather that is still draining (it only gets CU slots
         # as solver waves retire) does not hold back the launch that wants to reuse its buffer
         return [bt.angle_buffer() for _ in range(max(2, len(bt.streams) + (2 if use_dist else 0)))]
+
+    lifeline = Lifeline(rank, json_fd) if (use_dist and world > 1) else None
+    if lifeline is not None:
+        # A PROVISIONAL headline first, on the plainest path there is (3 steps in flight, the library's kernel choice, grouped
+        # RCCL point-to-point as the gather): should a calibration, a gather probe or a leg below ever get stuck, this is the
+        # line that comes out (marked provisional) instead of nothing.
+        bufs0 = buffers_for(batch)
+        g0 = sharding.GatherPipeline(dist, world, rank, bufs0[0], dst=0, n_buffers=len(bufs0))
+        tm0, _ = timed_region(batch, bufs0, g0, args.steps, args.warmup)
+        prov = {"metric": "leg-IK solves/s (frames x 6 legs)", "value": units_all * args.steps / tm0, "unit": "leg-frame solves/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": tm0 / args.steps * 1e3,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"config 3, {args.scaling} scaling over {world} ranks ({S_total} sequences of {T} frames x 6 legs"
+                                       f"{' per GPU' if args.scaling == 'weak' else ' in total'}), PROVISIONAL measurement: 3 steps in flight, "
+                                       "library's kernel choice, grouped RCCL point-to-point gather -- the run got stuck behind it",
+                           "provisional": True, "streams": len(batch.streams), "sequences_per_gpu": S, "legs": L, "frames_per_sequence": T},
+                "roofline": {"bound": "hbm", "achieved": BYTES_PATH * units_per_step / (tm0 / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": BYTES_PATH * units_per_step / (tm0 / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "note": "algorithmic bytes of this rank's share / wall time per step (no kernel events in the provisional line)"}}
+        del bufs0, g0
+        lifeline.arm(float(os.environ.get("SEQIK_BENCH_STAGE_TIMEOUT", "900")), lambda: prov, "the calibrations / the headline")
 
     if not explicit_depth:
         # How many steps to keep in flight, and on which kernel family: measured here, on this rank's batch, with the gather
@@ -1388,27 +1441,18 @@ def main():
         if not args.no_extras:
             # The headline is measured.  The legs below are collectives over all ranks: if one of them ever hangs (a rank that
             # fails where the others do not and never enters the collective they wait in), the line must still come out --
-            # every rank runs the same timer from here; when it fires, rank 0 prints the headline with the legs finished so
-            # far and every rank leaves with exit code 0.
-            import threading
+            # the lifeline (armed on every rank alike) prints the headline with the legs finished so far.
             legs_deadline_s = float(os.environ.get("SEQIK_BENCH_LEGS_TIMEOUT", "600"))
 
-            def give_up():
+            def line_with_legs_so_far():
+                o = make_out()
                 try:
-                    if rank == 0:
-                        o = make_out()
-                        try:
-                            o["multi_gpu"] = dict(multi, legs_timed_out_after_s=legs_deadline_s)
-                        except RuntimeError:     # (the main thread was adding a leg at this very moment)
-                            o["multi_gpu"] = {"legs_timed_out_after_s": legs_deadline_s}
-                        os.write(json_fd, (json.dumps(o) + "\n").encode())
-                    sys.stderr.write(f"bench.py rank {rank}: extra legs did not finish within {legs_deadline_s:.0f} s -- headline printed, leaving\n")
-                finally:
-                    os._exit(0)
+                    o["multi_gpu"] = dict(multi, legs_timed_out_after_s=legs_deadline_s)
+                except RuntimeError:     # (the main thread was adding a leg at this very moment)
+                    o["multi_gpu"] = {"legs_timed_out_after_s": legs_deadline_s}
+                return o
 
-            legs_timer = threading.Timer(legs_deadline_s, give_up)
-            legs_timer.daemon = True
-            legs_timer.start()
+            lifeline.arm(legs_deadline_s, line_with_legs_so_far, "the extra legs")
 
             def guarded(name, fn):
                 """One extra leg.  The headline above is measured and must survive whatever happens here: a leg that
@@ -1562,7 +1606,8 @@ def main():
                 oth = multi.get(other_scaling)
                 if oth and "value" in oth:
                     oth["efficiency_vs_n1"] = oth["value"] / (world * n1["value"])
-            legs_timer.cancel()
+    if lifeline is not None:
+        lifeline.disarm()
 
     if rank == 0:
         out = make_out()
