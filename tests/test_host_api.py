@@ -1,6 +1,8 @@
 """CPU tier: host-side mirror of the reference interface -- chain factories, constants,
 argument checks (mirrors the reference's tests/test_kin_chain.py: link names per stage,
 ValueError on bad leg / stage)."""
+import os
+
 import numpy as np
 import pytest
 
