@@ -272,13 +272,13 @@ def test_bench_lifeline_prints_the_line_so_far_and_leaves():
     import subprocess
     import sys
     from conftest import ROOT
-    code = ("import importlib.util, os, sys, time\\n"
-            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\\n"
-            "rank = int(sys.argv[1])\\n"
-            "l = b.Lifeline(rank, 1)\\n"
-            "l.arm(30.0, lambda: {'never': 1}, 'first stage'); l.disarm(); time.sleep(0.6)\\n"
-            "l.arm(0.2, lambda: {'value': 42, 'provisional': True}, 'second stage')\\n"
-            "time.sleep(5); print('NOT REACHED')\\n" % os.path.join(ROOT, "bench.py"))
+    code = ("import importlib.util, os, sys, time\n"
+            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "rank = int(sys.argv[1])\n"
+            "l = b.Lifeline(rank, 1)\n"
+            "l.arm(30.0, lambda: {'never': 1}, 'first stage'); l.disarm(); time.sleep(0.6)\n"
+            "l.arm(0.2, lambda: {'value': 42, 'provisional': True}, 'second stage')\n"
+            "time.sleep(5); print('NOT REACHED')\n" % os.path.join(ROOT, "bench.py"))
     r0 = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=300)
     assert r0.returncode == 0 and r0.stdout.strip() == '{"value": 42, "provisional": true}', r0.stdout + r0.stderr
     assert "second stage did not finish in time" in r0.stderr and "NOT REACHED" not in r0.stdout
