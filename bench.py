@@ -1219,7 +1219,7 @@ def main():
                              "unit": "GB/s", "frac": BYTES_PATH * units_per_step / (tm0 / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "note": "algorithmic bytes of this rank's share / wall time per step (no kernel events in the provisional line)"}}
         del bufs0, g0
-        lifeline.arm(float(os.environ.get("SEQIK_BENCH_STAGE_TIMEOUT", "900")), lambda: prov, "the calibrations / the headline")
+        lifeline.arm(float(os.environ.get("SEQIK_BENCH_STAGE_TIMEOUT", "300")), lambda: prov, "the calibrations / the headline")
 
     if not explicit_depth:
         # How many steps to keep in flight, and on which kernel family: measured here, on this rank's batch, with the gather
@@ -1442,7 +1442,7 @@ def main():
             # The headline is measured.  The legs below are collectives over all ranks: if one of them ever hangs (a rank that
             # fails where the others do not and never enters the collective they wait in), the line must still come out --
             # the lifeline (armed on every rank alike) prints the headline with the legs finished so far.
-            legs_deadline_s = float(os.environ.get("SEQIK_BENCH_LEGS_TIMEOUT", "600"))
+            legs_deadline_s = float(os.environ.get("SEQIK_BENCH_LEGS_TIMEOUT", "300"))
 
             def line_with_legs_so_far():
                 o = make_out()
