@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "sequential-inverse-kinematics_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-import bench  # noqa: E402
+import bench_support as bench  # noqa: E402
 from seqikpy_amd import _lib, synthetic  # noqa: E402
 
 

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.argv = [sys.argv[0]]
 import numpy as np  # noqa: E402
 
-import bench  # noqa: E402
+import bench_extras as bench  # noqa: E402
 
 za = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
 print(json.dumps(bench.generic_batches(za)))

@@ -165,17 +165,23 @@ def test_host_objects_are_picklable_like_the_reference_parallel_example_needs():
     assert gen.kinematic_chain_class.create_leg_chain("RF").links[-1].name == "RF_Claw"
 
 
-def test_package_import_asks_for_eight_hardware_queues():
-    """Streams of one process only overlap on separate hardware queues (HIP default: 4); the package asks for 8
-    before the runtime starts unless the user has set the variable (Multi-GPU (i))."""
+def test_package_import_leaves_the_environment_alone():
+    """Round-5 review, item 7: importing the package does not touch os.environ (a library must not change the process it
+    is loaded into); `recommended_env()` RETURNS what a process should start with, `SEQIK_SET_ENV=1` makes the import apply
+    it (explicit settings win), `runtime_env()` reports what is set."""
     import subprocess
     import sys
     from conftest import PKG_PARENT
-    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); import seqikpy_amd; "
-            "print(os.environ['GPU_MAX_HW_QUEUES']); os.environ['GPU_MAX_HW_QUEUES'] = '2'; "
-            "import importlib; importlib.reload(seqikpy_amd); print(os.environ['GPU_MAX_HW_QUEUES'])") % PKG_PARENT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
-    assert out == ["8", "2"]
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None); os.environ.pop('SEQIK_SET_ENV', None); "
+            "before = dict(os.environ); import seqikpy_amd; print(dict(os.environ) == before); "
+            "print(seqikpy_amd.recommended_env()['GPU_MAX_HW_QUEUES'], seqikpy_amd.recommended_env(20)['GPU_MAX_HW_QUEUES'], "
+            "seqikpy_amd.recommended_env(40)['GPU_MAX_HW_QUEUES']); "
+            "os.environ['SEQIK_SET_ENV'] = '1'; import importlib; importlib.reload(seqikpy_amd); print(os.environ['GPU_MAX_HW_QUEUES']); "
+            "os.environ['GPU_MAX_HW_QUEUES'] = '2'; importlib.reload(seqikpy_amd); print(os.environ['GPU_MAX_HW_QUEUES']); "
+            "print(sorted(seqikpy_amd.runtime_env()))") % PKG_PARENT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "True" and out[1].split() == ["8", "22", "22"] and out[2] == "8" and out[3] == "2"
+    assert "GPU_MAX_HW_QUEUES" in out[4] and "SEQIK_SET_ENV" in out[4]
 
 
 def test_frame_parallel_default_and_chunk_report(monkeypatch):
@@ -236,15 +242,14 @@ def test_output_side_converters_and_resampling():
 
 def test_bench_depth_candidates_cover_the_measured_region():
     """bench.py calibrates how many steps it keeps in flight over exactly the region it measures: the candidate
-    list is a function of the step count -- the fixed depths, the balanced depth (fewest rounds of at most 16, equal size) and
-    depth 16 with a short last round on the latency kernel; never more than 16 (more streams than hardware queues collapse)."""
-    import importlib.util
+    list is a function of the step count -- the fixed depths, the balanced depth (fewest rounds of at most 20, equal size) and
+    depths 16 / 20 with a short last round on the latency kernel; never more than 20 (more streams than hardware queues collapse)."""
     import os
+    import sys
     from conftest import ROOT
-    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    assert os.environ.get("GPU_MAX_HW_QUEUES") is not None
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench_support as bench
     assert bench.MAX_DEPTH == 20
     c20 = bench.depth_candidates(20)
     assert c20[:5] == [(3, 0, None), (8, 1, None), (12, 1, None), (16, 1, None), (20, 1, None)]
@@ -260,27 +265,43 @@ def test_bench_depth_candidates_cover_the_measured_region():
     # the whole problem brings 1 465 wavefronts per step: depths beyond 2 x 3 072 slots / that are left out; a 1/8 share keeps all
     assert bench.depth_candidates(20, 93750) == [(3, 0, None)] and len(bench.depth_candidates(20, 11718)) == 6
     assert [c[0] for c in bench.depth_candidates(20, 46872)] == [3, 8]
-    # (bench.py asks for 22 hardware queues before anything imports the HIP runtime -- 24 held queues cost the other kernels of
-    # a process 10 % --; in THIS process the package was imported first)
+    # bench.py asks for the environment of 20 steps in flight (22 hardware queues: 24 held queues cost the other kernels of a
+    # process 10 %) in its __main__ block, before anything imports the HIP runtime, and records what it ran with
+    import seqikpy_amd
+    assert seqikpy_amd.recommended_env(steps_in_flight=bench.MAX_DEPTH)["GPU_MAX_HW_QUEUES"] == "22"
     with open(os.path.join(ROOT, "bench.py")) as fh:
-        assert 'os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")' in fh.read()
+        text = fh.read()
+    assert "recommended_env(steps_in_flight=20)" in text and '"env": runtime_env()' in text
 
 
 def test_bench_lifeline_prints_the_line_so_far_and_leaves():
-    """bench.Lifeline: when an armed deadline passes, rank 0 writes the line the caller registered to the JSON descriptor and
-    the process leaves with exit code 0 (other ranks write nothing); a disarmed lifeline does nothing."""
+    """bench_support.Lifeline: when an armed deadline passes, rank 0 writes the line the caller registered to the JSON descriptor
+    and the process leaves with the exit code the deadline was armed with -- 75 while only the provisional headline exists, 0 once
+    the verified headline is what gets printed (round-5 advice: a stuck run must not look healthy); other ranks write nothing; a
+    disarmed lifeline does nothing."""
     import subprocess
     import sys
     from conftest import ROOT
-    code = ("import importlib.util, os, sys, time\n"
-            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
-            "rank = int(sys.argv[1])\n"
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import bench_support as b\n"
+            "rank, code = int(sys.argv[1]), int(sys.argv[2])\n"
             "l = b.Lifeline(rank, 1)\n"
-            "l.arm(30.0, lambda: {'never': 1}, 'first stage'); l.disarm(); time.sleep(0.6)\n"
-            "l.arm(0.2, lambda: {'value': 42, 'provisional': True}, 'second stage')\n"
-            "time.sleep(5); print('NOT REACHED')\n" % os.path.join(ROOT, "bench.py"))
-    r0 = subprocess.run([sys.executable, "-c", code, "0"], capture_output=True, text=True, timeout=300)
-    assert r0.returncode == 0 and r0.stdout.strip() == '{"value": 42, "provisional": true}', r0.stdout + r0.stderr
-    assert "second stage did not finish in time" in r0.stderr and "NOT REACHED" not in r0.stdout
-    r1 = subprocess.run([sys.executable, "-c", code, "1"], capture_output=True, text=True, timeout=300)
-    assert r1.returncode == 0 and r1.stdout.strip() == "" and "leaving" in r1.stderr
+            "l.arm(30.0, lambda: 'never', 'first stage', 75); l.disarm(); time.sleep(0.6)\n"
+            "l.arm(0.2, lambda: '{\"value\": 42}', 'second stage', code)\n"
+            "time.sleep(8); print('NOT REACHED')\n" % ROOT)
+    for want in (75, 0):
+        r0 = subprocess.run([sys.executable, "-c", code, "0", str(want)], capture_output=True, text=True, timeout=300)
+        assert r0.returncode == want and r0.stdout.strip() == '{"value": 42}', r0.stdout + r0.stderr
+        assert "second stage did not finish in time" in r0.stderr and "NOT REACHED" not in r0.stdout
+    assert b_exit_provisional() == 75
+    r1 = subprocess.run([sys.executable, "-c", code, "1", "75"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 75 and r1.stdout.strip() == "" and "leaving" in r1.stderr
+
+
+def b_exit_provisional():
+    import sys
+    from conftest import ROOT
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench_support
+    return bench_support.Lifeline.EXIT_PROVISIONAL
