@@ -26,6 +26,9 @@ Fixtures (all float64 unless noted; DOF order = c_oracle.DOFS):
   df3d_align_pins.npz   reference-HELD pins of the alignment row on all six legs: the un-aligned df3d key points of
                         frames 300:400 (seqikpy_locomotion.ipynb cell 2), the six find_scale_leg values the
                         notebook's stored cell-6 output prints, and the shipped pose3d_aligned.pkl of that cut
+  df3d_notebook_cell16.png  (an image, not an .npz) the STORED OUTPUT of seqikpy_locomotion.ipynb cell 16: real ikpy 3.3.4's
+                        joint angles of all six legs x 100 frames (the df3d_100 inputs), as the plot the notebook keeps --
+                        the only real-IKPy output for RM / RH / LM / LH and BOUNDS_LOCOMOTION in reach (tests/test_notebook_pin.py)
 """
 import argparse
 import importlib.util
@@ -249,6 +252,21 @@ def gen_df3d_align_pins():
     return out
 
 
+def gen_df3d_notebook_cell16():
+    """Image data held by the reference (nothing is run or imported): the PNG that examples/seqikpy_locomotion.ipynb keeps as
+    the output of its cell 16 -- `leg_joint_angles` of cell 14 (LegInvKinSeq.run_ik_and_fk over real ikpy on frames 300:400 of
+    the df3d recording, all six legs) plotted in degrees, 3 x 2 axes, figsize (9, 7), dpi 200, lw 2.  Returned as bytes."""
+    import base64
+    import json
+    with open(os.path.join(REFERENCE_ROOT, "examples", "seqikpy_locomotion.ipynb")) as fh:
+        nb = json.load(fh)
+    cell = nb["cells"][16]
+    assert cell["cell_type"] == "code" and "leg_joint_angles[f\"Angle_{leg_name}_{angle_name}\"]" in "".join(cell["source"])
+    pngs = [o["data"]["image/png"] for o in cell["outputs"] if "image/png" in o.get("data", {})]
+    assert len(pngs) == 1
+    return base64.b64decode(pngs[0])
+
+
 GENERATORS = {
     "anipose_shipped": gen_anipose_shipped,
     "anipose_scipy_cut": gen_anipose_scipy_cut,
@@ -258,6 +276,7 @@ GENERATORS = {
     "anipose_head": gen_anipose_head,
     "anipose_raw_cut": gen_anipose_raw_cut,
     "df3d_align_pins": gen_df3d_align_pins,
+    "df3d_notebook_cell16": gen_df3d_notebook_cell16,
 }
 
 
@@ -271,8 +290,13 @@ def main():
             continue
         t0 = time.time()
         data = fn()
-        path = os.path.join(OUT, name + ".npz")
-        np.savez_compressed(path, **data)
+        if isinstance(data, bytes):          # an image the reference holds, kept as it is
+            path = os.path.join(OUT, name + ".png")
+            with open(path, "wb") as fh:
+                fh.write(data)
+        else:
+            path = os.path.join(OUT, name + ".npz")
+            np.savez_compressed(path, **data)
         print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB in {time.time() - t0:.1f} s")
 
 
