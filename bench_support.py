@@ -108,7 +108,7 @@ _STREAMS = []
 def stream_pool(n):
     """The first n streams of ONE pool per process (the current stream first): every batch of a run launches on the same
     streams, so the process never holds more streams than the deepest pipeline asks for -- the library keeps a hand-off
-    workspace per (device, stream), at most 16 of them, and the hardware queues are as few."""
+    workspace per (device, stream), at most 64 of them, and the hardware queues are fewer (GPU_MAX_HW_QUEUES)."""
     if not _STREAMS:
         _STREAMS.append(torch.cuda.current_stream())
     while len(_STREAMS) < n:

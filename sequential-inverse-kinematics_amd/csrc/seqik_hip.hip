@@ -115,15 +115,19 @@ void fault_block()
     });
 }
 
-// slot of (current device, stream): found or assigned; the table never shrinks (streams are pooled by every caller in
-// this tree); when it is full the last slot is shared
-int fault_slot(hipStream_t stream)
+// slot of (current device, stream).  `assign` = false (the CHECK paths: seqik_check_faults_stream, the entry check of the device
+// entry points): lookup only, -1 for a stream nothing was ever launched on -- a caller that polls or enters on transient
+// streams (torch's pools hold 32 streams per device and priority) must not use the table up.  `assign` = true (a LAUNCH):
+// found or assigned; the table never shrinks (streams are pooled by every caller in this tree); when it is full the last slot
+// is shared.
+int fault_slot(hipStream_t stream, bool assign)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
     std::lock_guard<std::mutex> lock(g_fault_mu);
     for (int i = 0; i < g_fault_used; ++i)
         if (g_fault_dev[i] == dev && g_fault_stream[i] == stream) return i;
+    if (!assign) return g_fault_used >= kFaultSlots - 1 ? kFaultSlots - 1 : -1;  // (table full: launches share the last word)
     if (g_fault_used < kFaultSlots - 1) {
         g_fault_dev[g_fault_used] = dev;
         g_fault_stream[g_fault_used] = stream;
@@ -136,14 +140,16 @@ int32_t *fault_word(hipStream_t stream)
 {
     fault_block();
     if (!g_fault_device) return nullptr;  // no mapped host memory on this system -- the watchdog then only leaves its NaN
-    return g_fault_device + fault_slot(stream);
+    return g_fault_device + fault_slot(stream, true);
 }
 
-// reads and clears the fault word of `slot` (-1: every word); SEQIK_OK or SEQIK_ERR_HIP with the message set
+constexpr int kNoSlot = -2;   // check_faults: a stream nothing was launched on has no fault to report
+
+// reads and clears the fault word of `slot` (-1: every word; kNoSlot: none); SEQIK_OK or SEQIK_ERR_HIP with the message set
 int check_faults(const char *where, int slot)
 {
     int32_t *words = g_fault_host.load(std::memory_order_acquire);
-    if (!words) return SEQIK_OK;   // nothing has been launched yet
+    if (!words || slot == kNoSlot) return SEQIK_OK;   // nothing has been launched yet (at all / on that stream)
     int32_t v = 0;
     const int lo = slot < 0 ? 0 : slot, hi = slot < 0 ? kFaultSlots : slot + 1;
     for (int i = lo; i < hi; ++i) {
@@ -156,6 +162,12 @@ int check_faults(const char *where, int slot)
              "remaining frames of its chain hold NaN -- the results of the calls since the last check are invalid",
              where, (int)v, (int)seqik::PIPE_SPIN_LIMIT);
     return SEQIK_ERR_HIP;
+}
+
+int known_slot(hipStream_t stream)
+{
+    const int slot = fault_slot(stream, false);
+    return slot < 0 ? kNoSlot : slot;
 }
 
 struct LegOrder {  // dispatch order of the legs, see chain_of_lane()
@@ -1081,6 +1093,7 @@ struct Workspace {
 // per call, the time of one call alone, against 2.0 ms on 16 streams; profiles/r05_stream_cliff.jsonl.)
 constexpr int kMaxWorkspaces = 64;
 std::mutex g_ws_mutex;
+std::mutex g_queue_enqueue_mutex;   // chain queue: {zero the counters, launch} is one unit per stream (see the launch)
 std::vector<Workspace> g_ws;
 uint64_t g_ws_clock = 0;
 
@@ -1491,7 +1504,7 @@ int seqik_check_faults(void) { return check_faults("seqik_check_faults", -1); }
 int seqik_check_faults_stream(void *hip_stream)
 {
     if (!g_fault_host.load(std::memory_order_acquire)) return SEQIK_OK;  // nothing has been launched yet
-    return check_faults("seqik_check_faults_stream", fault_slot(static_cast<hipStream_t>(hip_stream)));
+    return check_faults("seqik_check_faults_stream", known_slot(static_cast<hipStream_t>(hip_stream)));
 }
 
 int seqik_validate_legs(const SeqikLegParams *legs, int32_t n_legs, int32_t first_stage, int32_t last_stage)
@@ -1522,7 +1535,7 @@ int seqik_solve_seq_device(const double *d_pose, int64_t n_seq, int32_t n_legs, 
     // asynchronous: a fault of THIS launch cannot be known yet; one an earlier launch left behind is reported now
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     if (g_fault_host.load(std::memory_order_acquire) &&
-        (rc = check_faults("seqik_solve_seq_device (fault of an earlier launch on this stream)", fault_slot(stream))) != SEQIK_OK)
+        (rc = check_faults("seqik_solve_seq_device (fault of an earlier launch on this stream)", known_slot(stream))) != SEQIK_OK)
         return rc;
     const seqik::LegConst *d_legs = nullptr;
     rc = device_leg_table(legs, affine, n_legs, &d_legs);
@@ -1602,6 +1615,11 @@ int seqik_solve_generic_device(const double *d_pose, int64_t n_seq, int32_t n_le
             double *ws = nullptr;
             if (int rc2 = workspace_for(stream, 256, &ws)) return rc2;
             int32_t *counters = reinterpret_cast<int32_t *>(ws);
+            // The per-leg counters live in the stream's workspace: zeroing them and launching the kernel that consumes them must
+            // reach the stream as ONE unit.  Two host threads launching on the same stream (both passing stream 0, say) could
+            // otherwise enqueue memset A, memset B, kernel A, kernel B -- kernel B would find every counter exhausted and retire
+            // without writing a result, and the call would still return SEQIK_OK (round-5 advice).  Both are enqueues (~10 us).
+            std::lock_guard<std::mutex> enqueue_lock(g_queue_enqueue_mutex);
             HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int32_t) * kMaxLegs, stream));
             const int64_t q_waves = n_waves < slots ? n_waves : slots;
             const dim3 q_grid((unsigned)q_waves), q_blk(64);
@@ -1746,7 +1764,7 @@ int seqik_solve_seq(const double *pose, int64_t n_seq, int32_t n_legs, int64_t n
     if (status) TRY_OUT(hipMemcpyAsync(status, d_status, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     if (nfev) TRY_OUT(hipMemcpyAsync(nfev, d_nfev, sizeof(int32_t) * 4 * n_lf, hipMemcpyDeviceToHost, stream));
     TRY_OUT(hipStreamSynchronize(stream));
-    return check_faults("seqik_solve_seq", fault_slot(stream));
+    return check_faults("seqik_solve_seq", known_slot(stream));
 }
 
 // Self-test hook of the floating-point contract: q[i] = div_(a[i], b[i]), r[i] = sqrt_(a[i]) on the device.

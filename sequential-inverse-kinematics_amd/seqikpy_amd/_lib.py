@@ -15,8 +15,12 @@ from .data import DOFS, SEGMENTS
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_PKG), "csrc")
-# in the source tree: csrc/ next to the package; installed (pyproject.toml / setup.py): the built library inside it
-_LIB_DIR = CSRC if os.path.isdir(CSRC) else os.path.join(_PKG, "_native")
+# installed (pyproject.toml / setup.py): the built library inside the package wins whenever it exists; the source tree is
+# recognised by a file of THIS project next to the package -- a stray top-level csrc/ in site-packages (several native packages
+# install one) must not switch an installed package into tree mode (round-5 advice)
+_NATIVE = os.path.join(_PKG, "_native")
+_IN_TREE = not os.path.isfile(os.path.join(_NATIVE, "libseqik_hip.so")) and os.path.isfile(os.path.join(CSRC, "seqik_hip.hip"))
+_LIB_DIR = CSRC if _IN_TREE else _NATIVE
 LIB_PATH = os.environ.get("SEQIK_LIB", os.path.join(_LIB_DIR, "libseqik_hip.so"))  # SEQIK_LIB: A/B builds
 SOURCES = ["seqik_hip.hip", "seqik_head.hip", "seqik_stream.hip", "seqik_align.hip", "seqik_peer.hip", "seqik_core.hpp",
            "seqik_consts.hpp", "seqik_head.hpp", "seqik_generic.hpp", "seqik_device_scope.hpp", "seqik_hostctx.hpp"]
@@ -180,7 +184,7 @@ def csrc_sha256(files=None, read=None) -> str:
 
 
 def is_stale() -> bool:
-    if not os.path.isdir(CSRC):
+    if not _IN_TREE:
         return False          # installed package: the library was compiled when the distribution was built
     if not os.path.exists(LIB_PATH):
         return True

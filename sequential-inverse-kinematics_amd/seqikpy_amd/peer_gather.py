@@ -164,7 +164,12 @@ def make_gather(dist, world: int, rank: int, like, n_buffers: int, dst: int = 0,
     """The gather pipeline for this process group: ``PeerWriteGather`` when it works on every rank (and each link
     delivers at least ``min_gbps``), else ``GatherPipeline``.  ``prefer``: "peer" / "rccl" / None = the environment
     variable SEQIK_GATHER or "auto" (peer writes for device buffers, point-to-point of the process group otherwise).
-    Returns (pipeline, description)."""
+    Returns (pipeline, description).
+
+    COLLECTIVE: every rank of the group must enter it (the shape check below and the set-up of the peer path are
+    collectives).  A caller whose ranks may fail on their own before this point -- allocating `like`, say -- reaches consensus on
+    that first (an all-reduce(MIN) of "my set-up worked": `bench_support.Ranks.all_ok`) and only then calls make_gather on all
+    ranks or on none; a rank that skips it while the others wait inside would hang the job."""
     prefer = prefer or os.environ.get("SEQIK_GATHER", "auto")
     # both pipelines move EQUAL blocks (one receive buffer shape / one slot size for every peer): a rank with another block
     # shape would make the point-to-point sizes disagree -- a hang on RCCL -- so that is refused here, on every rank alike

@@ -260,3 +260,52 @@ def test_chain_queue_on_gpu_equals_the_static_launch(hiplib, oracle):
     a = hiplib.solve_generic(pose[:500], params, init_angles=init, chain_queue=1)
     b = hiplib.solve_generic(pose[:500], params, init_angles=init, chain_queue=2)
     assert np.array_equal(a["angles"], b["angles"]) and np.array_equal(a["fk"], b["fk"])
+
+
+@pytest.mark.gpu
+def test_chain_queue_from_two_host_threads_on_one_stream(hiplib):
+    """Round-5 advice: the chain queue's per-leg counters live in the stream's workspace; two host threads that launch on the
+    SAME stream (both passing the null stream to seqik_solve_generic_device) must each get their results -- zeroing the counters
+    and launching the kernel that consumes them reach the stream as one unit.  Without that the enqueue order memset A, memset
+    B, kernel A, kernel B leaves kernel B's outputs unwritten while the call returns SEQIK_OK."""
+    import ctypes
+    import threading
+    import torch
+    z = load_golden("generic_rf_100")
+    legs = ["RF", "LF"]
+    params = [hiplib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
+    arr = (hiplib.SeqikLegParams * 2)(*params)
+    rec = np.stack([z[f"{l}_pose"] for l in legs])
+    S, T = 256, 4
+    offs = (np.arange(S) * 5) % (100 - T)
+    pose = np.ascontiguousarray(rec[:, offs[:, None] + np.arange(T)[None, :]].transpose(1, 0, 2, 3, 4))
+    want = hiplib.solve_generic(pose, params, chain_queue=1)["angles"]
+    d_pose = torch.from_numpy(pose).cuda()
+    lib = hiplib.load()
+    n_threads, rounds = 2, 60
+    outs = [[torch.full((S, 2, T, 7), float("nan"), dtype=torch.float64, device="cuda") for _ in range(rounds)] for _ in range(n_threads)]
+    torch.cuda.synchronize()
+    start = threading.Barrier(n_threads)
+    errors = []
+
+    def worker(t):
+        torch.cuda.set_device(0)
+        opt = hiplib.SeqikOptions()
+        opt.reserved[1] = 2           # the chain queue, whatever the batch size
+        start.wait()
+        for r in range(rounds):
+            rc = lib.seqik_solve_generic_device(d_pose.data_ptr(), S, 2, T, arr, outs[t][r].data_ptr(), None, None, None, None, None, None,
+                                                ctypes.byref(opt), None)     # the null stream, from both threads
+            if rc != 0:
+                errors.append((t, r, rc))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    hiplib.check_faults()
+    assert not errors, errors
+    for t in range(n_threads):
+        for r in range(rounds):
+            assert np.array_equal(outs[t][r].cpu().numpy(), want), (t, r)

@@ -716,6 +716,10 @@ pose = np.stack([z[f"{l}_pose"][:40] for l in legs])[None]
 params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
 d_pose = torch.from_numpy(pose).cuda()
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+# (round-5 advice) a caller that POLLS transient streams must not use up the (device, stream) -> word table: the check paths only
+# look a stream up; with the 63 slots gone A and B would share the last word and B's check below would take A's fault
+for k in range(200):
+    _lib.check_faults(0x7000 + 8 * k)
 a_ang = torch.zeros((1, len(legs), 40, 7), dtype=torch.float64, device="cuda")
 b_ang = torch.zeros_like(a_ang)
 torch.cuda.synchronize()
