@@ -308,8 +308,9 @@ def reference_configs(time_box_s=240.0):
     zd = np.load(os.path.join(ROOT, "tests", "golden", "df3d_1000.npz"))
     zh = np.load(os.path.join(ROOT, "tests", "golden", "anipose_head.npz"))
     out = {"note": "ms = fastest of 5 whole calls on host arrays (upload, kernels, download, dict building); "
-                   "leg_frames_per_s = legs x frames / that; default = the reference's serial walk (bit-identical to the C "
-                   "restatement), frame_parallel_auto = verified frame chunks (opt-in); latency_floor_frac = issue floor of "
+                   "leg_frames_per_s = legs x frames / that; default = frame_parallel='auto', verified frame chunks (the default of "
+                   "the Python API since round 6); serial_walk = frame_parallel=False, the reference's own order (bit-identical to "
+                   "the C restatement); latency_floor_frac = issue floor of "
                    "the critical wavefront (committed PMC instruction counts x lone-wavefront issue costs) / measured kernel "
                    "time, for the kernels that are bound by the latency of one dependent chain, not by throughput"}
 
@@ -323,7 +324,7 @@ def reference_configs(time_box_s=240.0):
             ok[legs.index("LF"), LF_WINDOW[0]:min(LF_WINDOW[1], n)] = False
         entry = {"workload": workload, "legs": legs, "frames": n, "leg_frames": len(legs) * n}
         got = {}
-        for key, mode in (("default", False), ("frame_parallel_auto", "auto")):
+        for key, mode in (("serial_walk", False), ("default", "auto")):
             holder = {}
 
             def call():
@@ -342,10 +343,10 @@ def reference_configs(time_box_s=240.0):
             if mode:
                 st = holder["ik"].frame_chunk_stats
                 e["chunk_stats"] = {k: v for k, v in st.items() if v}
-                dd = np.abs(a - got["default"])
-                e["max_abs_vs_default"] = float(dd[ok].max())
+                dd = np.abs(a - got["serial_walk"])
+                e["max_abs_vs_serial_walk"] = float(dd[ok].max())
                 if mask_lf and "LF" in legs:
-                    e["max_abs_vs_default_incl_lf_window"] = float(dd.max())
+                    e["max_abs_vs_serial_walk_incl_lf_window"] = float(dd.max())
             entry[key] = e
         return entry, aligned, chain
 
@@ -365,22 +366,23 @@ def reference_configs(time_box_s=240.0):
                                body_size=utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs6))
     holder = {}
 
-    def many():
-        holder["res"] = run_ik_and_fk_many(recs, chain6, data.INITIAL_ANGLES_LOCOMOTION)
-    ms_many = best_ms(many, reps=3)
-    a_many = np.stack([np.stack([holder["res"][-1][0][f"Angle_{l}_{d}"] for d in DOFS], 1) for l in legs6])
     ref6 = np.stack([zd[f"{l}_angles"] for l in legs6])
-    out["2"]["default_64_recordings_one_call"] = {
-        "what": "run_ik_and_fk_many: 64 recordings x 6 legs x 1000 frames in one call, DEFAULT semantics (serial walk per chain, "
-                "bit-identical to the one-recording call)", "ms": ms_many, "leg_frames_per_s": 64 * 6 * 1000 / ms_many * 1e3,
-        "max_abs_dtheta_vs_fixture_last_recording": float(np.abs(a_many - ref6).max())}
+    for key, mode in (("serial_walk_64_recordings_one_call", False), ("default_64_recordings_one_call", "auto")):
+        def many():
+            holder["res"] = run_ik_and_fk_many(recs, chain6, data.INITIAL_ANGLES_LOCOMOTION, frame_parallel=mode)
+        ms_many = best_ms(many, reps=3)
+        a_many = np.stack([np.stack([holder["res"][-1][0][f"Angle_{l}_{d}"] for d in DOFS], 1) for l in legs6])
+        out["2"][key] = {
+            "what": "run_ik_and_fk_many: 64 recordings x 6 legs x 1000 frames in one call, frame_parallel=%r (every recording's result "
+                    "the bits it gets alone in that mode)" % (mode,), "ms": ms_many, "leg_frames_per_s": 64 * 6 * 1000 / ms_many * 1e3,
+            "max_abs_dtheta_vs_fixture_last_recording": float(np.abs(a_many - ref6).max())}
     # ---- config 4: legs + head / antenna angles of the shipped 6000-frame recording in ONE submission ----------------
     e4, aligned4, chain4 = leg_entry(za, ["RF", "LF"], 6000, data.BOUNDS, data.INITIAL_ANGLES, data.NMF_TEMPLATE,
                                      "config 4: anipose_220525_aJO_Fly001_001 (6000 frames; stands in for the absent "
                                      "anipose_220807_Fly002_002), legs RF + LF + the 7 head / antenna angles", True)
     body_in = dict(aligned4, R_head=zh["R_head"], L_head=zh["L_head"], Neck=zh["Neck"])
     e4["legs_and_head_one_submission"] = {}
-    for key, mode in (("default", False), ("frame_parallel_auto", "auto")):
+    for key, mode in (("serial_walk", False), ("default", "auto")):
         holder = {}
 
         def call():
@@ -504,7 +506,7 @@ def reference_configs(time_box_s=240.0):
     except Exception as exc:  # noqa: BLE001
         out["generic"]["batch"] = {"error": f"{type(exc).__name__}: {exc}"}
     # ---- latency floors of the two latency-bound kernels (item: "latency-bound" as a number) -------------------------
-    for entry, kernel_key, live_ms in ((out["4"], "config4_serial_walk", out["4"]["default"]["ms"]),
+    for entry, kernel_key, live_ms in ((out["4"], "config4_serial_walk", out["4"]["serial_walk"]["ms"]),
                                        (out["generic"], "generic_rf_6000", out["generic"]["ms"])):
         fl = latency_floor(kernel_key)
         if fl:
@@ -751,10 +753,11 @@ def detail_legs(ctx):
         return obj
     names = ("anipose_shipped", "df3d_1000")
     rec["detail_scalars"] = {
-        "config1_default_ms": dig(cf, "1", "default", "ms"), "config1_auto_ms": dig(cf, "1", "frame_parallel_auto", "ms"),
-        "config2_default_ms": dig(cf, "2", "default", "ms"), "config2_auto_ms": dig(cf, "2", "frame_parallel_auto", "ms"),
+        "config1_default_ms": dig(cf, "1", "default", "ms"), "config1_serial_ms": dig(cf, "1", "serial_walk", "ms"),
+        "config2_default_ms": dig(cf, "2", "default", "ms"), "config2_serial_ms": dig(cf, "2", "serial_walk", "ms"),
         "config2_64_recordings_per_s": dig(cf, "2", "default_64_recordings_one_call", "leg_frames_per_s"),
-        "config4_default_ms": dig(cf, "4", "default", "ms"), "config4_auto_ms": dig(cf, "4", "frame_parallel_auto", "ms"),
+        "config2_64_recordings_serial_per_s": dig(cf, "2", "serial_walk_64_recordings_one_call", "leg_frames_per_s"),
+        "config4_default_ms": dig(cf, "4", "default", "ms"), "config4_serial_ms": dig(cf, "4", "serial_walk", "ms"),
         "config5_per_s": dig(cf, "5", "one_recording", "value"), "config5_sequences_per_s": dig(cf, "5", "synthetic_sequences", "value"),
         "generic_6000_frames_s": (dig(cf, "generic", "ms") or 0.0) / 1e3 or None,
         "generic_batch_per_s": dig(cf, "generic", "batch", "leg_frames_per_s"),

@@ -26,11 +26,11 @@ from seqikpy_amd.utils import save_file  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("-p", "--path", required=True)
-    ap.add_argument("--frame-chunks", action="store_true",
-                    help="solve every recording in concurrently running, verified frame chunks (frame_parallel='auto': "
-                         "10-70x faster for one recording, equal to the serial walk to ~1e-5 rad) instead of the default, "
-                         "the reference's serial walk frame by frame (bit-exact restatement of the reference)")
-    ap.add_argument("--serial", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--frame-chunks", action="store_true", help="(default since round 6; kept for older command lines)")
+    ap.add_argument("--serial", action="store_true",
+                    help="walk every recording frame by frame as the reference does (frame_parallel=False: bit-exact restatement of "
+                         "the reference) instead of the default, concurrently solved and verified frame chunks (frame_parallel="
+                         "'auto': 10-70x faster for one recording, equal to the serial walk to ~1e-5 rad)")
     args = ap.parse_args()
     data_path = Path(args.path)
     t0 = time.time()
@@ -47,7 +47,7 @@ def main():
     seq_ik = LegInvKinSeq(aligned_pos=aligned_pos,
                           kinematic_chain_class=KinematicChainSeq(bounds_dof=BOUNDS, legs_list=["RF", "LF"], body_size=None),
                           initial_angles=INITIAL_ANGLES, log_level="INFO")
-    leg_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=data_path, frame_parallel="auto" if (args.frame_chunks and not args.serial) else False)
+    leg_angles, forward_kinematics = seq_ik.run_ik_and_fk(export_path=data_path, frame_parallel=False if args.serial else "auto")
     save_file(data_path / "body_joint_angles.pkl", {**head_angles, **leg_angles})
     print(f"Total time taken to execute the code: {time.time() - t0:.2f} s")
 

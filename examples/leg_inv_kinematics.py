@@ -28,11 +28,11 @@ def main():
     ap.add_argument("-p", "--path", default=None, help="directory holding pose3d_aligned.pkl")
     ap.add_argument("--legs", nargs="+", default=["RF", "LF"])
     ap.add_argument("--generic", action="store_true", help="also run the single-chain (generic) IK")
-    ap.add_argument("--frame-chunks", action="store_true",
-                    help="solve every recording in concurrently running, verified frame chunks (frame_parallel='auto': "
-                         "10-70x faster for one recording, equal to the serial walk to ~1e-5 rad) instead of the default, "
-                         "the reference's serial walk frame by frame (bit-exact restatement of the reference)")
-    ap.add_argument("--serial", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--frame-chunks", action="store_true", help="(default since round 6; kept for older command lines)")
+    ap.add_argument("--serial", action="store_true",
+                    help="walk every recording frame by frame as the reference does (frame_parallel=False: bit-exact restatement of "
+                         "the reference) instead of the default, concurrently solved and verified frame chunks (frame_parallel="
+                         "'auto': 10-70x faster for one recording, equal to the serial walk to ~1e-5 rad)")
     ap.add_argument("--export", action="store_true", help="write leg_joint_angles.pkl / forward_kinematics.pkl")
     args = ap.parse_args()
     if args.path:
@@ -49,7 +49,7 @@ def main():
                           kinematic_chain_class=KinematicChainSeq(bounds_dof=BOUNDS, legs_list=args.legs, body_size=None),
                           initial_angles=INITIAL_ANGLES)
     angles_seq, fk_seq = seq_ik.run_ik_and_fk(export_path=export, hide_progress_bar=True,
-                                              frame_parallel="auto" if (args.frame_chunks and not args.serial) else False)
+                                              frame_parallel=False if args.serial else "auto")
     n = len(next(iter(angles_seq.values())))
     print(f"Sequential IK of {len(fk_seq)} legs x {n} frames took {time.time() - start:.3f} s")
 

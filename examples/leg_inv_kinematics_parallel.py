@@ -27,7 +27,7 @@ from seqikpy_amd.utils import calculate_body_size, load_file  # noqa: E402
 LEGS = ["RF", "RM", "RH", "LF", "LM", "LH"]
 
 
-def solve(aligned_pos, legs, frame_parallel=False):
+def solve(aligned_pos, legs, frame_parallel="auto"):
     kin_chain = KinematicChainSeq(bounds_dof=BOUNDS_LOCOMOTION, body_size=calculate_body_size(TEMPLATE_NMF_LOCOMOTION, legs),
                                   legs_list=legs)
     seq_ik = LegInvKinSeq(aligned_pos=aligned_pos, kinematic_chain_class=kin_chain, initial_angles=INITIAL_ANGLES_LOCOMOTION,
@@ -45,7 +45,8 @@ def main(argv=None):
     ap.add_argument("-p", "--path", default=None)
     ap.add_argument("--pool", action="store_true", help="the reference's process pool, one leg per task")
     ap.add_argument("--processes", type=int, default=6, help="workers of the pool (the reference uses 6)")
-    ap.add_argument("--frame-chunks", action="store_true", help="frame_parallel='auto' (verified frame chunks)")
+    ap.add_argument("--frame-chunks", action="store_true", help="(default since round 6; kept for older command lines)")
+    ap.add_argument("--serial", action="store_true", help="frame_parallel=False: every chain walked frame by frame, as the reference does")
     args = ap.parse_args(argv)
     if args.path:
         pose_data = load_file(Path(args.path) / "pose3d_aligned.pkl")
@@ -63,7 +64,7 @@ def main(argv=None):
             all_legs_joint_angles.update(ik)
             all_legs_for_kins.update(fk)
     else:
-        all_legs_joint_angles, all_legs_for_kins = solve(pose_data, legs, "auto" if args.frame_chunks else False)
+        all_legs_joint_angles, all_legs_for_kins = solve(pose_data, legs, False if args.serial else "auto")
     n = len(next(iter(all_legs_joint_angles.values())))
     how = "process pool" if args.pool else "one launch"
     print(f"Sequential IK of {len(legs)} legs x {n} frames took {time.time() - start:.3f} s [{how}]")

@@ -27,8 +27,9 @@ def run_ik_and_fk_many(recordings: Sequence[Dict[str, np.ndarray]], kinematic_ch
                        ) -> List[Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]]:
     """``LegInvKinSeq(rec, kinematic_chain_class, initial_angles).run_ik_and_fk(frame_parallel=...)`` for every ``rec``.
 
-    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` (None = its default, the serial walk).  With ``"auto"`` the
-    chunk geometry depends on a recording's length only, so every recording gets the bits it would get alone (with
+    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` (None = its default, ``"auto"``; ``False`` = the serial walk, which is
+    also the faster choice once a call carries enough recordings to fill the GPU by itself -- some 40 000 chains: the chunks'
+    run-in frames are extra work).  With ``"auto"`` the chunk geometry depends on a recording's length only, so every recording gets the bits it would get alone (with
     ``pad_to_multiple`` it is the PADDED length that counts).  ``reports``: a list that receives one
     ``frame_chunk_report`` dict per recording.
 

@@ -23,8 +23,8 @@ def run_body_ik(aligned_pos: Dict[str, np.ndarray], kinematic_chain_class: Kinem
                 frame_parallel=None, stats: Optional[dict] = None) -> Tuple[Dict[str, np.ndarray], Dict[str, np.ndarray]]:
     """Returns ``(body_joint_angles, forward_kinematics)``: the 7 head / antenna angles (when ``R_head``, ``L_head``
     and ``Neck`` are present) + 7 angles per leg, and the ``"<leg>_leg" -> (N, 9, 3)`` joint positions.
-    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` -- ``False`` / None (default: the reference's serial walk) or
-    ``"auto"`` (verified frame chunks; the same device-side per-leg guard as every other entry point).  ``stats``: a dict
+    ``frame_parallel``: as ``LegInvKinSeq.run_ik_and_fk`` -- None / ``"auto"`` (default: verified frame chunks; the same
+    device-side per-leg guard as every other entry point) or ``False`` (the reference's serial walk).  ``stats``: a dict
     that receives the chunk statistics of the launch."""
     import torch
     from .leg_inverse_kinematics import default_frame_parallel

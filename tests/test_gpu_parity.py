@@ -378,7 +378,7 @@ def test_many_recordings_of_different_length_in_one_call(lib):
     recs = [{f"{l}_leg": z[f"{l}_pose"][a:b] for l in legs} | {"Neck": np.zeros((1, 1, 3))} for a, b in cuts]
     single = [LegInvKinSeq(r, kc, data.INITIAL_ANGLES_LOCOMOTION, log_level="ERROR").run_ik_and_fk(frame_parallel=False) for r in recs]
     for pad in (0, 64):
-        many = run_ik_and_fk_many(recs, kc, data.INITIAL_ANGLES_LOCOMOTION, pad_to_multiple=pad)
+        many = run_ik_and_fk_many(recs, kc, data.INITIAL_ANGLES_LOCOMOTION, pad_to_multiple=pad, frame_parallel=False)
         assert len(many) == len(recs)
         for (ang, fk), (ang1, fk1) in zip(many, single):
             assert list(ang.keys()) == list(ang1.keys()) and list(fk.keys()) == list(fk1.keys())

@@ -123,7 +123,7 @@ def test_many_recordings_bucketing_and_padding(monkeypatch):
     calls = []
 
     def fake_solve(pose, legs, want_fk=True, device=0, affine=None, frame_chunk=0, **_):
-        assert frame_chunk == 0   # the default of run_ik_and_fk_many is the reference's serial walk
+        assert frame_chunk == -1   # the default of run_ik_and_fk_many is run_ik_and_fk's: automatic frame chunks
         calls.append(pose.shape)
         S, L, N = pose.shape[:3]
         ang = np.broadcast_to(pose[..., 1, 0][..., None], (S, L, N, 7)).copy()   # echoes a key-point coordinate
@@ -185,16 +185,17 @@ def test_package_import_leaves_the_environment_alone():
 
 
 def test_frame_parallel_default_and_chunk_report(monkeypatch):
-    """The default of run_ik_and_fk is the reference's serial walk unless SEQIK_FRAME_PARALLEL says otherwise; the
+    """The default of run_ik_and_fk is "auto" (verified frame chunks; round 6) unless SEQIK_FRAME_PARALLEL says serial; the
     per-leg report is built from the library's chunk statistics and per-chunk flags."""
     from seqikpy_amd import _lib
     from seqikpy_amd.leg_inverse_kinematics import chunk_report, default_frame_parallel
     monkeypatch.delenv("SEQIK_FRAME_PARALLEL", raising=False)
-    assert default_frame_parallel() is False
+    assert default_frame_parallel() == "auto"
     monkeypatch.setenv("SEQIK_FRAME_PARALLEL", "auto")
     assert default_frame_parallel() == "auto"
-    monkeypatch.setenv("SEQIK_FRAME_PARALLEL", "0")
-    assert default_frame_parallel() is False
+    for v in ("0", "serial", "off", "False"):
+        monkeypatch.setenv("SEQIK_FRAME_PARALLEL", v)
+        assert default_frame_parallel() is False
     flags = np.zeros((2, 2, 5), np.uint8)
     flags[0, 0, 2] = _lib.CHUNK_FLAG_FAILED_FIRST | _lib.CHUNK_FLAG_REPAIRED
     flags[0, 0, 4] = _lib.CHUNK_FLAG_SWEPT

@@ -4,7 +4,7 @@ planar layout from pinned memory, and "in time" (carry) against the unsplit reco
 import numpy as np
 import pytest
 
-from conftest import leg_arrays, load_golden
+from conftest import DOFS, leg_arrays, load_golden
 
 from seqikpy_amd import data
 from seqikpy_amd.alignment import AlignPose
@@ -220,3 +220,78 @@ def test_stream_slots_follow_a_padded_layout_and_bad_layouts_are_rejected(lib):
                 lib.SeqikLayout(15 * T, 0, 3, 7 * T, T, 1)):             # zero stride
         with pytest.raises(ValueError):
             SeqikStream(params, S, T, layout=bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_config5_at_its_full_size_ten_million_frames_streamed(lib, oracle):
+    """BASELINE config 5 at its LITERAL size (round-5 review, item 5): 10 M frames x 6 legs -- 20 slabs of 7 813 sequences of 64
+    frames = 10 000 640 frames, 60 M leg-frames -- streamed from pinned host memory over 3 slots, RAW key points, the alignment
+    (reference: seqikpy/alignment.py:436-487) fused into the kernel prologue, warm start from the previous frame
+    (leg_inverse_kinematics.py:272), 7 angles + 9 x 3 FK back in pinned memory.  One distinct slab is generated and re-submitted
+    (what `scripts/stream_config5.py --unique 1` and bench.py --detail time; the kernels cannot tell), so size-independent
+    properties take the place of an oracle run over 60 M leg-frames:
+      * EVERY one of the 20 slabs comes back, bit for bit the same result (the output slots are poisoned with NaN before each use);
+      * finite everywhere, every angle within its limits, FK == forward kinematics of the returned angles (independent numpy FK);
+      * sampled chains == the C oracle on the host-aligned key points, bit for bit (angles and FK);
+      * streamed == one direct blocking call on a sampled piece of the slab, bit for bit."""
+    import time
+    from seqikpy_amd import synthetic, utils
+    from seqikpy_amd.streaming import PinnedArray, SeqikStream
+    legs = data.LEGS
+    L, T, S, n_slabs, n_slots = len(legs), 64, 7813, 20, 3
+    assert n_slabs * S * T >= 10_000_000
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    params = [lib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
+    rng = np.random.default_rng(5)
+    scales, fixed = 1.0 + 0.4 * rng.random(L), rng.normal(0.0, 2.0, (L, 3))          # a made-up camera frame per leg
+    tcs = [np.asarray(data.TEMPLATE_NMF_LOCOMOTION[f"{l}_Coxa"], dtype=np.float64) for l in legs]
+    affs = [lib.make_affine(fixed[i], scales[i], tcs[i]) for i in range(L)]
+    al = synthetic.synthetic_pose(S, T, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION, variant="iid",
+                                  seed=synthetic.SEED_BASE + 5)
+    raw = np.empty_like(al)
+    for i in range(L):
+        raw[:, i] = (al[:, i] - tcs[i]) / scales[i] + fixed[i]
+    slab = PinnedArray((S, L, 5, T, 3))
+    slab.array[...] = raw.transpose(0, 1, 3, 2, 4)
+    outs = [(PinnedArray((S, L, 7, T)), PinnedArray((S, L, T, 9, 3))) for _ in range(n_slots)]
+    first, seconds = None, 0.0
+    with SeqikStream(params, S, T, affine=affs, layout=lib.planar_layout(T), want_fk=True, n_slots=n_slots) as st:
+        done = 0
+        while done < n_slabs:
+            group = min(n_slots, n_slabs - done)
+            for k in range(group):
+                outs[k][0].array.fill(np.nan)
+                outs[k][1].array.fill(np.nan)
+            t0 = time.perf_counter()
+            for k in range(group):
+                st.submit(slab.array, outs[k][0].array, outs[k][1].array)
+            st.wait()
+            seconds += time.perf_counter() - t0
+            if first is None:
+                first = (outs[0][0].array.copy(), outs[0][1].array.copy())
+            for k in range(group):
+                assert np.array_equal(outs[k][0].array, first[0]) and np.array_equal(outs[k][1].array, first[1]), done + k
+            done += group
+    lib.check_faults()
+    ang, fk = first[0].transpose(0, 1, 3, 2), first[1]                                  # (S, L, T, 7), (S, L, T, 9, 3)
+    assert np.isfinite(ang).all() and np.isfinite(fk).all()
+    for li, leg in enumerate(legs):
+        lb = np.array([data.BOUNDS_LOCOMOTION[f"{leg}_{d}"][0] for d in DOFS])
+        ub = np.array([data.BOUNDS_LOCOMOTION[f"{leg}_{d}"][1] for d in DOFS])
+        assert (ang[:, li] >= lb).all() and (ang[:, li] <= ub).all()
+        seg = [body[f"{leg}_{s}"] for s in data.SEGMENTS]
+        kp = synthetic.leg_forward_kinematics(ang[:, li], seg) + tcs[li]      # fused alignment: the origin is the template's coxa
+        assert np.abs(kp - fk[:, li][:, :, [0, 4, 6, 7, 8]]).max() < 1e-12
+    # the oracle gets what AlignPose.align_leg makes of the RAW key points (numpy, three separately rounded operations)
+    pick = np.random.default_rng(11)
+    for s, li in zip(pick.integers(0, S, 18), pick.integers(0, L, 18)):
+        aligned = (raw[s, li] - fixed[li]) * scales[li] + tcs[li]
+        seg, b, seeds = oracle.leg_params(legs[li], data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+        ref = oracle.seq_leg(aligned, seg, b, seeds)
+        assert np.array_equal(ang[s, li], ref["angles"]) and np.array_equal(fk[s, li], ref["fk"]), (s, li)
+    direct = lib.solve_seq(raw[1000:1512], params, want_fk=True, affine=affs)
+    assert np.array_equal(ang[1000:1512], direct["angles"]) and np.array_equal(fk[1000:1512], direct["fk"])
+    units = n_slabs * S * L * T
+    print(f"config 5 at full size: {units} leg-frames in {seconds:.2f} s (groups of {n_slots} slabs, PCIe-inclusive) = {units / seconds:.3g} /s")
+    assert units / seconds > 1e6        # the north star's target rate, PCIe and fused alignment included
