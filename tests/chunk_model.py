@@ -119,3 +119,54 @@ def chunked_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, roun
     m.speculate()
     m.settle()
     return dict(angles=m.angles, fk=m.fk, stats=m.stats, flags=m.flags)
+
+
+def sharded_chunked_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, world, tol=1e-6):
+    """One chain of ONE recording sharded by frame over `world` ranks, in one process: the loop of
+    seqikpy_amd.frame_sharding.FrameShardedRecording.solve (contiguous slabs of whole chunks on the global chunk grid, every slab
+    speculates with `lead` = min(halo, first frame) run-in frames, end states exchanged, ranks > 0 settle their first chunk in
+    resume calls until no end state changes) with a ChunkedChain per slab.  -> dict(angles (N, 7), fk, rounds, resumes, slabs,
+    repaired_after_exchange).  tests/test_distributed_gloo.py checks it against the real loop over a gloo process group."""
+    N = pose.shape[0]
+    n_chunks = -(-N // chunk)
+
+    def part(r):
+        base, rem = divmod(n_chunks, world)
+        a = r * base + min(r, rem)
+        return a, a + base + (1 if r < rem else 0)
+    slabs = [(min(part(r)[0] * chunk, N), min(part(r)[1] * chunk, N)) for r in range(world)]
+    models = {}
+    for r, (a, b) in enumerate(slabs):
+        if b <= a:
+            continue
+        lead = min(halo, a) if r > 0 else 0
+        if lead == 0 and chunk >= b - a and r == 0 and world == 1:
+            raise ValueError("a recording of one chunk is walked serially")
+        m = ChunkedChain(oracle, pose[a - lead:b], seg, bounds, seeds, chunk, halo, tol=tol, lead=lead)
+        m.speculate()
+        m.settle()
+        models[r] = (m, lead)
+    owners = sorted(models)
+    left_of = {r: max([q for q in owners if q < r], default=None) for r in owners}
+    left_prev, rounds, resumes, repaired = {}, 0, 0, 0
+    while world > 1:
+        ends = {r: models[r][0].angles[-1].copy() for r in owners}
+        changed = 0
+        for r in owners:
+            if left_of[r] is None:
+                continue
+            left = ends[left_of[r]]
+            if r not in left_prev or not np.array_equal(left, left_prev[r]):
+                m = models[r][0]
+                before = m.angles[-1].copy()
+                m.settle(init=left.copy(), resume=True)
+                repaired += int(m.stats[3:7].sum())
+                resumes += 1
+                left_prev[r] = left.copy()
+                changed += int(not np.array_equal(before, m.angles[-1]))
+        if changed == 0:
+            break
+        rounds += 1
+    return dict(angles=np.concatenate([models[r][0].angles[models[r][1]:] for r in owners]),
+                fk=np.concatenate([models[r][0].fk[models[r][1]:] for r in owners]), rounds=rounds, resumes=resumes, slabs=slabs,
+                repaired_after_exchange=repaired)

@@ -125,9 +125,9 @@ class OracleSlab:
         self.S, self.L, self.n = pose_slab.shape[:3]
         self.lead, self.repaired = lead, 0
         self.serial = lead == 0 and chunk >= self.n      # (what pick_frame_chunks does with a one-chunk call)
-        self.chains = [[ChunkedChain(c_oracle, pose_slab[s, li], z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"],
-                                     chunk, halo, tol=max(tol, 0.0), lead=lead) for li, leg in enumerate(legs)]
-                       for s in range(self.S)]
+        par = [leg if isinstance(leg, tuple) else (z[f"{leg}_seg"], z[f"{leg}_bounds"], z[f"{leg}_seeds"]) for leg in legs]
+        self.chains = [[ChunkedChain(c_oracle, pose_slab[s, li], *par[li], chunk, halo, tol=max(tol, 0.0), lead=lead)
+                        for li in range(len(legs))] for s in range(self.S)]
         self.oracle = c_oracle
 
     def speculate(self):
@@ -210,6 +210,83 @@ def test_one_recording_sharded_by_frame_over_ranks(tmp_path, oracle, world):
         assert int(got["spec_resumes"]) == (1 if r > 0 else 0)
         slabs.append(tuple(got["spec_slab"]))
     assert slabs[0][0] == 0 and slabs[-1][1] == 610 and all(slabs[i][1] == slabs[i + 1][0] for i in range(world - 1))
+
+
+# placements of the anipose LF recording (start frame, chunk, halo) for which a rank boundary falls next to / into the
+# kinematic-singularity episode of frames 284-301 (tests/conftest.py::LF_DEGENERATE) and chunks of it are repaired after the exchange
+LF_EDGE_CASES = [(108, 16, 4), (156, 16, 4), (124, 4, 4), (176, 4, 4), (132, 8, 8), (164, 8, 2)]
+
+
+def _lf_edge_worker(rank, world, port, out_dir):
+    for p in (PKG_PARENT, ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from seqikpy_amd import frame_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    za = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
+    par = (za["LF_seg"], za["LF_bounds"], za["LF_seeds"])
+    res = {}
+    for start, chunk, halo in LF_EDGE_CASES:
+        st = {}
+        pose = za["LF_pose"][start:start + 320][None, None]
+        out = frame_sharding.solve_frame_sharded(pose, [par], chunk=chunk, halo=halo, tol=1e-6, stats=st, slab_factory=OracleSlab)
+        res[f"a_{start}_{chunk}_{halo}"] = out["angles"][0, 0]
+        res[f"r_{start}_{chunk}_{halo}"] = np.array([st["boundary_rounds"], st["resume_calls"], st["chunks_repaired_after_exchange"]])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_frame_sharding_across_a_singular_episode_is_bounded_not_bit_identical(tmp_path, oracle):
+    """Round-5 review, item 6: is the frame-sharded result independent of the number of ranks?  On well-posed data yes, bit for
+    bit (tests above and the GPU tier).  Next to the anipose LF kinematic-singularity episode (frames 284-301), where chunks fail
+    their verification and are repaired, NOT always: the one-rank call verifies the chunk behind a rank boundary in its first
+    round, together with every other chunk, the sharded run after the end states are exchanged -- a chunk can then be repaired
+    from a predecessor state that differs in the last bits, and inside the episode the solve amplifies that (two equivalent leg
+    configurations pi apart: the reference does not reproduce itself there either, profiles/r02_perturbation_report.json).  What
+    holds, and is asserted here over rank boundaries placed across the episode at world 2, 3 and 8 and four chunk geometries:
+      * OUTSIDE the episode the sharded result is within 1e-7 rad of the one-rank call -- a tenth of the verification tolerance
+        `chunk_tol` = 1e-6 every chunk start is allowed anyway -- and as close to the serial walk as the one-rank call is;
+      * differences above that are confined to the episode's frames;
+      * most placements ARE bit-identical, and each non-identical one repaired chunks after the exchange (that is the cause);
+      * the real loop (FrameShardedRecording over a gloo process group, 2 and 3 ranks) == the one-process re-enactment used for
+        the sweep, bit for bit."""
+    from chunk_model import chunked_oracle, sharded_chunked_oracle
+    from conftest import LF_DEGENERATE
+    za = np.load(os.path.join(ROOT, "tests", "golden", "anipose_shipped.npz"))
+    par = (za["LF_seg"], za["LF_bounds"], za["LF_seeds"])
+    for world in (2, 3):
+        out_dir = tmp_path / f"w{world}"
+        out_dir.mkdir()
+        mp.spawn(_lf_edge_worker, args=(world, free_port(), str(out_dir)), nprocs=world, join=True)
+        for start, chunk, halo in LF_EDGE_CASES:
+            model = sharded_chunked_oracle(oracle, za["LF_pose"][start:start + 320], *par, chunk, halo, world)
+            for r in range(world):
+                got = np.load(out_dir / f"rank{r}.npz")
+                assert np.array_equal(got[f"a_{start}_{chunk}_{halo}"], model["angles"]), (world, start, chunk, halo, r)
+    identical, different = 0, []
+    for world in (2, 3, 8):
+        n = 320 if world < 8 else 640
+        for start, chunk, halo in LF_EDGE_CASES + [(s, c, h) for c, h in ((16, 4), (4, 4)) for s in range(100, 300, 24)]:
+            pose = za["LF_pose"][start:start + n]
+            one = chunked_oracle(oracle, pose, *par, chunk, halo)
+            sh = sharded_chunked_oracle(oracle, pose, *par, chunk, halo, world)
+            serial = oracle.seq_leg(pose, *par)["angles"]
+            d = np.abs(sh["angles"] - one["angles"]).max(1)
+            outside = np.ones(n, bool)
+            outside[max(LF_DEGENERATE[0] - start, 0):max(LF_DEGENERATE[1] - start, 0)] = False
+            assert d[outside].max() <= 1e-7, (world, start, chunk, halo, float(d[outside].max()))
+            assert abs(np.abs(sh["angles"] - serial)[outside].max() - np.abs(one["angles"] - serial)[outside].max()) <= 1e-7
+            if d.max() == 0:
+                identical += 1
+            else:
+                different.append((world, start, chunk, halo, float(d.max())))
+                assert sh["repaired_after_exchange"] > 0, (world, start, chunk, halo)
+    assert identical > 3 * len(different) > 0, (identical, different)
 
 
 @pytest.mark.timeout(600)
@@ -547,6 +624,11 @@ def _frame_shard_gpu_worker(rank, world, port, out_dir):
     pose_a = np.stack([za[f"{l}_pose"][200:520] for l in ("LF", "RF")])[None]
     out_a = frame_sharding.solve_frame_sharded(pose_a, pa, chunk=8, halo=2, stats=st)
     res.update(a_angles=out_a["angles"], a_fk=out_a["fk"])
+    # rank boundaries next to / inside the LF singularity episode, chunks of it repaired after the exchange (LF_EDGE_CASES): the
+    # sharded result is then NOT always the one-rank call's -- but it is the model's (tests/chunk_model.py), bit for bit
+    for start, chunk, halo in LF_EDGE_CASES[:4]:
+        out_e = frame_sharding.solve_frame_sharded(za["LF_pose"][start:start + 320][None, None], pa[:1], chunk=chunk, halo=halo)
+        res[f"edge_{start}_{chunk}_{halo}"] = out_e["angles"][0, 0]
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **res)
     dist.barrier()
     dist.destroy_process_group()
@@ -555,10 +637,12 @@ def _frame_shard_gpu_worker(rank, world, port, out_dir):
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("world", [2, 3])
-def test_one_recording_sharded_by_frame_on_the_gpu_equals_one_rank(tmp_path, hiplib, world):
+def test_one_recording_sharded_by_frame_on_the_gpu_equals_one_rank(tmp_path, hiplib, oracle, world):
     """Round-2 review item 4: ONE recording (df3d x 50 = 50 000 frames x 6 legs), frame-sharded over 2 / 3 ranks that
     hand their slabs to the library's frame chunks (frame_lead, chunk_states, chunk_resume), == the one-rank chunked
-    call with the same geometry, bit for bit -- angles and FK, on every rank."""
+    call with the same geometry, bit for bit -- angles and FK, on every rank.  Round-5 review, item 6: with a rank boundary
+    across the LF singularity episode the HIP path == the model of the sharded run bit for bit, and within 1e-7 rad of the
+    one-rank call outside the episode (test_frame_sharding_across_a_singular_episode_is_bounded_not_bit_identical)."""
     port = free_port()
     mp.spawn(_frame_shard_gpu_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     z = load_golden("df3d_1000")
@@ -578,6 +662,19 @@ def test_one_recording_sharded_by_frame_on_the_gpu_equals_one_rank(tmp_path, hip
         assert np.array_equal(got["angles"], one["angles"]) and np.array_equal(got["fk"], one["fk"]), r
         assert int(got["resumes"]) == (1 if r > 0 else 0) and int(got["rounds"]) == 0
         assert np.array_equal(got["a_angles"], one_a["angles"]) and np.array_equal(got["a_fk"], one_a["fk"]), r
+    from chunk_model import sharded_chunked_oracle
+    from conftest import LF_DEGENERATE
+    par = (za["LF_seg"], za["LF_bounds"], za["LF_seeds"])
+    for start, chunk, halo in LF_EDGE_CASES[:4]:
+        pose_e = za["LF_pose"][start:start + 320]
+        model = sharded_chunked_oracle(oracle, pose_e, *par, chunk, halo, world)
+        one_e = hiplib.solve_seq(pose_e[None, None], pa[:1], frame_chunk=chunk, frame_halo=halo, want_fk=False)["angles"][0, 0]
+        outside = np.ones(320, bool)
+        outside[LF_DEGENERATE[0] - start:LF_DEGENERATE[1] - start] = False
+        for r in range(world):
+            got = np.load(tmp_path / f"rank{r}.npz")[f"edge_{start}_{chunk}_{halo}"]
+            assert np.array_equal(got, model["angles"]), (start, chunk, halo, r)
+            assert np.abs(got - one_e)[outside].max() <= 1e-7
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ import head_oracle  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("frame_parallel", [False, True])  # True: --frame-chunks
+@pytest.mark.parametrize("frame_parallel", [False, True])  # False: --serial; True: the default (verified frame chunks)
 def test_entire_pipeline(tmp_path, oracle, hiplib, monkeypatch, frame_parallel):
     z = load_golden("anipose_raw_cut")
     raw = {str(k): z[f"raw_{k}"] for k in z["segments"]}
@@ -26,7 +26,7 @@ def test_entire_pipeline(tmp_path, oracle, hiplib, monkeypatch, frame_parallel):
     spec = importlib.util.spec_from_file_location("entire_pipeline", os.path.join(ROOT, "examples", "entire_pipeline.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    argv = ["entire_pipeline.py", "-p", str(tmp_path)] + (["--frame-chunks"] if frame_parallel else [])
+    argv = ["entire_pipeline.py", "-p", str(tmp_path)] + ([] if frame_parallel else ["--serial"])
     monkeypatch.setattr(sys, "argv", argv)
     mod.main()
     for name in ("pose3d_aligned.pkl", "head_joint_angles.pkl", "leg_joint_angles.pkl", "forward_kinematics.pkl",
