@@ -148,7 +148,7 @@ def compact_line(rec):
     bytes.  Everything else of `rec` stays in bench_detail.json."""
     roof, cfg, cpu, multi = rec.get("roofline") or {}, rec.get("config") or {}, rec.get("cpu_baseline") or {}, rec.get("multi_gpu")
     line = {k: rec.get(k) for k in HEAD_KEYS}
-    line["config"] = {k: cfg[k] for k in ("workload", "variant", "streams", "stage_pipeline", "provisional", "gather", "env",
+    line["config"] = {k: cfg[k] for k in ("workload", "variant", "streams", "stage_pipeline", "chain_queue", "provisional", "gather", "env",
                                              "frames_per_rank", "boundary_rounds") if k in cfg}
     valu = roof.get("valu_issue") or {}
     line["roofline"] = {k: roof.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")}
@@ -194,9 +194,10 @@ def build_roofline(args, batch, ev, ms_per_step, device_index):
         dom = int(np.argmax(stage_ms)) + 1
         kname, key, bytes_unit, dom_ms = f"seqik_stage_kernel<{dom}, ...>", f"stage{dom}", BYTES_STAGE[dom], float(stage_ms[dom - 1])
     else:  # one kernel per step: event [0] is recorded in front of it, [1] behind it
-        kname, key, bytes_unit, dom_ms = "seqik_fused_kernel<true>", "fused", BYTES_PATH, float(stage_ms[0])
+        queued = batch.pool > 0
+        kname, key, bytes_unit, dom_ms = ("seqik_fused_queue_kernel<true>" if queued else "seqik_fused_kernel<true>"), "fused", BYTES_PATH, float(stage_ms[0])
     ach_gbs = bytes_unit * batch.units / (dom_ms * 1e-3) / 1e9
-    traffic, valu, fp64, matches, pmc_file = bs.pmc_roofline(args.variant, args.staged, key, batch.units, ms_per_step, device_index)
+    traffic, valu, fp64, matches, pmc_file = bs.pmc_roofline(args.variant, args.staged, key, batch.units, ms_per_step, device_index, batch.pool)
     hbm = {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS, "bytes_per_unit": bytes_unit,
            "note": f"algorithmic bytes x units per launch / the kernel's average launch duration (launches of {len(batch.streams)} steps "
                    f"overlap, so a launch lasts ~{len(batch.streams)}x a step); HBM is not what binds: ~1e4 f64 instructions per 392 B"}
@@ -297,6 +298,7 @@ def main():
                 "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
                 "config": {"workload": workload, "variant": args.variant, "streams": len(bt.streams), "stage_pipeline": bt.pipeline,
+                           "chain_queue": bt.pool,
                            "frames_total": S_total * T * (world if args.scaling == "weak" else 1), "leg_frames_per_step_all_ranks": int(units_all),
                            "frames_per_gpu": S * T, "legs": L, "sequences_per_gpu": S, "frames_per_sequence": T, "chains_per_gpu": S * L,
                            "warm_start": "previous frame", "outputs": "7 angles + 9x3 FK per leg-frame", "device_layout": "planar",
@@ -330,10 +332,12 @@ def main():
         # fastest on the SLOWEST rank.  The whole problem fills the GPU at depth 3 (the only candidate then); a 1/8 share needs 20.
         depth_calibration = {"candidates": [], "rule": "fastest ms per step on the slowest rank over the same region as the headline"}
         best = None
-        for n_st, pipe, lat in bs.depth_candidates(args.steps, S * L):
+        plain = args.lanes_per_wave == 0 and not args.staged and not args.interleave_legs
+        for n_st, pipe, lat, pool in [c + (0,) for c in bs.depth_candidates(args.steps, S * L)] + \
+                [(d, 1, None, p) for d, p in (bs.queue_candidates(S * L) if plain else [])]:
             bt, ms = None, float("inf")
             try:
-                bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch)
+                bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch, pool=pool)
                 bt.lat_range = lat
                 bufs = buffers_for(bt)
                 local_ok = True
@@ -347,13 +351,13 @@ def main():
                     g.close()
                 ms = tm / args.steps * 1e3
                 if best is None or ms < best[0]:
-                    best = (ms, n_st, pipe, bt, lat)
-            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat,
+                    best = (ms, n_st, pipe, bt, lat, pool)
+            depth_calibration["candidates"].append({"streams": n_st, "stage_pipeline": pipe, "latency_kernel_steps": lat, "chain_queue": pool,
                                                     "ms_per_step": None if ms == float("inf") else ms})
             del bufs
         if best is None:
             raise SystemExit("bench: no pipeline depth could be run")
-        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2], "latency_kernel_steps": best[4]}
+        depth_calibration["chosen"] = {"streams": best[1], "stage_pipeline": best[2], "latency_kernel_steps": best[4], "chain_queue": best[5]}
         batch = best[3]
         del batch.d_fks[len(batch.streams):]
         torch.cuda.empty_cache()
@@ -371,7 +375,8 @@ def main():
     chk_ang, chk_fk = torch.zeros_like(d_ang[0]), torch.zeros_like(batch.d_fks[0])
     _lib.solve_seq_device(batch.d_pose.data_ptr(), S, L, T, params, chk_ang.data_ptr(), chk_fk.data_ptr(),
                           stream=batch.main.cuda_stream, block_size=args.block, layout=batch.layout,
-                          lanes_per_wave=args.lanes_per_wave, staged=int(args.staged), interleave_legs=args.interleave_legs)
+                          lanes_per_wave=min(args.lanes_per_wave, 64),    # (a chain-queue run is checked against the PLAIN launch)
+                          staged=int(args.staged), interleave_legs=args.interleave_legs)
     torch.cuda.synchronize()
     n_used = max(args.steps, args.warmup)  # warm-up and timed steps both count from 0
     same = all(torch.equal(d_ang[b], chk_ang) for b in range(min(len(d_ang), n_used))) and \
@@ -448,10 +453,10 @@ def main():
             rec["value_single_job"] = rec["single_job"]["value"]
             other = "smooth" if args.variant == "iid" else "iid"
             _, _, pose_o, _ = bs.make_workload(S, T, other, synthetic.SEED_BASE)
-            bo = Batch(pose_o, params, args, len(batch.streams), pipeline=batch.pipeline)
+            bo = Batch(pose_o, params, args, len(batch.streams), pipeline=batch.pipeline, pool=batch.pool)
             dto = bs.timed_steps(bo, d_ang, args.steps, len(bo.streams), warmup=args.warmup)
             ms_o = dto / args.steps * 1e3
-            _, valu_o, fp64_o, match_o, file_o = bs.pmc_roofline(other, args.staged, "fused", bo.units, ms_o, device_index)
+            _, valu_o, fp64_o, match_o, file_o = bs.pmc_roofline(other, args.staged, "fused", bo.units, ms_o, device_index, pool=batch.pool)
             rec["variants"] = {other: {"value": bo.units * args.steps / dto, "unit": "leg-frame solves/s", "ms_per_step": ms_o, "steps": args.steps,
                                        "roofline": {"pmc_file": file_o, "pmc_matches_build": match_o,
                                                     **({"bound": "valu-fp64", "frac": fp64_o["flops_per_step"] / (ms_o * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,

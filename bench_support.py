@@ -119,7 +119,7 @@ def stream_pool(n):
 class Batch:
     """One rank's batch resident in HBM (planar layout) + the launch of one step on a given stream."""
 
-    def __init__(self, pose, params, args, n_streams, pipeline=None, like=None, s_pad=None):
+    def __init__(self, pose, params, args, n_streams, pipeline=None, like=None, s_pad=None, pool=0):
         """`like`: another Batch of the SAME key points (its device copy and streams are shared, only FK buffers are added).
         `s_pad`: sequences the ANGLE buffers are allocated for (>= this rank's own): the shares of the fixed problem differ by
         one sequence between ranks (15 625 = 8 x 1 953 + 1), and the gather moves equal blocks from every rank."""
@@ -129,6 +129,8 @@ class Batch:
         self.streams = stream_pool(n_streams)
         self.main = self.streams[0]
         self.lat_range = None     # [lo, hi) steps of a timed region launched with the library's own kernel choice (depth_candidates)
+        # chain queue (SeqikOptions.reserved[0] = 128, 256, ...: chains a wavefront owns); 0 = --lanes-per-wave as given
+        self.pool = int(pool) or (a_pool if (a_pool := getattr(args, "lanes_per_wave", 0)) > 64 else 0)
         if like is not None:
             self.S, self.L, self.T, self.layout, self.d_pose = like.S, like.L, like.T, like.layout, like.d_pose
             self.d_fks = list(like.d_fks[:n_streams])
@@ -155,8 +157,8 @@ class Batch:
         pipe = 0 if tail else self.pipeline
         _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.T, self.params, buf.data_ptr(),
                               self.d_fks[k].data_ptr(), stream=stream.cuda_stream, block_size=a.block, layout=self.layout,
-                              lanes_per_wave=a.lanes_per_wave, staged=int(a.staged), interleave_legs=a.interleave_legs,
-                              pipeline=pipe,
+                              lanes_per_wave=(self.pool if (self.pool and not tail) else a.lanes_per_wave), staged=int(a.staged),
+                              interleave_legs=a.interleave_legs, pipeline=pipe,
                               stage_events=[e.cuda_event for e in events] if events else None)
         return stream
 
@@ -173,6 +175,18 @@ def depth_candidates(steps, chains=None):
     which a process should not hold more than it needs (see the strong_projection leg)."""
     cap = depth_cap(chains)
     return [c for c in _depth_candidates(steps) if c[0] <= cap]
+
+
+def queue_candidates(chains):
+    """(steps in flight, chains per wavefront) of the fused kernel's CHAIN QUEUE the run calibrates beside depth_candidates(): a
+    wavefront that owns 128 / 256 chains instead of 64 halves / quarters the wavefronts of a launch, so twice / four times the
+    steps are kept in flight.  Only for batches that fill the GPU at depth 3 (a share of an N-GPU run is short of wavefronts
+    as it is).  Measured (profiles/r06_queue_pool_sweep.json): smooth poses -5 / -6 % per step over 100 steps, iid -2 %; over the
+    driver's 20 steps the deeper pipeline's fill and drain cost more than the queue saves -- which is why this is calibrated
+    over the very region that is measured and not switched on."""
+    if not chains or chains < 80000:
+        return []
+    return [c for c in ((4, 128), (6, 128), (12, 256)) if c[0] <= MAX_DEPTH]
 
 
 def depth_cap(chains):
@@ -259,12 +273,12 @@ def measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step):
                       "profiles/r03_fused_isa.json for the split of the instructions the PMC classes do not cover"}
 
 
-def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index):
+def pmc_roofline(variant, staged, key, units_per_step, ms_per_step, device_index, pool=0):
     """The VALU-side roofline figures from the newest committed PMC summary (profiles/traffic_rNN*.json, written by
     scripts/summarize_profile.py) that matches this workload -- used only if it was measured on THIS build: the summary
     carries the sha256 of the solver kernels' sources, which must equal the sources the loaded library was built from.
     -> (traffic, valu, fp64, matches_build, file)"""
-    suffix = ("_staged" if staged else "") + ("" if variant == "iid" else "_" + variant)
+    suffix = ("_staged" if staged else "") + (f"_queue{pool}" if pool else "") + ("" if variant == "iid" else "_" + variant)
     for rnd in TRAFFIC_ROUNDS:
         tpath = os.path.join(ROOT, "profiles", f"traffic_{rnd}{suffix}.json")
         if not os.path.exists(tpath):

@@ -78,7 +78,14 @@ typedef struct SeqikOptions {
                              stage-1..4 kernels ([0]..[3], only for stages that run) and behind the last one
                              ([4]) -- lets a caller time the individual kernels of one call (see reserved[1]) */
     int32_t reserved[4];  /* [0]: chains per wavefront, 1..64 (0 = automatic: one to four while there are fewer than
-                             1024 chains, 64 from there on);
+                             1024 chains, 64 from there on); 128, 192, ... 4096 (multiples of 64; since round 6) = CHAIN
+                             QUEUE of the single-launch lane-per-chain kernel: a wavefront OWNS that many chains of one
+                             leg, its 64 lanes start on the first 64 and a lane that has finished its chain takes the
+                             next one instead of idling until the wavefront's slowest chain is done (stage by stage).
+                             The launch then has 64 / [0] as many wavefronts: a caller that wants the GPU full keeps
+                             [0] / 64 as many calls in flight.  Only for runs of all four stages without diagnostics,
+                             frame chunks, [1] = 1 or [2] = 1, on the lane-per-chain path ([3] = 1, or more than
+                             40 000 chains); refused with SEQIK_ERR_BAD_ARG elsewhere;
                              [1]: 0 = a run of all four stages without diagnostics is ONE launch (every wave takes its
                              chains through stages 1, 2, 3, 4 in turn; stage_events[0] is then recorded in front of that
                              kernel and [1]..[4] behind it), 1 = always one launch per stage (this also switches the

@@ -91,6 +91,36 @@ SEQIK_HD bool wave_any(bool c)
 #endif
 }
 
+// The chain queue of run_stage<..., QUEUE>: which of the active lanes of this wavefront satisfy c (a bit mask; on the host: this
+// lane is lane 0), and how many set bits of a mask lie below this lane.
+SEQIK_HD unsigned long long wave_ballot(bool c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(c);
+#else
+    return c ? 1ull : 0ull;
+#endif
+}
+
+SEQIK_HD int lane_rank_in(unsigned long long mask)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+#else
+    (void)mask;
+    return 0;
+#endif
+}
+
+SEQIK_HD int mask_count(unsigned long long mask)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(mask);
+#else
+    return (int)__builtin_popcountll(mask);
+#endif
+}
+
 SEQIK_HD double div_(double a, double b)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !SEQIK_IEEE_DIV_SQRT
@@ -1417,6 +1447,13 @@ struct ChainIO {
                             // = the warm start the stored frames were computed from) when t_store > t_begin
     // --- PIPED instantiations only ----------------------------------------------------------------------------
     PipeLane pipe;
+    // --- QUEUE instantiations only (chain queue of the fused kernel: seqik_fused_queue_kernel in seqik_hip.hip) ---------------
+    // (pose / angles / fk / init / frames then point at the FIRST chain of the wavefront's pool: the same in every lane)
+    int32_t q_seq;          // the chain of the pool this lane starts on (0 .. 63)
+    int32_t q_next;         // next chain of the POOL that no lane has taken yet (the same value in every lane; 64 at the start)
+    int32_t q_end;          // chains in the pool
+    uint32_t q_pose, q_ang, q_fk, q_init, q_frames;  // element strides from one chain of the pool to the next (32 bits: one
+                            // v_mad_u64_u32 per pointer; the launcher refuses the queue when a stride does not fit)
 };
 
 // Prefix frame of STAGE from the angles of the earlier stages: the "fixed" links of
@@ -1473,10 +1510,37 @@ SEQIK_HD void build_prefix(Frame &pre, const LegConst &lc, const double *ang, in
 //               kept across passes and not re-derived after a rejected trial when no lane of the wavefront has moved (see
 //               jac_valid below; the 168-register build would spill the 14 doubles); (ii) the reflective select_step and
 //               the post-trial block in their branch-free forms (select_step_reflective_ilp).  Same values.
+//   QUEUE     : CHAIN QUEUE (round 6).  The wavefront owns a POOL of chains of one leg (io.q_next .. io.q_end, sequences; the
+//               lanes start on the pool's first 64) and a lane that has finished the last frame of its chain takes the next
+//               chain nobody has taken yet instead of idling until the slowest lane of the wavefront is done: the tail of
+//               a wavefront -- ever fewer active lanes issuing whole passes -- is paid once per pool instead of once per 64
+//               chains.  Which lane walks a chain does not enter its arithmetic: same bits.  The hand-out needs no atomic and no
+//               LDS: the lanes that finish in the same pass number themselves by a ballot (lane_rank_in), every lane of the
+//               wavefront advances its copy of q_next by the same count.  Costs one ballot and one scalar branch per pass.
 template <int STAGE, bool WANT_FK, bool WANT_DIAG, bool FROM_ANGLES, bool HANDOFF, bool CHUNKED = false, bool PIPED = false,
-          bool SPLIT = false, bool LAT = false>
-SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
+          bool SPLIT = false, bool LAT = false, bool QUEUE = false>
+SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io_arg)
 {
+    static_assert(!QUEUE || (!CHUNKED && !PIPED && !SPLIT && !LAT && !WANT_DIAG && !FROM_ANGLES),
+                  "the chain queue belongs to the fused lane-per-chain kernel");
+    // QUEUE: io_arg points at the first chain of the wavefront's pool (wave-uniform: scalar registers); the lane's current chain
+    // is q_seq, and its pointers are formed from that where a frame starts and where it ends -- they are not kept in vector
+    // registers across the body of a pass (the first version of the queue, which re-based per-lane pointers, spilled 11 more
+    // registers than the plain kernel and gave back what the queue saved)
+    ChainIO io_q;
+    if constexpr (QUEUE) io_q = io_arg;
+    const ChainIO &io = QUEUE ? io_q : io_arg;
+    int32_t q_next = QUEUE ? io_arg.q_next : 0, q_seq = QUEUE ? io_arg.q_seq : 0;
+    auto queue_point_at = [&](int32_t seq) {
+        if constexpr (QUEUE) {
+            const uint32_t u = (uint32_t)seq;
+            io_q.pose = io_arg.pose + (uint64_t)u * io_arg.q_pose;
+            io_q.angles = io_arg.angles + (uint64_t)u * io_arg.q_ang;
+            if constexpr (WANT_FK) io_q.fk = io_arg.fk + (uint64_t)u * io_arg.q_fk;   // (WANT_FK: the launcher passes a buffer)
+            io_q.frames = io_arg.frames + (uint64_t)u * io_arg.q_frames;
+        }
+    };
+    queue_point_at(q_seq);
     static_assert(!LAT || (PIPED && !WANT_DIAG), "LAT is a stage-pipeline option");
     constexpr bool PAIRED = SPLIT && StageTraits<STAGE>::NA == 2;
     const bool odd = PAIRED && pair_is_odd();
@@ -1502,8 +1566,9 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
     double x[2] = {sc.seed[0], (NA == 2) ? sc.seed[1] : 0.0}, f[3] = {0.0, 0.0, 0.0};
     if (io.init) {
         const int64_t is = CHUNKED ? io.init_stride : 1;
-        x[0] = io.init[DOF0 * is];
-        if constexpr (NA == 2) x[1] = io.init[(DOF0 + 1) * is];
+        const double *init_c = QUEUE ? io_arg.init + (uint64_t)(uint32_t)q_seq * io_arg.q_init : io.init;
+        x[0] = init_c[DOF0 * is];
+        if constexpr (NA == 2) x[1] = init_c[(DOF0 + 1) * is];
     }
     double cost = 0.0, Delta = 0.0, alpha = 0.0;
     double sa = 0.0, ca = 1.0, sb = 0.0, cb = 1.0;  // sin/cos of the active joints at x
@@ -1587,6 +1652,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         if constexpr (PIPED) SEQIK_BLK_END_OF(BLK_PIPE_WAIT);
         if (new_solve) {
             SEQIK_BLK_COUNT(CNT_NEW_SOLVE);
+            queue_point_at(q_seq);
             const double *org = io.pose + t * io.pose_frame;
             const double *kp = org + STAGE * io.pose_row;
             if constexpr (STAGE > 1) {
@@ -1855,6 +1921,7 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
         SEQIK_BLK_END_OF(BLK_POST_TRIAL);
         if (finished) {
             SEQIK_BLK_COUNT(CNT_FINISHED);
+            queue_point_at(q_seq);
             // ---- solve done: store, advance to the next frame -------------------------------
             const bool stored = !CHUNKED || t >= io.t_store;  // run-in frames leave nothing but the hand-off
             if (stored) {
@@ -1920,6 +1987,30 @@ SEQIK_HD void run_stage(const LegConst &lc, const ChainIO &io)
             new_solve = true;
         }
         SEQIK_BLK_END_OF(BLK_FINISHED);
+        if constexpr (QUEUE) {
+            // (all lanes that are still in the loop are converged here)
+            const bool chain_done = t >= io.n_frames;
+            const unsigned long long done_mask = wave_ballot(chain_done);
+            if (done_mask != 0ull) {  // wave-uniform; once per chain and lane
+                if (chain_done) {
+                    const int32_t s_new = q_next + lane_rank_in(done_mask);
+                    if (s_new < io_arg.q_end) {
+                        q_seq = s_new;
+                        // a new chain starts as every chain does (function entry): seeds / init, first frame, general start
+                        x[0] = sc.seed[0];
+                        x[1] = (NA == 2) ? sc.seed[1] : 0.0;
+                        if (io_arg.init) {
+                            const double *init_c = io_arg.init + (uint64_t)(uint32_t)s_new * io_arg.q_init;
+                            x[0] = init_c[DOF0];
+                            if constexpr (NA == 2) x[1] = init_c[DOF0 + 1];
+                        }
+                        have_pe = false;
+                        t = 0;
+                    }
+                }
+                q_next += mask_count(done_mask);
+            }
+        }
     }
     SEQIK_BLK_END(STAGE);
 }

@@ -190,6 +190,7 @@ struct KernelArgs {
     int32_t lanes_per_wave;       // W: chains a wavefront carries (1..64), see chain_of_lane()
     LegOrder leg_order;           // dispatch order of the legs
     int32_t lane_pairs;           // stage pipeline: thin waves split a pass over lane pairs (0 = off, for measurements)
+    int32_t pool;                 // chain queue (seqik_fused_queue_kernel): sequences of one leg a wavefront owns (> 64), else 0
     int32_t *fault;               // host-visible fault word ("Device faults" below); the stage pipeline's watchdog writes it
     // element strides (SeqikLayout): pose (chain, key-point row, frame), angles (chain, dof, frame)
     int64_t pose_chain, pose_row, pose_frame;
@@ -416,6 +417,72 @@ seqik_fused_kernel(KernelArgs a)
     seqik::run_stage<2, WANT_FK, false, false, true>(lc, io);
     seqik::run_stage<3, WANT_FK, false, false, true>(lc, io);
     seqik::run_stage<4, WANT_FK, false, false, false>(lc, io);
+}
+
+// CHAIN QUEUE of the fused kernel (round 6; SeqikOptions.reserved[0] = 128, 192, ... 4096: chains per wavefront).
+// A wavefront of seqik_fused_kernel lives as long as the slowest of its 64 chains and spends the tail of every stage with
+// ever fewer active lanes -- in the body of a pass 52 of 64 lanes are active on the benchmark's iid poses, 31-47 on the smooth ones
+// (profiles/r03_block_entries_*.json).  Here a wavefront owns a POOL of `pool` consecutive sequences of one leg; its 64 lanes
+// start on the first 64 and a lane that has finished its chain takes the next one of the pool (run_stage<..., QUEUE>: ballot
+// arithmetic, no atomics), stage by stage: the wave finishes stage s for the whole pool, then walks the pool again for stage
+// s + 1.  A stage-(s + 1) chain may be walked by another lane than its stage s was, so the hand-off frames cross lanes OF
+// THE SAME WAVEFRONT through the workspace in HBM: a device-scope fence between the stages makes the stores of stage s
+// visible to the loads of stage s + 1 (the vector L1 is not coherent across the lanes' earlier reads of the same lines).
+// The launch has 64 / pool as many wavefronts: a caller that wants the GPU full keeps pool / 64 as many calls in flight
+// (bench.py calibrates (steps in flight, pool) together).  Bound of the gain, in issue cycles, from the oracle's pass counts
+// (profiles/r06_queue_bound.json): pool 128 / 256 / 512 -> 6 / 10 / 13 % (iid), 10 / 17 / 22 % (smooth).  Same bits as every
+// other launch path (tests/test_gpu_parity.py::test_chain_queue_of_the_fused_kernel_bit_for_bit, the soak).
+template <bool WANT_FK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SEQIK_WAVES_PER_EU, SEQIK_WAVES_PER_EU)))
+seqik_fused_queue_kernel(KernelArgs a)
+{
+    __shared__ seqik::LegConst s_legs[kMaxLegs];
+    {
+        const int words = a.n_legs * (int)(sizeof(seqik::LegConst) / sizeof(uint32_t));
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.legs);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(s_legs);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    // one wavefront per workgroup: wave = blockIdx.x; the waves of a leg are adjacent, legs in dispatch order (chain_of_lane)
+    const int64_t n_grp = (a.n_seq + a.pool - 1) / a.pool;   // pools (= wavefronts) per leg
+    const int64_t slot = (int64_t)blockIdx.x / n_grp;
+    if (slot >= a.n_legs) return;
+    const int leg = a.leg_order.leg[slot];
+    const int64_t pool_first = ((int64_t)blockIdx.x - slot * n_grp) * a.pool;
+    const int64_t pool_end = pool_first + a.pool < a.n_seq ? pool_first + a.pool : a.n_seq;
+    if (pool_first + (int64_t)threadIdx.x >= pool_end) return;   // (only in the last pool of a leg: a lane with no chain to start on)
+    const int64_t c0 = pool_first * a.n_legs + leg;   // first chain of the pool: wave-uniform, so are the pointers below
+    seqik::ChainIO io;
+    io.pose = a.pose + c0 * a.pose_chain;
+    io.pose_row = a.pose_row;
+    io.pose_frame = a.pose_frame;
+    io.angles = a.angles + c0 * a.ang_chain;
+    io.ang_dof = a.ang_dof;
+    io.ang_frame = a.ang_frame;
+    io.fk = a.fk ? a.fk + c0 * a.n_frames * 27 : nullptr;
+    io.status = nullptr;
+    io.nfev = nullptr;
+    io.init = a.init ? a.init + c0 * 7 : nullptr;
+    io.frames = a.frames + c0 * a.n_frames * 12;
+    io.n_frames = a.n_frames;
+    io.q_seq = (int32_t)threadIdx.x;
+    io.q_next = 64;
+    io.q_end = (int32_t)(pool_end - pool_first);
+    io.q_pose = (uint32_t)(a.n_legs * a.pose_chain);   // (launch() has checked that these fit)
+    io.q_ang = (uint32_t)(a.n_legs * a.ang_chain);
+    io.q_fk = (uint32_t)((int64_t)a.n_legs * a.n_frames * 27);
+    io.q_init = (uint32_t)(a.n_legs * 7);
+    io.q_frames = (uint32_t)((int64_t)a.n_legs * a.n_frames * 12);
+    const seqik::LegConst &lc = s_legs[leg];
+    // every stage starts on the lane's FIRST chain again (run_stage works on a copy of io)
+    seqik::run_stage<1, false, false, false, true, false, false, false, false, true>(lc, io);
+    __threadfence();
+    seqik::run_stage<2, WANT_FK, false, false, true, false, false, false, false, true>(lc, io);
+    __threadfence();
+    seqik::run_stage<3, WANT_FK, false, false, true, false, false, false, false, true>(lc, io);
+    __threadfence();
+    seqik::run_stage<4, WANT_FK, false, false, false, false, false, false, false, true>(lc, io);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1269,6 +1336,28 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         n_waves = (n_vchains + a.lanes_per_wave - 1) / a.lanes_per_wave;
         a.lanes_per_wave = -a.lanes_per_wave;
     }
+    // chain queue of the fused kernel: SeqikOptions.reserved[0] in 65..4096 = chains a wavefront OWNS (a multiple of 64; its 64
+    // lanes take them one after the other).  Only where seqik_fused_kernel would run: all four stages, no diagnostics, not
+    // chunked, not piped, leg-pure wavefronts, at least 1024 chains; anywhere else the option is refused rather than ignored.
+    a.pool = 0;
+    if (opt && opt->reserved[0] > 64) {
+        const bool plain_fused = first_stage == 1 && last_stage == 4 && !diag && !chunked && !piped && !staged && opt->reserved[2] != 1;
+        const int64_t widest = n_legs * (a.pose_chain > a.ang_chain ? a.pose_chain : a.ang_chain) > (int64_t)n_legs * n_frames * 27
+                                   ? n_legs * (a.pose_chain > a.ang_chain ? a.pose_chain : a.ang_chain) : (int64_t)n_legs * n_frames * 27;
+        if (opt->reserved[0] > 4096 || opt->reserved[0] % 64 != 0 || !plain_fused || n_seq > 0x7fffffffLL || widest > 0xffffffffLL)
+            return fail(SEQIK_ERR_BAD_ARG, "reserved[0] > 64 (chain queue: chains per wavefront) must be a multiple of 64 up to 4096 and "
+                                           "needs the single-launch lane-per-chain path (all four stages, no diagnostics, no frame "
+                                           "chunks, reserved[1] != 1, reserved[2] != 1, reserved[3] = 1 or more than 40 000 chains)%s");
+        a.pool = opt->reserved[0];
+        n_waves = ((n_seq + a.pool - 1) / a.pool) * n_legs;
+        block = 64;
+    }
+    static const bool queue64 = getenv("SEQIK_QUEUE64") != nullptr;   // measurement: the queue kernel with pools of 64 (no pulls)
+    if (queue64 && a.pool == 0 && a.lanes_per_wave == 64 && first_stage == 1 && last_stage == 4 && !diag && !chunked && !piped && !staged &&
+        !(opt && opt->reserved[2] == 1)) {
+        a.pool = 64;
+        block = 64;
+    }
     int64_t grid64 = (n_waves * 64 + block - 1) / block;
     if (grid64 > 0x7fffffffLL || n_waves > 0x7fffffffLL) return fail(SEQIK_ERR_BAD_ARG, "too many chains for one launch%s");
     const dim3 grid((unsigned)grid64), blk(block);
@@ -1378,6 +1467,9 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
                 else hipLaunchKernelGGL((seqik_pipe_kernel<false, 2>), pipe_grid, pipe_blk, 0, stream, a);
             } else if (fk) hipLaunchKernelGGL((seqik_pipe_kernel<true, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
             else hipLaunchKernelGGL((seqik_pipe_kernel<false, SEQIK_WAVES_PER_EU>), pipe_grid, pipe_blk, 0, stream, a);
+        } else if (a.pool > 0) {
+            if (fk) hipLaunchKernelGGL((seqik_fused_queue_kernel<true>), grid, blk, 0, stream, a);
+            else hipLaunchKernelGGL((seqik_fused_queue_kernel<false>), grid, blk, 0, stream, a);
         } else if (fk) hipLaunchKernelGGL((seqik_fused_kernel<true>), grid, blk, 0, stream, a);
         else hipLaunchKernelGGL((seqik_fused_kernel<false>), grid, blk, 0, stream, a);
         HIP_TRY(hipGetLastError());

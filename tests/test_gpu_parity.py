@@ -746,3 +746,65 @@ print("ALL CLEAR")
     assert "A NAN" in out and "B ACCEPTED B FINITE" in out and "B NO FAULT" in out, out
     assert "A: seqik: HIP error: seqik_check_faults_stream: stage pipeline watchdog" in out, out
     assert "ALL CLEAR" in out, out
+
+
+def test_chain_queue_of_the_fused_kernel_bit_for_bit(lib, oracle):
+    """Round 6: SeqikOptions.reserved[0] = 128 ... 4096 -- a wavefront of the single-launch kernel owns a POOL of chains and a
+    lane that has finished its chain takes the next one (run_stage<..., QUEUE>, seqik_fused_queue_kernel).  Which lane walks a
+    chain must not enter its arithmetic: == the plain launch bit for bit (angles and FK) for pools of 128 / 192 / 1024 / 4096
+    chains (more than a leg has: one pool per leg; ragged last pools: 1500 = 11 x 128 + 92 sequences), with and without FK,
+    with per-chain warm starts, dense and planar layouts, RAW key points with the alignment fused; sampled chains == the
+    oracle; options the queue cannot serve are refused, not ignored."""
+    import torch
+    from seqikpy_amd import data, synthetic, utils
+    legs = data.LEGS
+    body = utils.calculate_body_size(data.TEMPLATE_NMF_LOCOMOTION, legs)
+    S, N, L = 1500, 24, len(legs)
+    pose = synthetic.synthetic_pose(S, N, legs, data.BOUNDS_LOCOMOTION, body, data.TEMPLATE_NMF_LOCOMOTION, variant="iid", seed=606)
+    params = [lib.make_leg_params(l, data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION) for l in legs]
+    plain = lib.solve_seq(pose, params, want_fk=True, pipeline=1)
+    rng = np.random.default_rng(3)
+    for s, li in zip(rng.integers(0, S, 8), rng.integers(0, L, 8)):
+        seg, b, seeds = oracle.leg_params(legs[li], data.BOUNDS_LOCOMOTION, body, data.INITIAL_ANGLES_LOCOMOTION)
+        ref = oracle.seq_leg(pose[s, li], seg, b, seeds)
+        assert np.array_equal(plain["angles"][s, li], ref["angles"]) and np.array_equal(plain["fk"][s, li], ref["fk"])
+    for pool in (128, 192, 1024, 4096):
+        q = lib.solve_seq(pose, params, want_fk=True, pipeline=1, lanes_per_wave=pool)
+        assert np.array_equal(q["angles"], plain["angles"]) and np.array_equal(q["fk"], plain["fk"]), pool
+    q = lib.solve_seq(pose, params, want_fk=False, pipeline=1, lanes_per_wave=256)
+    assert np.array_equal(q["angles"], plain["angles"]) and q["fk"] is None
+    # per-chain warm starts (init_angles) travel with the chain a lane takes
+    init = plain["angles"][:, :, -1].copy()
+    a = lib.solve_seq(pose, params, want_fk=True, pipeline=1, init_angles=init)
+    b = lib.solve_seq(pose, params, want_fk=True, pipeline=1, init_angles=init, lanes_per_wave=128)
+    assert np.array_equal(a["angles"], b["angles"]) and np.array_equal(a["fk"], b["fk"]) and not np.array_equal(a["angles"], plain["angles"])
+    # RAW key points, alignment fused into the frame start
+    scales, fixed = 1.0 + 0.3 * rng.random(L), rng.normal(0.0, 1.5, (L, 3))
+    tcs = [np.asarray(data.TEMPLATE_NMF_LOCOMOTION[f"{l}_Coxa"], dtype=np.float64) for l in legs]
+    affs = [lib.make_affine(fixed[i], scales[i], tcs[i]) for i in range(L)]
+    raw = np.stack([(pose[:, i] - tcs[i]) / scales[i] + fixed[i] for i in range(L)], 1)
+    fa = lib.solve_seq(raw, params, want_fk=True, pipeline=1, affine=affs)
+    fb = lib.solve_seq(raw, params, want_fk=True, pipeline=1, affine=affs, lanes_per_wave=192)
+    assert np.array_equal(fa["angles"], fb["angles"]) and np.array_equal(fa["fk"], fb["fk"])
+    # the benchmark's path: planar device buffers, asynchronous entry point, two launches in flight on two streams
+    d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
+    outs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for k, pool in enumerate((128, 256)):
+        d_ang = torch.zeros((S, L, 7, N), dtype=torch.float64, device="cuda")
+        d_fk = torch.zeros((S, L, N, 9, 3), dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(streams[k]):
+            lib.solve_seq_device(d_pose.data_ptr(), S, L, N, params, d_ang.data_ptr(), d_fk.data_ptr(), stream=streams[k].cuda_stream,
+                                 layout=lib.planar_layout(N), lanes_per_wave=pool, pipeline=1)
+        outs.append((d_ang, d_fk))
+    torch.cuda.synchronize()
+    lib.check_faults()
+    for d_ang, d_fk in outs:
+        assert np.array_equal(d_ang.cpu().numpy().transpose(0, 1, 3, 2), plain["angles"]) and np.array_equal(d_fk.cpu().numpy(), plain["fk"])
+    # refused, not ignored: not a multiple of 64, too large, one launch per stage, diagnostics, frame chunks, the stage pipeline
+    for kw in (dict(lanes_per_wave=100), dict(lanes_per_wave=8192), dict(lanes_per_wave=128, staged=1), dict(lanes_per_wave=128, want_diag=True),
+               dict(lanes_per_wave=128, frame_chunk=8), dict(lanes_per_wave=128, interleave_legs=1)):
+        with pytest.raises(ValueError):
+            lib.solve_seq(pose[:64], params, **({"pipeline": 1} | kw))
+    with pytest.raises(ValueError):
+        lib.solve_seq(pose[:64], params, lanes_per_wave=128)      # 384 chains: the library would take the stage pipeline

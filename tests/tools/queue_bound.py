@@ -25,7 +25,11 @@ only has something to pull when a launch carries several times more chains than 
 what that would buy (m = 2, 4, 8: launches of 2 / 4 / 8 M frames x 6 legs with half / a quarter / an eighth of the
 waves).
 
-    python tests/tools/queue_bound.py  > profiles/r04_queue_bound.json         (CPU, ~1 min)
+Round 6 (round-5 review, item 4): the same for the launch shape a PERSISTENT-wavefront kernel could have inside config 3 --
+the three steps the benchmark keeps in flight fed to ONE grid of 3 072 resident wavefronts as one queue: 281 250 chains on
+196 608 lanes, 92 chains per wavefront (m = 1.43) -- next to m = 2, 4, 8, for both variants; cycles are compared per chain.
+
+    python tests/tools/queue_bound.py  > profiles/r06_queue_bound.json         (CPU, ~1 min)
 """
 import json
 import os
@@ -127,16 +131,19 @@ def main():
         p = lane_passes(variant, n_seq)                     # (L, S, 4)
         models = {s: cost_model(ej, s) for s in (1, 2, 3, 4)}
         rows = {}
-        for name, m in (("now", 1), ("queue_m2", 2), ("queue_m4", 4), ("queue_m8", 8)):
+        for name, pool in (("now", 64), ("queue_m1.43_three_steps_as_one_queue", 92), ("queue_m2", 128), ("queue_m4", 256), ("queue_m8", 512)):
             wave_passes = cost = 0.0
+            chains = 0
             for li in range(p.shape[0]):
-                for w0 in range(0, n_seq, 64 * m):
+                for w0 in range(0, n_seq - pool + 1, pool):      # full pools only; cycles are compared per chain below
+                    chains += pool
                     for s in (1, 2, 3, 4):
-                        chunk = p[li, w0:w0 + 64 * m, s - 1]
-                        life, c = wave_cost_now(models[s], chunk) if m == 1 else wave_cost_queue(models[s], chunk)
+                        chunk = p[li, w0:w0 + pool, s - 1]
+                        life, c = wave_cost_now(models[s], chunk) if pool == 64 else wave_cost_queue(models[s], chunk)
                         wave_passes += life
                         cost += c
-            rows[name] = {"wave_passes": wave_passes, "cycles": cost}
+            rows[name] = {"chains_per_wavefront": pool, "chains": chains, "wave_passes": wave_passes * n_seq * p.shape[0] / chains,
+                          "cycles": cost * n_seq * p.shape[0] / chains}
         packed_passes = sum(p[:, :, s - 1].sum() / 64.0 for s in (1, 2, 3, 4))
         packed_cost = sum(p[:, :, s - 1].sum() / 64.0 * float(pass_cost(models[s], 64)) for s in (1, 2, 3, 4))
         rows["packed"] = {"wave_passes": float(packed_passes), "cycles": float(packed_cost)}
@@ -160,6 +167,13 @@ def main():
         rows["model_check_cycles_per_wave_pass"] = {"predicted": pred, "measured_r03": meas}
         rows["full_pass_cost_over_3_lane_pass_cost"] = {s: float(pass_cost(models[s], 64) / pass_cost(models[s], 3)) for s in (1, 2, 3, 4)}
         res[variant] = rows
+    res["reading_round_6"] = (
+        "Inside config 3 the most a queue can be given is the three steps in flight as ONE pool: 92 chains per resident wavefront "
+        "(m = 1.43).  Its bound (`queue_m1.43_three_steps_as_one_queue`.cycles_vs_now) is what a persistent-wavefront kernel that "
+        "takes all three batches in one launch could save AT BEST -- before the queue's own instructions (an atomic, the "
+        "per-lane reload of the chain's addresses, a second frame-start evaluation path) and at the price of an API in which a "
+        "'step' is three batches; m = 2 needs a step of 4.2 M frames, m = 4 of 8.4 M.  The 10 % bar of the review is reached "
+        "for the smooth variant from m = 2 on, for iid from m = 4 on; at the launch shape config 3 allows it is not.")
     res["reading"] = ("`now` -> `packed` is everything lane balancing could ever give; `queue_m` is what a chain queue gives when a "
                       "LAUNCH carries 64 m chains per wave.  One benchmark step is 93 750 chains on 196 608 lane slots (m < 1), "
                       "and the steps in flight are separate launches, so for config 3 as BASELINE.json states it (1M frames x 6 "
