@@ -28,7 +28,7 @@ BYTES_STAGE = {1: 48 + 16 + 96, 2: 48 + 96 + 16 + 96 + 48, 3: 48 + 96 + 16 + 96 
 # stage k reads the origin + its key point (48 B) and the 96-byte prefix frame the previous stage left in
 # the workspace, writes its own angles, the next prefix frame (96 B) and its rows of the 9 x 3 FK record
 TRAFFIC_ROUNDS = ("r06", "r05", "r04", "r03", "r02", "r01")  # newest first; a summary is used only if it matches the workload AND the build
-LATENCY_ROUND = "r05"     # profiles/<round>_latency_floor.json (scripts/latency_floor.py)
+LATENCY_ROUND = "r06"     # profiles/<round>_latency_floor.json (scripts/latency_floor.py)
 LF_WINDOW = (284, 302)   # tests/conftest.py::LF_DEGENERATE: the anipose LF kinematic-singularity episode
 
 
@@ -251,7 +251,7 @@ def measured_cost_floor(mix, n_all, simds, clock_hz, ms_per_step):
     ones (~2.7).  None when the files are absent."""
     try:
         costs = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_issue_costs.json")))["classes"]
-        isa_path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_fused_isa.json") for r in ("r05", "r04", "r03")) if os.path.exists(p))
+        isa_path = next(p for p in (os.path.join(ROOT, "profiles", f"{r}_fused_isa.json") for r in ("r06", "r05", "r04", "r03")) if os.path.exists(p))
         isa = json.load(open(isa_path))["kernels"]["fused_kernel<fk=1>"]
         share4 = isa["valu_not_f64_arith_issue_split"]["share_about_4.2_cycles"]
     except (OSError, KeyError, ValueError, StopIteration):

@@ -128,15 +128,15 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_committed_pmc_summary_belongs_to_these_kernel_sources(hiplib):
-    """bench.py prices its roofline with the PMC counters of profiles/traffic_r05*.json only while they were measured on
+    """bench.py prices its roofline with the PMC counters of profiles/traffic_r06*.json only while they were measured on
     the kernel code of this tree (`_lib.csrc_sha256`: code only, comments and white space do not count).  If this fails the
-    solver kernels changed: re-run `bash scripts/gpu_profile.sh r05 [--variant smooth]` + `scripts/summarize_profile.py r05 r05`
-    (and `bash scripts/gpu_latency_profile.sh r05` + `scripts/latency_floor.py r05 r05` for the latency-bound kernels)."""
+    solver kernels changed: re-run `bash scripts/gpu_profile.sh r06` / `r06s --variant smooth` + `scripts/summarize_profile.py r06 r06` / `r06s r06`
+    (and `bash scripts/gpu_latency_profile.sh r06` + `scripts/latency_floor.py r06 r06` for the latency-bound kernels)."""
     import json
     assert hiplib._code_only("a = b; // note\n/* block\n comment */  c  =\td;") == "a = b; c = d;"
-    for name in ("traffic_r05.json", "traffic_r05_smooth.json"):
+    for name in ("traffic_r06.json", "traffic_r06_smooth.json"):
         t = json.load(open(os.path.join(ROOT, "profiles", name)))
         assert t["csrc_files"] == hiplib.KERNEL_SOURCES
         assert t["csrc_sha256"] == hiplib.csrc_sha256(), name
-    lat = json.load(open(os.path.join(ROOT, "profiles", "r05_latency_floor.json")))
+    lat = json.load(open(os.path.join(ROOT, "profiles", "r06_latency_floor.json")))
     assert lat["csrc_files"] == hiplib.LATENCY_SOURCES and lat["csrc_sha256"] == hiplib.csrc_sha256(hiplib.LATENCY_SOURCES)
