@@ -84,3 +84,37 @@ suffix = ("_staged" if "stage1" in pm.index else "") + ("" if b["config"]["varia
 json.dump(out, open(f"{dst}/traffic_{rnd}{suffix}.json", "w"), indent=1)
 print(pm.round(0).to_string())
 print(json.dumps({k: round(v / units, 1) for k, v in out.items() if k.endswith("bytes_per_launch")}, indent=0))
+
+
+# ---- round 6: the chain-queue launches of the same run (bench.py calibrates them beside the plain kernel): one summary per pool size,
+# told apart by the grid (ceil(sequences / pool) x legs wavefronts of 64 lanes) -> profiles/traffic_<rnd>_queue<pool>[_variant].json
+def pmc_queue(kind, grid):
+    d = pd.read_csv(newest(f"{src}/{tag}_{kind}/*/*_counter_collection.csv"))
+    d = d[d.Kernel_Name.str.contains("seqik_fused_queue_kernel") & (d.Grid_Size == grid)]
+    return d.pivot_table(index="Kernel_Id", columns="Counter_Name", values="Counter_Value", aggfunc="mean").mean(axis=0) if len(d) else None
+
+try:
+    S_, L_ = b["config"]["sequences_per_gpu"], b["config"]["legs"]
+    allq = pd.read_csv(newest(f"{src}/{tag}_sq/*/*_counter_collection.csv"))
+    grids = sorted(set(allq[allq.Kernel_Name.str.contains("seqik_fused_queue_kernel")].Grid_Size))
+    for grid in grids:
+        pools = [p_ for p_ in range(128, 4097, 64) if -(-S_ // p_) * L_ * 64 == grid]
+        if not pools:
+            continue
+        pool = pools[0]
+        parts = {kind: pmc_queue(kind, grid) for kind in ("fetch", "write", "sq", "f64")}
+        if any(v is None for v in parts.values()):
+            continue
+        f, w = float(parts["fetch"]["FETCH_SIZE"]) * 1024, float(parts["write"]["WRITE_SIZE"]) * 1024
+        q = dict(out, kernel="seqik_fused_queue_kernel<true>", chain_queue=pool)
+        q.update({"fused_fetch_bytes_per_launch": f, "fused_write_bytes_per_launch": w, "fused_hbm_bytes_per_launch": f + w,
+                  "fused_valu_insts_per_launch": float(parts["sq"]["SQ_INSTS_VALU"]),
+                  "fused_valu_lane_utilisation": float(parts["sq"]["SQ_THREAD_CYCLES_VALU"]) / (64.0 * float(parts["sq"]["SQ_ACTIVE_INST_VALU"]))})
+        for c in ("ADD", "MUL", "FMA", "TRANS"):
+            q[f"fused_f64_{c.lower()}_insts_per_launch"] = float(parts["f64"][f"SQ_INSTS_VALU_{c}_F64"])
+        vt = "" if b["config"]["variant"] == "iid" else "_" + b["config"]["variant"]
+        json.dump(q, open(f"{dst}/traffic_{rnd}_queue{pool}{vt}.json", "w"), indent=1)
+        print(f"chain queue, pool {pool}: {q['fused_valu_insts_per_launch']:.4g} VALU instructions per launch, lanes {q['fused_valu_lane_utilisation']:.3f}, "
+              f"HBM {q['fused_hbm_bytes_per_launch'] / units:.0f} B per leg-frame")
+except Exception as exc:  # noqa: BLE001
+    print("chain-queue summary skipped:", exc)
