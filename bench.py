@@ -334,7 +334,7 @@ def main():
         best = None
         plain = args.lanes_per_wave == 0 and not args.staged and not args.interleave_legs
         for n_st, pipe, lat, pool in [c + (0,) for c in bs.depth_candidates(args.steps, S * L)] + \
-                [(d, 1, None, p) for d, p in (bs.queue_candidates(S * L) if plain else [])]:
+                [(d, 1 if p else 0, None, p) for d, p in (bs.queue_candidates(S * L) if plain else [])]:
             bt, ms = None, float("inf")
             try:
                 bt = Batch(None, params, args, n_st, pipeline=pipe, like=batch, pool=pool)

@@ -186,7 +186,9 @@ def queue_candidates(chains):
     over the very region that is measured and not switched on."""
     if not chains or chains < 80000:
         return []
-    return [c for c in ((4, 128), (6, 128), (12, 256)) if c[0] <= MAX_DEPTH]
+    # (pool 0 = the plain kernel one and two steps deeper than the depth-3 candidate: 11.28 against 11.48 ms per step at depth 4
+    # over 100 steps, profiles/r05_n1_streams.jsonl)
+    return [c for c in ((4, 0), (5, 0), (4, 128), (6, 128), (12, 256)) if c[0] <= MAX_DEPTH]
 
 
 def depth_cap(chains):
