@@ -788,15 +788,13 @@ def test_chain_queue_of_the_fused_kernel_bit_for_bit(lib, oracle):
     assert np.array_equal(fa["angles"], fb["angles"]) and np.array_equal(fa["fk"], fb["fk"])
     # the benchmark's path: planar device buffers, asynchronous entry point, two launches in flight on two streams
     d_pose = torch.from_numpy(np.ascontiguousarray(pose.transpose(0, 1, 3, 2, 4))).cuda()
-    outs = []
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [(torch.zeros((S, L, 7, N), dtype=torch.float64, device="cuda"), torch.zeros((S, L, N, 9, 3), dtype=torch.float64, device="cuda"))
+            for _ in streams]
+    torch.cuda.synchronize()      # the upload and the zero fills ran on the default stream: done before the side streams start
     for k, pool in enumerate((128, 256)):
-        d_ang = torch.zeros((S, L, 7, N), dtype=torch.float64, device="cuda")
-        d_fk = torch.zeros((S, L, N, 9, 3), dtype=torch.float64, device="cuda")
-        with torch.cuda.stream(streams[k]):
-            lib.solve_seq_device(d_pose.data_ptr(), S, L, N, params, d_ang.data_ptr(), d_fk.data_ptr(), stream=streams[k].cuda_stream,
-                                 layout=lib.planar_layout(N), lanes_per_wave=pool, pipeline=1)
-        outs.append((d_ang, d_fk))
+        lib.solve_seq_device(d_pose.data_ptr(), S, L, N, params, outs[k][0].data_ptr(), outs[k][1].data_ptr(), stream=streams[k].cuda_stream,
+                             layout=lib.planar_layout(N), lanes_per_wave=pool, pipeline=1)
     torch.cuda.synchronize()
     lib.check_faults()
     for d_ang, d_fk in outs:
