@@ -13,7 +13,7 @@ in verified frame chunks), ``frame_sharding`` (one recording over the GPUs of a 
 All arithmetic runs in ``csrc/libseqik_hip.so`` (hand-written HIP for gfx950) behind the C ABI
 of ``include/seqik.h``; there is no CPU fallback.
 """
-__version__ = "0.4.0"
+__version__ = "0.5.0"
 
 import os as _os
 
