@@ -7,8 +7,9 @@ Same module / class names as the reference for this path:
     from seqikpy_amd.data import BOUNDS, INITIAL_ANGLES
 
 plus, beyond the reference: ``batch.run_ik_and_fk_many`` (many recordings in one launch),
-``streaming.SeqikStream`` (slabs from pinned host memory), ``run_ik_and_fk(frame_parallel="auto")`` (one long recording
-in verified frame chunks), ``frame_sharding`` (one recording over the GPUs of a node).
+``streaming.SeqikStream`` (slabs from pinned host memory), verified frame chunks that let ONE recording fill the GPU (the
+default of ``run_ik_and_fk`` since 0.5: ``frame_parallel="auto"``; ``frame_parallel=False`` is the reference's frame-by-frame
+walk, bit-identical to the C restatement), ``frame_sharding`` (one recording over the GPUs of a node).
 
 All arithmetic runs in ``csrc/libseqik_hip.so`` (hand-written HIP for gfx950) behind the C ABI
 of ``include/seqik.h``; there is no CPU fallback.

@@ -655,8 +655,8 @@ def solve_seq(pose, legs, first_stage=1, last_stage=4, angles=None, want_fk=True
     pose: (S, L, N, 5, 3) float64; legs: list of L ``SeqikLegParams``; angles: optional
     (S, L, N, 7) with earlier-stage columns filled when ``first_stage > 1``.
     ``affine``: optional list of L ``SeqikAffine`` -- ``pose`` then holds RAW key points and the
-    alignment is fused into the kernels.  ``lanes_per_wave``: chains per wavefront (0 = automatic, see
-    ``SeqikOptions.reserved[0]``); ``staged=1``: one launch per stage instead of the single fused launch.
+    alignment is fused into the kernels.  ``lanes_per_wave``: chains per wavefront (0 = automatic; 128, 192, ... 4096 = the chain
+    queue of the single-launch kernel, see ``SeqikOptions.reserved[0]``); ``staged=1``: one launch per stage instead of the single fused launch.
     ``frame_chunk`` (0 = serial walk, bit-exact; -1 = automatic; > 0 = frames per chunk), ``frame_halo``,
     ``chunk_tol``, ``chunk_rounds``: frame chunks, see ``SeqikOptions`` in include/seqik.h -- one long recording
     solved in concurrently running pieces, equal to the serial walk to about ``chunk_tol`` (default 1e-6 rad).
