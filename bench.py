@@ -161,7 +161,7 @@ def compact_line(rec):
     if cpu:
         line["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "sample", "error") if k in cpu}
         line["cpu_baseline"]["python_scipy_pool_value"] = (cpu.get("python_scipy_pool") or {}).get("value")
-    for k in ("parity_max_abs_dtheta", "parity_tolerance", "value_single_job", "value_smooth", "gpu_over_cpu", "verified", "extras_error",
+    for k in ("parity_max_abs_dtheta", "parity_tolerance", "value_single_job", "value_smooth", "value_iid", "gpu_over_cpu", "verified", "extras_error",
               "check", "detail", "detail_scalars"):
         if rec.get(k) is not None:
             line[k] = rec[k]
