@@ -88,7 +88,8 @@ def one_recording_leg(dist, world, rank, n_frames, steps, warmup, coll_dev="cpu"
     params = [_lib.leg_params_from_arrays(z[f"{l}_seg"], z[f"{l}_bounds"], z[f"{l}_seeds"]) for l in legs]
     base = np.stack([z[f"{l}_pose"] for l in legs])                                          # (L, 1000, 5, 3)
     pose = np.tile(base, (1, -(-n_frames // base.shape[1]), 1, 1))[None, :, :n_frames]       # (1, L, N, 5, 3)
-    rec = frame_sharding.FrameShardedRecording(pose, params, want_fk=True)
+    # (SEQIK_FRAME_LOCKSTEP=0: the round-2 protocol -- every slab settles itself first --, for the comparison in EXPERIMENTS.md 6.3)
+    rec = frame_sharding.FrameShardedRecording(pose, params, want_fk=True, lockstep=os.environ.get("SEQIK_FRAME_LOCKSTEP", "1") != "0")
 
     def sync():
         torch.cuda.synchronize()
@@ -129,6 +130,7 @@ def one_recording_leg(dist, world, rank, n_frames, steps, warmup, coll_dev="cpu"
             "speculative_pass_ms_this_rank": float(np.mean(spec_ms)) if spec_ms else None,
             "frames": n_frames, "legs": L, "frames_per_rank": [b - a for a, b in rec.slabs],
             "frames_per_chunk": rec.C, "run_in_frames": rec.h, "boundary_rounds": rec.stats.get("boundary_rounds"),
+            "protocol": rec.stats.get("protocol", "settle, then resume"),
             "resume_calls_per_step_this_rank": rec.stats.get("resume_calls"),
             "data": "df3d locomotion recording (fixture, 1000 frames x 6 legs) repeated end to end",
             "exchange": "all-gather of 56 B end states per leg and rank + one padded all-gather of the joint angles; FK stays sharded",

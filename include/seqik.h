@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEQIK_ABI_VERSION 6
+#define SEQIK_ABI_VERSION 7
 
 #define SEQIK_OK 0
 #define SEQIK_ERR_HIP (-1)               /* HIP runtime error (no device, launch failure, ...) */
@@ -148,7 +148,8 @@ typedef struct SeqikOptions {
     /* ---- ABI 3 ---------------------------------------------------------------------------------------------------- */
     uint8_t *chunk_flags; /* nullable [n_seq][n_legs][K] (K from seqik_frame_chunk_plan; host / device memory as
                              chunk_stats): per chunk, bit 0 = failed the first verification, bit 1 = re-solved in a
-                             repair round, bit 2 = re-solved by the sweep, bit 3 = its chain was walked serially.
+                             repair round, bit 2 = re-solved by the sweep, bit 3 = its chain was walked serially
+                             (bit 7 of a chain's first entry: INPUT of chunk_resume = 4, see there).
                              Lets a caller see WHERE a recording is chaotic (kinematic-singularity episodes) */
     double *chunk_states; /* nullable [n_seq][n_legs][K][7], DEVICE entry point only, in/out: the warm start the stored
                              frames of every chunk were computed from.  Kept by the caller between a call and the
@@ -158,7 +159,17 @@ typedef struct SeqikOptions {
                              verification, repair rounds and sweep run (chunk 0 included).  Needs an explicit
                              frame_chunk > 0 and chunk_states.  2: as 1, and chunk 0 is accepted only if its run-in
                              reproduced d_init_angles bit for bit (otherwise re-solved from it): the slab then continues
-                             the frames in front of it EXACTLY, like a carried slab of a stream */
+                             the frames in front of it EXACTLY, like a carried slab of a stream.
+                             ABI 7 -- LOCKSTEP pieces of one chunked call, for a recording whose slabs live on several GPUs
+                             (seqikpy_amd/frame_sharding.py): the ranks run the speculative pass, every {scan, repair} round
+                             and the sweep of ONE call together, exchanging the slabs' end states in between, so the result is
+                             the one-GPU call's bit for bit whatever the number of ranks.  3: the speculative pass and the
+                             first verification only (needs chunk_states).  4: ONE {scan, repair} round: d_init_angles =
+                             the CURRENT last frame of the slab to the left (NULL on the first slab), and where the caller
+                             has set bit 7 (0x80) of chunk_flags[chain][0] -- "the last chunk of the slab to the left is
+                             itself inconsistent in this round" -- an inconsistent chunk 0 is held back, as a chunk whose
+                             predecessor is about to change is inside one call (the bit is cleared).  5: the final scan and
+                             the serial sweep only (d_init_angles = the FINAL last frame of the slab to the left) */
     int32_t pad2_;
 } SeqikOptions;
 

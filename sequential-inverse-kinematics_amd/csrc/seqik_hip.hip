@@ -600,7 +600,11 @@ constexpr int kMaxChunkRounds = 8;
 constexpr int kCtrlSerial = kMaxChunkRounds + 1;  // ctrl entry whose `count` is the length of the serial list
 
 // per-chunk report bits (SeqikOptions.chunk_flags)
-enum : uint8_t { CHUNK_FLAG_FAILED_FIRST = 1, CHUNK_FLAG_REPAIRED = 2, CHUNK_FLAG_SWEPT = 4, CHUNK_FLAG_SERIAL = 8 };
+enum : uint8_t { CHUNK_FLAG_FAILED_FIRST = 1, CHUNK_FLAG_REPAIRED = 2, CHUNK_FLAG_SWEPT = 4, CHUNK_FLAG_SERIAL = 8,
+                 // INPUT of a lockstep round (chunk_resume = 4), set by the caller on chunk 0 of a chain: the last chunk of the slab
+                 // to the LEFT (another GPU's) is inconsistent in this round, so chunk 0 -- if it is inconsistent itself -- must not be
+                 // repaired yet (its predecessor is about to change), exactly as inside one call; cleared by the scan that reads it
+                 CHUNK_FLAG_LEFT_BLOCKED = 0x80 };
 
 struct ChunkArgs {
     int64_t n_chunks;      // K, chunks per chain
@@ -622,6 +626,7 @@ struct ChunkArgs {
     int32_t resume;        // chunk_resume call: the per-chunk report of the call it continues is kept (bits are added)
     int32_t round;         // entry of ctrl this launch writes (scan) / reads (repair, sweep)
     int32_t n_rounds;      // R
+    int32_t left_blocked;  // lockstep round: honour CHUNK_FLAG_LEFT_BLOCKED on chunk 0 (needs ca.flags)
 };
 
 enum : int { CHUNK_SPEC = 0, CHUNK_REPAIR = 1, CHUNK_SWEEP = 2, CHUNK_SERIAL = 3 };
@@ -705,6 +710,10 @@ __global__ void __launch_bounds__(256) seqik_chunk_scan_kernel(KernelArgs a, Chu
             inc = chunk_inconsistent(a, ca, c, k);
             // repaired now only if the chunk in front of it is not about to change
             if (inc) ready = !(k > ca.k_first && chunk_inconsistent(a, ca, c, k - 1));
+            if (ca.left_blocked && k == 0 && ca.k_first == 0) {   // the chunk in front of chunk 0 lives on another GPU
+                uint8_t *fl = ca.flags + c * ca.n_chunks;
+                if (*fl & CHUNK_FLAG_LEFT_BLOCKED) { ready = false; *fl &= (uint8_t)~CHUNK_FLAG_LEFT_BLOCKED; }
+            }
         }
     }
     int mine = -1;
@@ -1386,8 +1395,21 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         ca.stats = opt->chunk_stats;
         ca.flags = opt->chunk_flags;
         ca.round = 0;
-        const bool resume = opt->chunk_resume != 0;
-        ca.resume = resume ? (opt->chunk_resume == 2 ? 2 : 1) : 0;
+        // chunk_resume: 0 = a whole call; 1 / 2 = resume (2: chunk 0 must continue d_init exactly); LOCKSTEP pieces of ONE call spread
+        // over the GPUs of a frame-sharded recording, so that the ranks together run exactly the rounds one GPU would run:
+        // 3 = the speculative pass and the first verification only; 4 = ONE {scan, repair} round (chunk 0 against d_init, held back
+        // where CHUNK_FLAG_LEFT_BLOCKED says the chunk in front of it is about to change); 5 = the final scan + serial sweep only
+        const int mode = opt->chunk_resume;
+        if (mode < 0 || mode > 5) return fail(SEQIK_ERR_BAD_ARG, "chunk_resume must be 0 .. 5%s");
+        const bool resume = mode == 1 || mode == 2 || mode == 4 || mode == 5;
+        ca.resume = resume ? (mode == 2 ? 2 : 1) : 0;
+        if ((mode >= 3) && opt->frame_chunk <= 0)
+            return fail(SEQIK_ERR_BAD_ARG, "chunk_resume 3 / 4 / 5 (lockstep pieces) need an explicit frame_chunk > 0%s");
+        if (mode == 3 && !opt->chunk_states)
+            return fail(SEQIK_ERR_BAD_ARG, "chunk_resume = 3 needs chunk_states (the rounds that follow are other calls)%s");
+        if (mode == 4) ca.n_rounds = 1;          // one round, no sweep (the loop below stops in front of it)
+        if (mode == 5) ca.n_rounds = 0;          // straight to the final scan + sweep
+        ca.left_blocked = (mode == 4 && opt->chunk_flags) ? 1 : 0;
         if (resume && !opt->chunk_states)
             return fail(SEQIK_ERR_BAD_ARG, "chunk_resume needs the chunk_states of the call it resumes%s");
         // chunk 0 is verified (and repaired) like the others when it started from a run-in and the caller says what the
@@ -1426,7 +1448,8 @@ int launch(const double *d_pose, int64_t n_seq, int32_t n_legs, int64_t n_frames
         const dim3 scan_grid((unsigned)((n_vchains + 255) / 256)), scan_blk(256);
         const int64_t rep_waves = n_waves < 4096 ? n_waves : 4096;  // the work list is walked grid-stride
         const dim3 rep_grid((unsigned)((rep_waves * 64 + block - 1) / block));
-        for (int r = 0; r <= ca.n_rounds; ++r) {
+        for (int r = 0; r <= ca.n_rounds && mode != 3; ++r) {
+            if (mode == 4 && r == ca.n_rounds) break;   // lockstep round: the sweep is another call (chunk_resume = 5)
             ca.round = r;
             hipLaunchKernelGGL(seqik_chunk_scan_kernel, scan_grid, scan_blk, 0, stream, a, ca);
             if (r < ca.n_rounds && piped) {

@@ -52,12 +52,13 @@ class SeqikOptions(ctypes.Structure):
                 ("chunk_resume", ctypes.c_int32), ("pad2_", ctypes.c_int32)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 N_CHUNK_STATS = 16
 CHUNK_STATS_FIELDS = ("chunks", "frames_per_chunk", "run_in_frames", "repaired_round_1", "repaired_round_2",
                       "repaired_later_rounds", "repaired_by_sweep", "inconsistent_at_first_check",
                       "chains_walked_serially", "chunks_of_those_chains")
 CHUNK_FLAG_FAILED_FIRST, CHUNK_FLAG_REPAIRED, CHUNK_FLAG_SWEPT, CHUNK_FLAG_SERIAL = 1, 2, 4, 8
+CHUNK_FLAG_LEFT_BLOCKED = 0x80   # input of a lockstep round (chunk_resume = 4), see include/seqik.h
 
 
 def chunk_stats_dict(stats):

@@ -5,32 +5,37 @@ The reference walks a recording serially: frame t is warm-started from frame t-1
 (``seqikpy/leg_inverse_kinematics.py:259-282``, warm start ``:272``), so contiguous frame slabs on different ranks are
 coupled through one 7-angle state per leg at every slab boundary.  The scheme is the library's frame chunks
 (``SeqikOptions.frame_chunk``, include/seqik.h) with the slab boundaries on the SAME global chunk grid, so the ranks
-together do what one GPU does for the whole recording:
+together do what one GPU does for the whole recording.
+
+Protocol (LOCKSTEP, the default since round 6 -- the ranks run the pieces of ONE chunked call together):
 
 1. every rank hands its slab ``[a_r, b_r)`` (whole chunks) plus the ``lead = min(halo, a_r)`` frames in front of it to
-   ``seqik_solve_seq_device`` with ``frame_lead = lead``: all chunks of the slab -- the first one too -- start from a
-   run-in and are verified / repaired against their predecessor inside the slab on the rank's GPU; the start states
-   stay in a caller-owned buffer (``chunk_states``);
-2. the ranks all-gather their END states (the 7 angles of frame ``b_r - 1``: 56 bytes per leg and rank);
-3. every rank > 0 makes a ``chunk_resume`` call with the true end state of its left neighbour as ``init_angles``:
-   only verification runs, and a repair of the boundary chunk (and whatever it cascades into) if the run-in had not
-   reproduced that state to ``tol``.  If that changed the rank's own end state, steps 2-3 repeat (at most
-   ``world - 1`` times; never on well-posed data);
-4. one padded all-gather returns the joint angles of all frames to every rank -- over RCCL / xGMI the "final
-   joint-angle gather" of the north star.  The forward kinematics can be gathered the same way or stay sharded.
+   ``seqik_solve_seq_device`` with ``frame_lead = lead`` and ``chunk_resume = 3``: the speculative pass only -- all chunks of
+   the slab, the first one too, start from a run-in; the start states stay in a caller-owned buffer (``chunk_states``);
+2. the ranks all-gather the LAST FRAME of their slabs (7 angles: 56 bytes per leg and rank); every rank works out which of
+   its chunks are inconsistent now (chunk 0 against its left neighbour's last frame) and the ranks all-gather one byte per
+   leg: "my last chunk is inconsistent" / "some chunk of mine is";
+3. nothing inconsistent anywhere (the usual case): done.  Otherwise every rank runs ONE {scan, repair} round
+   (``chunk_resume = 4``): chunk 0 is verified against the left neighbour's current last frame and held back when that
+   neighbour's last chunk is itself inconsistent in this round -- exactly the "ready" rule of a round inside one call.
+   Back to 2, at most ``rounds`` (3) times;
+4. what is still inconsistent after that (a cascade longer than ``rounds``) is swept slab by slab, left to right
+   (``chunk_resume = 5``), each slab once the slab to its left is final -- the serial sweep of one call, cut at the slab edges;
+5. one padded all-gather returns the joint angles of all frames to every rank -- over RCCL / xGMI the "final joint-angle
+   gather" of the north star.  The forward kinematics can be gathered the same way or stay sharded.
 
-No collective runs while the kernels do.  Chunk k of the recording is solved from the same run-in, verified against
-the same predecessor and repaired from the same state as in a one-GPU call with the same (chunk, halo, tol): the
-result is that call's, bit for bit, on every recording in the tree as long as no chunk next to a rank boundary has to be
-REPAIRED (tests: world 2 / 3 / 8 against the one-rank result).  When one has -- a rank boundary across the anipose LF
-kinematic-singularity episode, frames 284-301 -- the one-rank call checks that chunk in its first round together with all the
-others and the sharded run after the exchange, so the chunk can be re-solved from a predecessor state that differs in the last
-bits.  Measured over boundaries swept across the episode at world 2 / 3 / 8 and four chunk geometries
-(tests/test_distributed_gloo.py::test_frame_sharding_across_a_singular_episode_is_bounded_not_bit_identical): three placements
-in four still give identical bits; the others stay within 1e-7 rad of the one-rank call OUTSIDE the episode (a tenth of the
-1e-6 rad every chunk start is allowed anyway, and as close to the serial walk), and differ by more only on the episode's own
-frames, where the leg has two configurations pi apart and the reference does not reproduce itself either.  The HIP path
-equals the model of the sharded run (tests/chunk_model.py::sharded_chunked_oracle) bit for bit in every case.
+No collective runs while the kernels do.  The ranks together execute the same sequence of solves, round by round, that one
+GPU executes for the whole recording with the same (chunk, halo, tol): **the result is that call's, bit for bit, whatever the
+number of ranks** -- also where repairs cascade across a rank boundary (tests: boundaries swept across the anipose LF
+kinematic-singularity episode at world 2 / 3 / 8 and four chunk geometries against the one-rank call, model on the CPU and HIP
+on the GPU: tests/test_distributed_gloo.py::test_frame_sharding_is_independent_of_the_number_of_ranks).
+
+``lockstep=False`` is the round-2 protocol: every slab runs a whole call for itself first (its first chunk unverified), the
+ranks exchange END states and every rank > 0 settles its boundary in a ``chunk_resume = 1`` call, repeated while end states
+change.  One exchange cheaper when a boundary chunk does need a repair -- but then a chunk behind a boundary is verified after
+the exchange instead of in round 1 and can be re-solved from a predecessor state that differs in the last bits: next to the
+LF episode three placements in four still give the one-rank call's bits, the others stay within 1e-7 rad of it outside the
+episode and differ by up to pi on the episode's own frames (the leg has two configurations there).
 The automatic mode's per-chain guard (chains with many inconsistent chunks walked serially) belongs to one-GPU calls;
 here the chunk geometry is fixed up front (``_lib.frame_chunk_plan`` of the whole recording) and explicit.
 
@@ -96,14 +101,18 @@ class DeviceSlab:
             self.d_fk = torch.zeros((self.S, self.L, self.n, 9, 3), dtype=torch.float64, device=self.dev) if want_fk else None
             self.d_states = torch.zeros((self.S, self.L, self.K, 7), dtype=torch.float64, device=self.dev)
             self.d_stats = torch.zeros(_lib.N_CHUNK_STATS, dtype=torch.int32, device=self.dev)
+            self.d_flags = torch.zeros((self.S, self.L, self.K), dtype=torch.uint8, device=self.dev)
         self.chunked = _lib.frame_chunk_plan(self.n, int(chunk), int(halo), self.lead)[2] > 0
         self.repaired = 0
+        self.C, self.tol = int(chunk), (float(tol) if tol > 0 else 0.0)
+        # last frame in front of chunk k (k >= 1) of the slab's buffers: lead + k C - 1
+        self._before = torch.arange(1, self.K, device=self.dev) * self.C + self.lead - 1
 
-    def _call(self, d_init=0, resume=0):
+    def _call(self, d_init=0, resume=0, flags=False):
         torch = self.torch
         with torch.cuda.device(self.dev):
             kw = dict(self.kw, frame_lead=self.lead, d_chunk_states=self.d_states.data_ptr(), chunk_resume=resume,
-                      d_chunk_stats=self.d_stats.data_ptr()) if self.chunked else {}
+                      d_chunk_stats=self.d_stats.data_ptr(), d_chunk_flags=self.d_flags.data_ptr() if flags else 0) if self.chunked else {}
             _lib.solve_seq_device(self.d_pose.data_ptr(), self.S, self.L, self.n, self.legs, self.d_ang.data_ptr(),
                                   self.d_fk.data_ptr() if self.want_fk else 0, d_init=d_init, affine=self.affine,
                                   layout=self.layout, stream=torch.cuda.current_stream(self.dev).cuda_stream, **kw)
@@ -120,6 +129,53 @@ class DeviceSlab:
         self._left = left_state.to(self.dev).contiguous()
         self._call(d_init=self._left.data_ptr(), resume=2 if exact else 1)
         st = self.d_stats.cpu().numpy()      # blocking read: the speculative pass and this resume call have finished
+        self._check_stream_faults()
+        self.repaired += int(st[3:7].sum())
+
+    # ---- lockstep pieces of ONE chunked call (SeqikOptions.chunk_resume = 3 / 4 / 5, include/seqik.h) ------------------------------
+    def speculate_only(self):
+        """The speculative pass alone (no repair round, no sweep): every chunk of the slab from its run-in."""
+        self.repaired = 0
+        self._call(resume=3 if self.chunked else 0)
+
+    def inc_flags(self, left_state=None):
+        """(S, L, K) bool on the GPU: which chunks are inconsistent NOW -- the state chunk k was started from against the current
+        last frame in front of it; chunk 0 against `left_state` (S, L, 7), the current last frame of the slab to the left (never
+        on the first slab).  The library's own test (chunk_inconsistent in seqik_hip.hip), NaN counting as a mismatch."""
+        torch = self.torch
+        inc = torch.zeros((self.S, self.L, self.K), dtype=torch.bool, device=self.dev)
+        if not self.chunked:
+            return inc
+        if self.K > 1:
+            before = self.d_ang[:, :, :, self._before].permute(0, 1, 3, 2)                      # (S, L, K - 1, 7)
+            inc[:, :, 1:] = ~((self.d_states[:, :, 1:] - before).abs() <= self.tol).all(-1)
+        if left_state is not None:
+            inc[:, :, 0] = ~((self.d_states[:, :, 0] - left_state.to(self.dev)).abs() <= self.tol).all(-1)
+        return inc
+
+    def one_round(self, left_state=None, left_blocked=None):
+        """ONE {scan, repair} round.  `left_blocked` (S, L) bool: the last chunk of the slab to the left is itself inconsistent in
+        this round, so an inconsistent chunk 0 waits (its predecessor is about to change), as inside one call."""
+        if not self.chunked:
+            return
+        if left_state is not None:
+            self._left = left_state.to(self.dev).contiguous()
+            if left_blocked is not None:
+                self.d_flags[:, :, 0] |= left_blocked.to(self.dev).to(self.torch.uint8) * _lib.CHUNK_FLAG_LEFT_BLOCKED
+        self._call(d_init=self._left.data_ptr() if left_state is not None else 0, resume=4, flags=True)
+        self._after_repairs()
+
+    def sweep_only(self, left_state=None):
+        """The final scan + serial sweep; `left_state` must be FINAL (the slab to the left has been swept)."""
+        if not self.chunked:
+            return
+        if left_state is not None:
+            self._left = left_state.to(self.dev).contiguous()
+        self._call(d_init=self._left.data_ptr() if left_state is not None else 0, resume=5, flags=True)
+        self._after_repairs()
+
+    def _after_repairs(self):
+        st = self.d_stats.cpu().numpy()      # blocking read: the call has finished (repairs are the rare path)
         self._check_stream_faults()
         self.repaired += int(st[3:7].sum())
 
@@ -157,7 +213,7 @@ class FrameShardedRecording:
 
     def __init__(self, pose: np.ndarray, legs: List, chunk: Optional[int] = None, halo: Optional[int] = None,
                  tol: float = 1e-6, want_fk: bool = True, affine=None, device: int = -1, group=None,
-                 slab_factory: Optional[Callable] = None):
+                 slab_factory: Optional[Callable] = None, lockstep: bool = True, rounds: int = 3):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
@@ -184,6 +240,11 @@ class FrameShardedRecording:
         self.coll_dev = (self.slab.dev if (self.slab is not None and hasattr(self.slab, "dev")) else
                          torch.device("cuda", torch.cuda.current_device())) if on_gpu else torch.device("cpu")
         self.stats: Dict = {}
+        #: True (default since round 6): the ranks run the rounds of ONE chunked call together (`_solve_lockstep`): the result is the
+        #: one-GPU call's bit for bit whatever the number of ranks.  False: the round-2 protocol (every slab settles itself, then
+        #: its boundary in resume calls): one exchange fewer when nothing needs a repair, but next to a singular episode the bits
+        #: can depend on where the rank boundaries fall (module docstring)
+        self.lockstep, self.rounds = bool(lockstep), int(rounds)
         #: set to a list to have solve() append a (start, end) pair of HIP events around each speculative pass
         self.spec_events: Optional[list] = None
 
@@ -195,9 +256,78 @@ class FrameShardedRecording:
         dist.all_gather(ends, mine, group=self.group)
         return ends
 
+    def _speculate(self, only: bool):
+        torch = self.torch
+        if self.slab is None:
+            return
+        run = self.slab.speculate_only if only else self.slab.speculate
+        if self.spec_events is not None and hasattr(self.slab, "dev"):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            self.spec_events.append((e0, e1))
+        else:
+            run()
+
+    def _exchange(self):
+        """-> (this rank's left neighbour's current last frame or None, (S, L) bool "its last chunk is inconsistent now", this
+        rank's own (S, L, K) inconsistency flags, "some chunk of some rank is inconsistent").  Two small all-gathers: the last
+        frames (56 B per leg and rank), then what every rank makes of them (one byte per leg and rank)."""
+        torch, dist = self.torch, self.dist
+        ends = self._gather_ends()
+        left = ends[self.left_of] if (self.slab is not None and self.left_of is not None) else None
+        inc = self.slab.inc_flags(left) if self.slab is not None else None
+        mine = torch.zeros((self.S, self.L), dtype=torch.uint8)
+        if inc is not None:
+            mine = inc[:, :, -1].to(torch.uint8) | (inc.any(-1).to(torch.uint8) << 1)    # bit 0: my last chunk, bit 1: any chunk of mine
+        mine = mine.to(self.coll_dev).contiguous()
+        flags = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(flags, mine, group=self.group)
+        any_inc = any(bool((f & 2).any().item()) for f in flags)
+        blocked = (flags[self.left_of] & 1).bool() if left is not None else None
+        return left, blocked, any_inc
+
+    def _solve_lockstep(self):
+        """The rounds of ONE chunked call, run by all ranks together (SeqikOptions.chunk_resume = 3 / 4 / 5): speculative pass ->
+        up to `rounds` x {exchange, one {scan, repair} round on every slab} while anything is inconsistent anywhere -> exchange
+        -> if something still is: sweep slab by slab, left to right.  == tests/chunk_model.py::lockstep_sharded_oracle."""
+        dist = self.dist
+        self._speculate(only=True)
+        done, calls, swept = 0, 0, False
+        for _ in range(self.rounds):
+            left, blocked, any_inc = self._exchange()
+            if not any_inc:
+                break
+            if self.slab is not None:
+                self.slab.one_round(left, blocked)
+                calls += 1
+            done += 1
+        else:
+            left, blocked, any_inc = self._exchange()
+        if any_inc:   # rare: a cascade longer than `rounds`; a slab may be swept once the slab to its left is final
+            swept = True
+            for r in range(self.world):
+                if r == self.rank and self.slab is not None:
+                    self.slab.sweep_only(left)
+                    calls += 1
+                if r + 1 < self.world:
+                    ends = self._gather_ends()      # (every rank takes part; only the right neighbour of r uses r's new end)
+                    if self.slab is not None and self.left_of == r:
+                        left = ends[r]
+        self.stats = dict(slab=(self.a, self.b), lead=self.lead, chunk=self.C, halo=self.h, boundary_rounds=done, resume_calls=calls,
+                          swept=swept, protocol="lockstep",
+                          chunks_repaired_after_exchange=getattr(self.slab, "repaired", 0) if self.slab is not None else 0)
+
     def solve(self, gather_fk: Optional[bool] = None):
         """-> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) as tensors on every rank (on the GPU under RCCL)."""
         torch, dist = self.torch, self.dist
+        if self.lockstep and self.world > 1:
+            self._solve_lockstep()
+            if gather_fk is None:
+                gather_fk = self.want_fk
+            return dict(angles=self._gather(lambda s: s.angles(), (7,)),
+                        fk=self._gather(lambda s: s.fk(), (9, 3)) if (self.want_fk and gather_fk) else None)
         if self.slab is not None:
             if self.spec_events is not None and hasattr(self.slab, "dev"):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -263,11 +393,11 @@ class FrameShardedRecording:
 
 def solve_frame_sharded(pose: np.ndarray, legs: List, chunk: Optional[int] = None, halo: Optional[int] = None,
                         tol: float = 1e-6, want_fk: bool = True, affine=None, device: int = -1, group=None,
-                        stats: Optional[Dict] = None, slab_factory: Optional[Callable] = None):
+                        stats: Optional[Dict] = None, slab_factory: Optional[Callable] = None, lockstep: bool = True):
     """``pose`` (S, L, N, 5, 3) -> dict(angles (S, L, N, 7), fk (S, L, N, 9, 3) or None) as numpy arrays on every rank.
     ``chunk`` / ``halo`` None: the library's automatic geometry for a recording of N frames.  Needs an initialised
     ``torch.distributed`` process group when there is more than one rank ("nccl" = RCCL on the GPUs, "gloo" in tests)."""
-    rec = FrameShardedRecording(pose, legs, chunk, halo, tol, want_fk, affine, device, group, slab_factory)
+    rec = FrameShardedRecording(pose, legs, chunk, halo, tol, want_fk, affine, device, group, slab_factory, lockstep=lockstep)
     out = rec.solve()
     rec.check_faults()
     if stats is not None:

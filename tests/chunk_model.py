@@ -112,6 +112,91 @@ class ChunkedChain:
         return self
 
 
+    # ---- lockstep pieces of one call (chunk_resume = 3 / 4 / 5): a slab of a recording whose other slabs live on other GPUs ----
+    def k_first(self):
+        return 0 if self.init is not None else 1
+
+    def inc_flags(self, init=None):
+        """bool[K]: which chunks are inconsistent now (chunk 0 against `init`, the current last frame of the slab to the left;
+        never on the first slab)."""
+        if init is not None:
+            self.init = init
+        return np.array([k >= self.k_first() and self._inconsistent(k) for k in range(self.K)])
+
+    def speculate_only(self):
+        """chunk_resume = 3: the speculative pass (and the first verification's statistics, which the result does not need)."""
+        self.speculate()
+        self.flags[:] = 0
+        return self
+
+    def one_round(self, init=None, left_blocked=False):
+        """chunk_resume = 4: ONE {scan, repair} round; chunk 0 is held back when the last chunk of the slab to the left is itself
+        inconsistent in this round (its end state is about to change)."""
+        inc = self.inc_flags(init)
+        kf = self.k_first()
+        ready = [k for k in range(kf, self.K) if inc[k] and not (k > kf and inc[k - 1])]
+        if left_blocked and kf == 0 and 0 in ready:
+            ready.remove(0)
+        for k in ready:
+            self._solve(k, True, REPAIRED)
+        return len(ready)
+
+    def sweep_only(self, init=None):
+        """chunk_resume = 5: left to right, every chunk that is still inconsistent is re-solved from the final state in front of it."""
+        if init is not None:
+            self.init = init
+        n = 0
+        for k in range(self.k_first(), self.K):
+            if self._inconsistent(k):
+                self._solve(k, True, SWEPT)
+                n += 1
+        return n
+
+
+def lockstep_sharded_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, world, tol=1e-6, rounds=3):
+    """One chain of ONE recording sharded by frame over `world` ranks, LOCKSTEP protocol of seqikpy_amd.frame_sharding (round 6):
+    every slab speculates; then, as long as some chunk anywhere is inconsistent and fewer than `rounds` rounds have run, the
+    slabs exchange (last frame, "my last chunk is inconsistent") and run ONE {scan, repair} round each; what is still
+    inconsistent after that is swept slab by slab, left to right.  By construction the sequence of solves one GPU runs for the
+    whole recording -> the one-rank result bit for bit.  -> dict(angles, fk, rounds, swept)."""
+    N = pose.shape[0]
+    n_chunks = -(-N // chunk)
+
+    def part(r):
+        base, rem = divmod(n_chunks, world)
+        a = r * base + min(r, rem)
+        return a, a + base + (1 if r < rem else 0)
+    slabs = [(min(part(r)[0] * chunk, N), min(part(r)[1] * chunk, N)) for r in range(world)]
+    owners = [r for r, (a, b) in enumerate(slabs) if b > a]
+    models = {}
+    for i, r in enumerate(owners):
+        a, b = slabs[r]
+        lead = min(halo, a) if i > 0 else 0
+        models[r] = (ChunkedChain(oracle, pose[a - lead:b], seg, bounds, seeds, chunk, halo, tol=tol, lead=lead).speculate_only(), lead)
+    left_of = {r: (owners[i - 1] if i > 0 else None) for i, r in enumerate(owners)}
+    done_rounds, swept = 0, 0
+
+    def exchange():
+        ends = {r: models[r][0].angles[-1].copy() for r in owners}
+        incs = {r: models[r][0].inc_flags(ends[left_of[r]].copy() if left_of[r] is not None else None) for r in owners}
+        return ends, incs
+    for _ in range(rounds):
+        ends, incs = exchange()
+        if not any(v.any() for v in incs.values()):
+            break
+        for r in owners:
+            lf = left_of[r]
+            models[r][0].one_round(ends[lf].copy() if lf is not None else None, left_blocked=bool(incs[lf][-1]) if lf is not None else False)
+        done_rounds += 1
+    ends, incs = exchange()
+    if any(v.any() for v in incs.values()):
+        for r in owners:                      # left to right: a slab is swept once the slab to its left is final
+            lf = left_of[r]
+            swept += models[r][0].sweep_only(models[lf][0].angles[-1].copy() if lf is not None else None)
+    return dict(angles=np.concatenate([models[r][0].angles[models[r][1]:] for r in owners]),
+                fk=np.concatenate([models[r][0].fk[models[r][1]:] for r in owners]), rounds=done_rounds, swept=swept, slabs=slabs)
+
+
 def chunked_oracle(oracle, pose, seg, bounds, seeds, chunk, halo, tol=1e-6, rounds=3, init=None, guard=False):
     """One chain: pose (N, 5, 3) -> dict(angles (N, 7), fk (N, 9, 3), stats int32[16], flags uint8[K]) (as chunk_stats /
     chunk_flags)."""

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     assert sorted(hiplib.EXPORTED_SYMBOLS) == declared_functions()
-    assert lib.seqik_abi_version() == 6 == hiplib.ABI_VERSION
+    assert lib.seqik_abi_version() == 7 == hiplib.ABI_VERSION
 
 
 def test_struct_layout_matches_header(hiplib):
