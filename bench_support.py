@@ -188,7 +188,8 @@ def queue_candidates(chains):
         return []
     # (pool 0 = the plain kernel one and two steps deeper than the depth-3 candidate: 11.28 against 11.48 ms per step at depth 4
     # over 100 steps, profiles/r05_n1_streams.jsonl)
-    return [c for c in ((4, 0), (5, 0), (4, 128), (6, 128), (12, 256)) if c[0] <= MAX_DEPTH]
+    # ((4, 128) -- too few wavefronts in flight -- measured 13.6 ms against 11.7 and was dropped from the list)
+    return [c for c in ((4, 0), (5, 0), (6, 128), (12, 256)) if c[0] <= MAX_DEPTH]
 
 
 def depth_cap(chains):
